@@ -1,0 +1,161 @@
+/*
+ * memb_hip.h -- C ABI of the MI355X (gfx950) batch-lookup path of memb.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types, no exceptions. It replaces, for a whole batch at once, what the
+ * reference does per word behind its plugin interface
+ *     CompressedStorage::extract(word, float*)      reference src/compression_strategy.h:7-12
+ * namely
+ *     TrainedCompressedStorage::extract              reference src/trained_compression.cpp:113-140
+ *       HuffmanTableDecoder::next / BitStreamReader::pull
+ *                                                    reference src/huffman_table_decoder.h:102-118,
+ *                                                    reference src/bit_stream_reader.h:16-31
+ *     UniformCompressedStorage::extract              reference src/uniform_compression.cpp:54-77
+ *     FullCompressedStorage::extract                 reference src/full_compression.cpp:37-47
+ *     the zero fill of a missing word                reference src/reader.cpp:41-47
+ * and the batch driver Reader::batchEmbeddingToBuffer (reference src/reader.cpp:59-86).
+ *
+ * The caller (memb::Reader in memb_amd/csrc/reader.cpp, or any other host
+ * language through its FFI -- see INTEGRATION.md) resolves word -> row on the
+ * host and hands over row ids; row id MEMB_HIP_MISSING_ROW produces a zero row.
+ *
+ * Every function returns 0 on success and a non-zero code on failure;
+ * memb_hip_last_error() returns the message for the calling thread.
+ * There is no CPU fallback: without a usable HIP device every decode entry
+ * point fails.
+ */
+#ifndef MEMB_HIP_H
+#define MEMB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEMB_HIP_MISSING_ROW 0xFFFFFFFFu
+
+#define MEMB_HIP_OK 0
+#define MEMB_HIP_ERR_INVALID 1   /* bad argument or inconsistent storage description */
+#define MEMB_HIP_ERR_DEVICE 2    /* HIP runtime error (no device, out of memory, launch failure) */
+
+typedef struct memb_hip_ctx memb_hip_ctx;
+
+/*
+ * `trained` storage (reference src/flatbuffers/trained_compression.fbs:6-13), as
+ * host pointers into the mapped file. Row r is the r-th word in sorted order;
+ * its bitstream starts, byte aligned, at packed_values + value_offsets[r]
+ * (reference src/trained_compression.cpp:126-131).
+ */
+typedef struct memb_hip_trained_desc {
+    uint32_t dim;
+    uint64_t n_rows;
+    const uint8_t* packed_values;
+    uint64_t packed_values_bytes;
+    const uint32_t* value_offsets;   /* [n_rows] */
+    const uint8_t* keys;             /* symbols by increasing code length (huffman_decoder.fbs:4) */
+    uint32_t n_keys;
+    const uint32_t* size_offsets;    /* size_offsets[k] = #symbols with length <= k (huffman_decoder.fbs:5) */
+    uint32_t n_size_offsets;
+    const float* centroids;          /* k-means codebook (kmeans.fbs:4) */
+    uint32_t n_centroids;
+    /*
+     * Upper bound on the bits resolved by the first-level lookup table, the
+     * counterpart of maxDirectDecodeBitLength (reference
+     * src/trained_compression.h:11-16). 0 selects the library default. Results
+     * do not depend on it; small values force the two-level path, which is how
+     * the reference tests that branch (reference src/tests.cpp:76-88).
+     */
+    uint32_t max_direct_bits;
+} memb_hip_trained_desc;
+
+/* One row of `uniform` storage (uniform_compression.fbs:3-12). */
+typedef struct memb_hip_uniform_row {
+    const uint8_t* values;   /* n_values quantised weights, one byte each */
+    uint32_t n_values;
+    float min_value;
+    float max_value;
+} memb_hip_uniform_row;
+
+typedef struct memb_hip_uniform_desc {
+    uint32_t dim;
+    uint64_t n_rows;
+    const memb_hip_uniform_row* rows;   /* [n_rows], sorted-word order */
+    uint8_t quantization_levels;        /* uniform_compression.fbs:16 */
+} memb_hip_uniform_desc;
+
+/* One row of `full` storage (full_compression.fbs:3-6). */
+typedef struct memb_hip_full_row {
+    const float* values;
+    uint32_t n_values;
+} memb_hip_full_row;
+
+typedef struct memb_hip_full_desc {
+    uint32_t dim;
+    uint64_t n_rows;
+    const memb_hip_full_row* rows;
+} memb_hip_full_desc;
+
+/* Facts about a context, for reporting (bench.py) and tests. */
+typedef struct memb_hip_ctx_info {
+    int32_t device;
+    uint32_t storage;            /* 1 full, 2 uniform, 3 trained (wire::Storage tags) */
+    uint32_t dim;
+    uint64_t n_rows;
+    uint64_t device_bytes;       /* HBM held by the context */
+    uint32_t root_bits;          /* trained: first-level table bits */
+    uint32_t max_code_bits;      /* trained: longest Huffman code */
+    uint32_t table_entries;      /* trained: entries of the device lookup table */
+    uint32_t max_stream_bytes;   /* trained: longest per-word bitstream */
+    uint32_t waves_per_block;    /* launch geometry chosen for the decode kernel */
+    uint32_t chunk_symbols;
+    uint32_t lds_bytes_per_block;
+} memb_hip_ctx_info;
+
+int memb_hip_device_count(int* count);
+
+/*
+ * Stage a storage to HBM on `device` (copied once; the host memory may be
+ * unmapped afterwards). One context per (Reader, device).
+ */
+int memb_hip_ctx_create_trained(memb_hip_ctx** ctx, int device, const memb_hip_trained_desc* desc);
+int memb_hip_ctx_create_uniform(memb_hip_ctx** ctx, int device, const memb_hip_uniform_desc* desc);
+int memb_hip_ctx_create_full(memb_hip_ctx** ctx, int device, const memb_hip_full_desc* desc);
+void memb_hip_ctx_destroy(memb_hip_ctx* ctx);
+
+int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
+
+/*
+ * Batch lookup, host buffers (the reference's calling convention: caller-owned
+ * output, fully overwritten, reference src/reader.cpp:41-57). Writes row i of
+ * the batch to out[i * ld + col_off .. + dim); ld >= col_off + dim. Synchronous.
+ */
+int memb_hip_decode_rows(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off);
+
+/*
+ * Batch lookup, device buffers: `rows` and `out` are device pointers on the
+ * context's device; the kernel is enqueued on `stream` (a hipStream_t, NULL =
+ * the context's own stream) and the call returns without waiting.
+ */
+int memb_hip_decode_rows_device(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream);
+
+/* Wait for everything enqueued on the context's own stream. */
+int memb_hip_sync(memb_hip_ctx* ctx);
+
+/*
+ * Algorithmic bytes moved for a batch: per row the row id,
+ * the row's index entry, its compressed payload and the fp32 row written;
+ * a missing row counts the id and the zero row.
+ */
+int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes);
+
+const char* memb_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MEMB_HIP_H */

@@ -1,0 +1,217 @@
+// pybind11 module `_memb`: the reference's binding surface
+// (python/memb_bindings.cpp:11-72) -- Reader(filename, num_threads) with
+// dim / word_embedding / batch_embedding / keys, Builder(dim, storage, bits)
+// with add_word / save, available_compression_strategies() -- plus additions
+// for device-resident results and strided (concatenated) outputs.
+#include "builder.h"
+#include "reader.h"
+#include "compression_strategy.h"
+
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <pybind11/numpy.h>
+
+namespace py = pybind11;
+
+namespace {
+
+std::shared_ptr<memb::Reader> makeReader(
+    const std::string& filename, size_t numThreads, int device, size_t maxDirectDecodeBits)
+{
+    if (maxDirectDecodeBits == 0) {
+        return std::make_shared<memb::Reader>(filename, numThreads, device);
+    }
+    // the reference's test hook: a trained strategy with a short first-level
+    // table, injected through the second Reader constructor (src/tests.cpp:76-88)
+    return std::make_shared<memb::Reader>(
+        filename, std::make_shared<memb::TrainedCompressionStrategy>(maxDirectDecodeBits), numThreads, device);
+}
+
+py::dict contextInfo(memb::Reader& reader)
+{
+    memb_hip_ctx_info info;
+    if (memb_hip_ctx_get_info(reader.deviceContext(), &info) != MEMB_HIP_OK) {
+        throw std::runtime_error(memb_hip_last_error());
+    }
+    py::dict result;
+    result["device"] = info.device;
+    result["storage"] = info.storage;
+    result["dim"] = info.dim;
+    result["n_rows"] = info.n_rows;
+    result["device_bytes"] = info.device_bytes;
+    result["root_bits"] = info.root_bits;
+    result["max_code_bits"] = info.max_code_bits;
+    result["table_entries"] = info.table_entries;
+    result["max_stream_bytes"] = info.max_stream_bytes;
+    result["waves_per_block"] = info.waves_per_block;
+    result["chunk_symbols"] = info.chunk_symbols;
+    result["lds_bytes_per_block"] = info.lds_bytes_per_block;
+    return result;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_memb, m) {
+    py::class_<memb::Builder>(m, "Builder")
+        .def(py::init<size_t, const std::string&, size_t>())
+        .def(
+            "add_word",
+            [](memb::Builder& builder, const std::string& word, py::array_t<float, py::array::c_style> values)
+            {
+                auto valuesBuffer = values.request();
+                if (valuesBuffer.ndim != 1) {
+                    throw std::runtime_error("Word vector must be 1-dimensional");
+                }
+                builder.addWord(
+                    word, reinterpret_cast<const float*>(valuesBuffer.ptr), static_cast<size_t>(valuesBuffer.shape[0]));
+            })
+        .def(
+            "add_words",
+            [](memb::Builder& builder,
+               const std::vector<std::string>& words,
+               py::array_t<float, py::array::c_style | py::array::forcecast> matrix)
+            {
+                auto buffer = matrix.request();
+                if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size()) {
+                    throw std::runtime_error("Expected a matrix with one row per word");
+                }
+                const float* values = reinterpret_cast<const float*>(buffer.ptr);
+                size_t dim = static_cast<size_t>(buffer.shape[1]);
+                for (size_t i = 0; i < words.size(); ++i) {
+                    builder.addWord(words[i], values + i * dim, dim);
+                }
+            })
+        .def(
+            "save",
+            [](memb::Builder& builder, const std::string& filename)
+            {
+                py::gil_scoped_release release;
+                builder.save(filename);
+            });
+
+    py::class_<memb::Reader, std::shared_ptr<memb::Reader>>(m, "Reader")
+        .def(py::init([](const std::string& filename, size_t numThreads) {
+            return makeReader(filename, numThreads, -1, 0);
+        }))
+        .def(
+            py::init([](const std::string& filename, size_t numThreads, int device, size_t maxDirectDecodeBits) {
+                return makeReader(filename, numThreads, device, maxDirectDecodeBits);
+            }),
+            py::arg("filename"),
+            py::arg("num_threads"),
+            py::arg("device"),
+            py::arg("max_direct_decode_bits") = 0)
+        .def("dim", [](memb::Reader& reader) { return reader.dim(); })
+        .def(
+            "word_embedding",
+            [](memb::Reader& reader, const std::string& word)
+            {
+                py::array_t<float> result(reader.dim());
+                auto buffer = result.request();
+                reader.wordEmbeddingToBuffer(word, reinterpret_cast<float*>(buffer.ptr));
+                return result;
+            })
+        .def(
+            "batch_embedding",
+            [](memb::Reader& reader, const std::vector<std::string>& words)
+            {
+                py::array_t<float> result({words.size(), reader.dim()});
+                auto buffer = result.request();
+                float* destination = reinterpret_cast<float*>(buffer.ptr);
+                {
+                    py::gil_scoped_release release;
+                    reader.batchEmbeddingToBuffer(words, destination);
+                }
+                return result;
+            })
+        .def("keys", [](memb::Reader& reader) { return reader.keys(); })
+        // ---- additions ----
+        .def("size", [](memb::Reader& reader) { return reader.size(); })
+        .def("device", [](memb::Reader& reader) { return reader.device(); })
+        .def("storage_name", [](memb::Reader& reader) { return reader.storageName(); })
+        .def("info", &contextInfo)
+        .def(
+            "context_handle",
+            [](memb::Reader& reader) { return reinterpret_cast<uintptr_t>(reader.deviceContext()); })
+        .def(
+            "resolve_rows",
+            [](memb::Reader& reader, const std::vector<std::string>& words)
+            {
+                py::array_t<uint32_t> rows(words.size());
+                auto buffer = rows.request();
+                uint32_t* destination = reinterpret_cast<uint32_t*>(buffer.ptr);
+                {
+                    py::gil_scoped_release release;
+                    reader.resolveRows(words, destination);
+                }
+                return rows;
+            })
+        .def(
+            "batch_embedding_into",
+            [](memb::Reader& reader,
+               const std::vector<std::string>& words,
+               py::array_t<float, py::array::c_style> out,
+               size_t colOff)
+            {
+                auto buffer = out.request(true);
+                if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size() ||
+                    static_cast<size_t>(buffer.shape[1]) < colOff + reader.dim()) {
+                    throw std::runtime_error("Output must be a (len(words), >= col_off + dim) float32 matrix");
+                }
+                float* destination = reinterpret_cast<float*>(buffer.ptr);
+                size_t ld = static_cast<size_t>(buffer.shape[1]);
+                py::gil_scoped_release release;
+                reader.batchEmbeddingToStridedBuffer(words, destination, ld, colOff);
+            })
+        .def(
+            "rows_embedding",
+            [](memb::Reader& reader, py::array_t<uint32_t, py::array::c_style | py::array::forcecast> rows)
+            {
+                auto rowsBuffer = rows.request();
+                if (rowsBuffer.ndim != 1) {
+                    throw std::runtime_error("Row ids must be 1-dimensional");
+                }
+                size_t n = static_cast<size_t>(rowsBuffer.shape[0]);
+                py::array_t<float> result({n, reader.dim()});
+                auto buffer = result.request();
+                float* destination = reinterpret_cast<float*>(buffer.ptr);
+                const uint32_t* source = reinterpret_cast<const uint32_t*>(rowsBuffer.ptr);
+                {
+                    py::gil_scoped_release release;
+                    reader.rowsToBuffer(source, n, destination, reader.dim(), 0);
+                }
+                return result;
+            })
+        .def(
+            "rows_to_device",
+            [](memb::Reader& reader,
+               uintptr_t rows,
+               size_t n,
+               uintptr_t out,
+               size_t ld,
+               size_t colOff,
+               uintptr_t stream)
+            {
+                reader.rowsToDeviceBuffer(
+                    reinterpret_cast<const uint32_t*>(rows),
+                    n,
+                    reinterpret_cast<float*>(out),
+                    ld,
+                    colOff,
+                    reinterpret_cast<void*>(stream));
+            },
+            py::arg("rows_ptr"),
+            py::arg("n"),
+            py::arg("out_ptr"),
+            py::arg("ld"),
+            py::arg("col_off") = 0,
+            py::arg("stream") = 0);
+
+    m.def("available_compression_strategies", &memb::availableCompressionStrategies);
+
+    m.def("hip_device_count", []() {
+        int count = 0;
+        memb_hip_device_count(&count);
+        return count;
+    });
+}

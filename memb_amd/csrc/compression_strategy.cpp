@@ -1,0 +1,648 @@
+#include "compression_strategy.h"
+#include "codec.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <thread>
+
+namespace memb {
+
+namespace {
+
+const std::string INVALID_STRATEGY_PREFIX = "Storage strategy ";  // reference src/compression_strategy.cpp:11
+const std::string INVALID_STRATEGY_SUFFIX = " is not supported";
+
+const std::vector<std::shared_ptr<CompressionStrategy>>& compressionStrategies()
+{
+    // same order as the reference registry (src/compression_strategy.cpp:13-18)
+    static const std::vector<std::shared_ptr<CompressionStrategy>> strategies = {
+        std::make_shared<FullCompressionStrategy>(),
+        std::make_shared<UniformCompressionStrategy>(),
+        std::make_shared<TrainedCompressionStrategy>(),
+    };
+    return strategies;
+}
+
+[[noreturn]] void throwDeviceError(const char* what)
+{
+    throw std::runtime_error(std::string(what) + ": " + memb_hip_last_error());
+}
+
+uint8_t quantizationLevelsFor(size_t bitsPerWeight)
+{
+    // reference src/trained_compression.cpp:29, src/uniform_compression.cpp:7
+    size_t levels = bitsPerWeight >= 8 ? 256 : (size_t(1) << bitsPerWeight);
+    return static_cast<uint8_t>(std::min<size_t>(levels, 255));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// CompressedStorage: device context handling shared by all storages
+// ---------------------------------------------------------------------------
+
+CompressedStorage::~CompressedStorage()
+{
+    if (context_) {
+        memb_hip_ctx_destroy(context_);
+    }
+}
+
+void CompressedStorage::setDevice(int device)
+{
+    std::lock_guard<std::mutex> lock(contextMutex_);
+    if (context_ && device != device_) {
+        memb_hip_ctx_destroy(context_);
+        context_ = nullptr;
+    }
+    device_ = device;
+}
+
+memb_hip_ctx* CompressedStorage::deviceContext() const
+{
+    std::lock_guard<std::mutex> lock(contextMutex_);
+    if (!context_) {
+        context_ = createDeviceContext(device_);
+    }
+    return context_;
+}
+
+void CompressedStorage::decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const
+{
+    if (memb_hip_decode_rows(deviceContext(), rows, n, out, ld, colOff) != MEMB_HIP_OK) {
+        throwDeviceError("HIP batch lookup failed");
+    }
+}
+
+void CompressedStorage::decodeRowsDevice(
+    const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream) const
+{
+    if (memb_hip_decode_rows_device(deviceContext(), rows, n, out, ld, colOff, stream) != MEMB_HIP_OK) {
+        throwDeviceError("HIP batch lookup failed");
+    }
+}
+
+bool CompressedStorage::extract(const std::string& word, float* destination) const
+{
+    uint32_t row = MEMB_HIP_MISSING_ROW;
+    if (!resolve(word.c_str(), &row)) {
+        return false;
+    }
+    decodeRows(&row, 1, destination, dim(), 0);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Registry (reference src/compression_strategy.cpp:24-78)
+// ---------------------------------------------------------------------------
+
+std::shared_ptr<CompressionStrategy> createCompressionStrategy(wire::Storage storage)
+{
+    for (const auto& strategy : compressionStrategies()) {
+        if (strategy->storageType() == storage) {
+            return strategy;
+        }
+    }
+    throw std::runtime_error(INVALID_STRATEGY_PREFIX + std::to_string(storage) + INVALID_STRATEGY_SUFFIX);
+}
+
+std::shared_ptr<CompressionStrategy> createCompressionStrategy(const std::string& name)
+{
+    for (const auto& strategy : compressionStrategies()) {
+        if (strategy->storageName() == name) {
+            return strategy;
+        }
+    }
+    throw std::runtime_error(INVALID_STRATEGY_PREFIX + name + INVALID_STRATEGY_SUFFIX);
+}
+
+std::vector<std::string> availableCompressionStrategies()
+{
+    std::vector<std::string> result;
+    for (const auto& strategy : compressionStrategies()) {
+        result.push_back(strategy->storageName());
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// trained
+// ---------------------------------------------------------------------------
+
+namespace {
+
+class TrainedCompressedStorage : public CompressedStorage {
+public:
+    TrainedCompressedStorage(const wire::TableView& flatStorage, size_t dim, size_t maxDirectDecodeBitLength):
+        dim_(dim),
+        maxDirectDecodeBitLength_(maxDirectDecodeBitLength)
+    {
+        wordOffsets_ = flatStorage.vector<uint32_t>(wire::field::Trained_word_offsets);
+        valueOffsets_ = flatStorage.vector<uint32_t>(wire::field::Trained_value_offsets);
+        packedWords_ = flatStorage.string(wire::field::Trained_packed_words);
+        packedValues_ = flatStorage.vector<uint8_t>(wire::field::Trained_packed_values);
+        wire::TableView decoder = flatStorage.table(wire::field::Trained_decoder);
+        keys_ = decoder.vector<uint8_t>(wire::field::HuffmanDecoder_keys);
+        sizeOffsets_ = decoder.vector<uint32_t>(wire::field::HuffmanDecoder_size_offsets);
+        wire::TableView clusterizer = flatStorage.table(wire::field::Trained_clusterizer);
+        centroids_ = clusterizer.vector<float>(wire::field::KMeansClusterizer_centroids);
+
+        if (valueOffsets_.size != wordOffsets_.size) {
+            throw std::runtime_error(wire::VERIFICATION_FAILED);
+        }
+        // every word must start inside packed_words, which ends with a NUL
+        for (uint32_t offset : wordOffsets_) {
+            if (offset > packedWords_.size) {
+                throw std::runtime_error(wire::VERIFICATION_FAILED);
+            }
+        }
+    }
+
+    size_t dim() const override { return dim_; }
+    size_t rowCount() const override { return wordOffsets_.size; }
+
+    // reference src/trained_compression.cpp:115-125: lower_bound with strcmp
+    // over the NUL separated sorted words. The reference dereferences the
+    // result even when it is end(); here that is a miss.
+    bool resolve(const char* word, uint32_t* row) const override
+    {
+        const char* words = packedWords_.data;
+        const uint32_t* first = wordOffsets_.begin();
+        const uint32_t* last = wordOffsets_.end();
+        const uint32_t* it = std::lower_bound(
+            first, last, word, [words](uint32_t offset, const char* w) { return std::strcmp(words + offset, w) < 0; });
+        if (it == last || std::strcmp(words + *it, word) != 0) {
+            return false;
+        }
+        *row = static_cast<uint32_t>(it - first);
+        return true;
+    }
+
+    std::vector<std::string> keys() const override
+    {
+        std::vector<std::string> result;
+        result.reserve(wordOffsets_.size);
+        for (uint32_t offset : wordOffsets_) {
+            result.emplace_back(packedWords_.data + offset);
+        }
+        return result;
+    }
+
+protected:
+    memb_hip_ctx* createDeviceContext(int device) const override
+    {
+        memb_hip_trained_desc desc{};
+        desc.dim = static_cast<uint32_t>(dim_);
+        desc.n_rows = valueOffsets_.size;
+        desc.packed_values = packedValues_.data;
+        desc.packed_values_bytes = packedValues_.size;
+        desc.value_offsets = valueOffsets_.data;
+        desc.keys = keys_.data;
+        desc.n_keys = static_cast<uint32_t>(keys_.size);
+        desc.size_offsets = sizeOffsets_.data;
+        desc.n_size_offsets = static_cast<uint32_t>(sizeOffsets_.size);
+        desc.centroids = centroids_.data;
+        desc.n_centroids = static_cast<uint32_t>(centroids_.size);
+        desc.max_direct_bits = static_cast<uint32_t>(maxDirectDecodeBitLength_);
+        memb_hip_ctx* context = nullptr;
+        if (memb_hip_ctx_create_trained(&context, device, &desc) != MEMB_HIP_OK) {
+            throwDeviceError("Cannot stage trained storage on the HIP device");
+        }
+        return context;
+    }
+
+private:
+    size_t dim_;
+    size_t maxDirectDecodeBitLength_;
+    wire::VectorView<uint32_t> wordOffsets_;
+    wire::VectorView<uint32_t> valueOffsets_;
+    wire::VectorView<char> packedWords_;
+    wire::VectorView<uint8_t> packedValues_;
+    wire::VectorView<uint8_t> keys_;
+    wire::VectorView<uint32_t> sizeOffsets_;
+    wire::VectorView<float> centroids_;
+};
+
+// reference src/trained_compression.cpp:25-101
+class TrainedCompressor : public Compressor {
+public:
+    TrainedCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight):
+        builder_(builder),
+        quantizationLevels_(quantizationLevelsFor(bitsPerWeight))
+    {}
+
+    void add(const std::string& word, const float* source, size_t dim) override
+    {
+        words_.push_back(word);
+        values_.insert(values_.end(), source, source + dim);
+        dim_ = dim;
+    }
+
+    wire::BufferBuilder::Ref finalize() override
+    {
+        static const size_t CLUSTER_SAMPLE_SIZE = 10000;  // reference src/trained_compression.cpp:21
+        const size_t wordCount = words_.size();
+        if (wordCount == 0) {
+            throw std::runtime_error("Nothing to encode");
+        }
+        const size_t sampleWords = std::min(CLUSTER_SAMPLE_SIZE, wordCount);
+        std::vector<float> sample(values_.begin(), values_.begin() + sampleWords * dim_);
+
+        KMeansClusterizer clusterizer(quantizationLevels_);
+        clusterizer.fit(sample);
+
+        // quantise everything, count symbol frequencies
+        std::vector<uint8_t> quantized(values_.size());
+        const size_t threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), wordCount / 4096 + 1));
+        const size_t wordsPerThread = (wordCount + threads - 1) / threads;
+        std::vector<std::vector<uint64_t>> partialCounts(threads, std::vector<uint64_t>(256, 0));
+        runParallel(threads, [&](size_t t) {
+            size_t first = std::min(wordCount, t * wordsPerThread) * dim_;
+            size_t last = std::min(wordCount, (t + 1) * wordsPerThread) * dim_;
+            clusterizer.predict(values_.data() + first, last - first, quantized.data() + first);
+            for (size_t i = first; i < last; ++i) {
+                partialCounts[t][quantized[i]] += 1;
+            }
+        });
+        std::vector<float>().swap(values_);
+        std::vector<uint64_t> counts(256, 0);
+        for (const auto& partial : partialCounts) {
+            for (size_t k = 0; k < 256; ++k) {
+                counts[k] += partial[k];
+            }
+        }
+
+        auto codeLengths = huffmanCodeLengths(counts);
+        auto codes = canonicalCodes(codeLengths);
+        std::vector<PrefixCode> codebook(256, PrefixCode{0, 0});
+        for (size_t i = 0; i < codeLengths.size(); ++i) {
+            if (codes[i].bitsCount > MAX_CODE_BITS) {
+                throw std::runtime_error("Huffman codes longer than 16 bits are not supported");
+            }
+            codebook[codeLengths[i].key] = codes[i];
+        }
+
+        // one byte aligned stream per word, concatenated in insertion order
+        std::vector<std::vector<uint8_t>> partialStreams(threads);
+        std::vector<uint32_t> streamLengths(wordCount);
+        runParallel(threads, [&](size_t t) {
+            size_t first = std::min(wordCount, t * wordsPerThread);
+            size_t last = std::min(wordCount, (t + 1) * wordsPerThread);
+            BitWriter writer;
+            size_t written = 0;
+            for (size_t w = first; w < last; ++w) {
+                const uint8_t* symbols = quantized.data() + w * dim_;
+                for (size_t i = 0; i < dim_; ++i) {
+                    const PrefixCode& code = codebook[symbols[i]];
+                    writer.push(code.code, code.bitsCount);
+                }
+                writer.flushToByte();
+                streamLengths[w] = static_cast<uint32_t>(writer.bytes().size() - written);
+                written = writer.bytes().size();
+            }
+            partialStreams[t].swap(writer.bytes());
+        });
+        std::vector<uint8_t>().swap(quantized);
+
+        size_t totalBytes = 0;
+        for (const auto& part : partialStreams) {
+            totalBytes += part.size();
+        }
+        if (totalBytes > 0xFFFFFFFFull) {
+            throw std::runtime_error("Packed values exceed 4 GiB");
+        }
+        std::vector<uint8_t> packedValues;
+        packedValues.reserve(totalBytes);
+        for (auto& part : partialStreams) {
+            packedValues.insert(packedValues.end(), part.begin(), part.end());
+            std::vector<uint8_t>().swap(part);
+        }
+
+        std::vector<uint32_t> insertionOffsets(wordCount);
+        {
+            uint64_t offset = 0;
+            for (size_t w = 0; w < wordCount; ++w) {
+                insertionOffsets[w] = static_cast<uint32_t>(offset);
+                offset += streamLengths[w];
+            }
+        }
+
+        // sort words with std::string::operator< (reference :73-79)
+        std::vector<uint32_t> order(wordCount);
+        for (size_t w = 0; w < wordCount; ++w) {
+            order[w] = static_cast<uint32_t>(w);
+        }
+        std::sort(order.begin(), order.end(), [this](uint32_t a, uint32_t b) { return words_[a] < words_[b]; });
+
+        std::string packedWords;
+        std::vector<uint32_t> wordOffsets;
+        std::vector<uint32_t> valueOffsets;
+        wordOffsets.reserve(wordCount);
+        valueOffsets.reserve(wordCount);
+        for (uint32_t w : order) {
+            wordOffsets.push_back(static_cast<uint32_t>(packedWords.size()));
+            valueOffsets.push_back(insertionOffsets[w]);
+            packedWords.append(words_[w].c_str(), std::strlen(words_[w].c_str()) + 1);
+        }
+
+        std::vector<uint8_t> decoderKeys;
+        std::vector<uint32_t> sizeOffsets;
+        decoderDescription(codeLengths, &decoderKeys, &sizeOffsets);
+
+        builder_.reserve(packedValues.size() + packedWords.size() + 8 * wordCount + 4096);
+        auto wordOffsetsRef = builder_.createVector(wordOffsets);
+        auto valueOffsetsRef = builder_.createVector(valueOffsets);
+        auto packedWordsRef = builder_.createString(packedWords);
+        auto packedValuesRef = builder_.createVector(packedValues);
+
+        auto keysRef = builder_.createVector(decoderKeys);
+        auto sizeOffsetsRef = builder_.createVector(sizeOffsets);
+        builder_.startTable();
+        builder_.addOffset(wire::field::HuffmanDecoder_keys, keysRef);
+        builder_.addOffset(wire::field::HuffmanDecoder_size_offsets, sizeOffsetsRef);
+        auto decoderRef = builder_.endTable();
+
+        auto centroidsRef = builder_.createVector(clusterizer.centroids());
+        builder_.startTable();
+        builder_.addOffset(wire::field::KMeansClusterizer_centroids, centroidsRef);
+        auto clusterizerRef = builder_.endTable();
+
+        builder_.startTable();
+        builder_.addOffset(wire::field::Trained_word_offsets, wordOffsetsRef);
+        builder_.addOffset(wire::field::Trained_value_offsets, valueOffsetsRef);
+        builder_.addOffset(wire::field::Trained_packed_words, packedWordsRef);
+        builder_.addOffset(wire::field::Trained_packed_values, packedValuesRef);
+        builder_.addOffset(wire::field::Trained_decoder, decoderRef);
+        builder_.addOffset(wire::field::Trained_clusterizer, clusterizerRef);
+        return builder_.endTable();
+    }
+
+private:
+    template <typename F>
+    static void runParallel(size_t threads, F body)
+    {
+        if (threads <= 1) {
+            body(0);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < threads; ++t) {
+            pool.emplace_back(body, t);
+        }
+        for (auto& thread : pool) {
+            thread.join();
+        }
+    }
+
+    wire::BufferBuilder& builder_;
+    uint8_t quantizationLevels_;
+    size_t dim_ = 0;
+    std::vector<std::string> words_;
+    std::vector<float> values_;
+};
+
+}  // namespace
+
+std::shared_ptr<Compressor> TrainedCompressionStrategy::createCompressor(
+    wire::BufferBuilder& builder, size_t bitsPerWeight) const
+{
+    return std::make_shared<TrainedCompressor>(builder, bitsPerWeight);
+}
+
+std::shared_ptr<CompressedStorage> TrainedCompressionStrategy::createCompressedStorage(
+    const wire::TableView& flatStorage, size_t dim) const
+{
+    return std::make_shared<TrainedCompressedStorage>(flatStorage, dim, maxDirectDecodeBitLength_);
+}
+
+// ---------------------------------------------------------------------------
+// uniform and full: vectors of tables sorted by their `word` key
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// flatbuffers' LookupByKey is a binary search with strcmp over the sorted
+// vector of tables (reference call sites src/uniform_compression.cpp:56,
+// src/full_compression.cpp:39).
+bool lookupByKey(const std::vector<const char*>& words, const char* word, uint32_t* row)
+{
+    auto it = std::lower_bound(
+        words.begin(), words.end(), word, [](const char* a, const char* b) { return std::strcmp(a, b) < 0; });
+    if (it == words.end() || std::strcmp(*it, word) != 0) {
+        return false;
+    }
+    *row = static_cast<uint32_t>(it - words.begin());
+    return true;
+}
+
+class UniformCompressedStorage : public CompressedStorage {
+public:
+    UniformCompressedStorage(const wire::TableView& flatStorage, size_t dim):
+        dim_(dim)
+    {
+        auto nodes = flatStorage.vector<uint32_t>(wire::field::Uniform_nodes);
+        quantizationLevels_ = flatStorage.scalar<uint8_t>(wire::field::Uniform_quantization_levels, 0);
+        words_.reserve(nodes.size);
+        rows_.reserve(nodes.size);
+        for (size_t i = 0; i < nodes.size; ++i) {
+            wire::TableView node = flatStorage.tableAt(nodes, i);
+            words_.push_back(node.string(wire::field::UniformQuantizedNode_word).data);
+            wire::TableView vector = node.table(wire::field::UniformQuantizedNode_compressed_values);
+            auto values = vector.vector<uint8_t>(wire::field::UniformQuantizedVector_values);
+            memb_hip_uniform_row row{};
+            row.values = values.data;
+            row.n_values = static_cast<uint32_t>(values.size);
+            row.min_value = vector.scalar<float>(wire::field::UniformQuantizedVector_min_value, 0.f);
+            row.max_value = vector.scalar<float>(wire::field::UniformQuantizedVector_max_value, 0.f);
+            rows_.push_back(row);
+        }
+    }
+
+    size_t dim() const override { return dim_; }
+    size_t rowCount() const override { return rows_.size(); }
+    bool resolve(const char* word, uint32_t* row) const override { return lookupByKey(words_, word, row); }
+
+    std::vector<std::string> keys() const override
+    {
+        return std::vector<std::string>(words_.begin(), words_.end());
+    }
+
+protected:
+    memb_hip_ctx* createDeviceContext(int device) const override
+    {
+        memb_hip_uniform_desc desc{};
+        desc.dim = static_cast<uint32_t>(dim_);
+        desc.n_rows = rows_.size();
+        desc.rows = rows_.data();
+        desc.quantization_levels = quantizationLevels_;
+        memb_hip_ctx* context = nullptr;
+        if (memb_hip_ctx_create_uniform(&context, device, &desc) != MEMB_HIP_OK) {
+            throwDeviceError("Cannot stage uniform storage on the HIP device");
+        }
+        return context;
+    }
+
+private:
+    size_t dim_;
+    uint8_t quantizationLevels_ = 0;
+    std::vector<const char*> words_;
+    std::vector<memb_hip_uniform_row> rows_;
+};
+
+// reference src/uniform_compression.cpp:5-48
+class UniformCompressor : public Compressor {
+public:
+    UniformCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight):
+        builder_(builder),
+        quantizationLevels_(quantizationLevelsFor(bitsPerWeight))
+    {}
+
+    void add(const std::string& word, const float* source, size_t dim) override
+    {
+        auto minMax = std::minmax_element(source, source + dim);
+        float minValue = *minMax.first;
+        float maxValue = *minMax.second;
+        std::vector<uint8_t> quantized(dim);
+        for (size_t i = 0; i < dim; ++i) {
+            float scaled = quantizationLevels_ * (source[i] - minValue) / (maxValue - minValue);
+            quantized[i] = static_cast<uint8_t>(scaled);
+        }
+        auto valuesRef = builder_.createVector(quantized);
+        builder_.startTable();
+        builder_.addScalar<float>(wire::field::UniformQuantizedVector_min_value, minValue);
+        builder_.addScalar<float>(wire::field::UniformQuantizedVector_max_value, maxValue);
+        builder_.addOffset(wire::field::UniformQuantizedVector_values, valuesRef);
+        embeddings_.emplace(word, builder_.endTable());
+    }
+
+    wire::BufferBuilder::Ref finalize() override
+    {
+        std::vector<wire::BufferBuilder::Ref> nodes;  // std::map iterates in key order
+        for (const auto& item : embeddings_) {
+            auto wordRef = builder_.createString(item.first.c_str(), std::strlen(item.first.c_str()));
+            builder_.startTable();
+            builder_.addOffset(wire::field::UniformQuantizedNode_word, wordRef);
+            builder_.addOffset(wire::field::UniformQuantizedNode_compressed_values, item.second);
+            nodes.push_back(builder_.endTable());
+        }
+        auto nodesRef = builder_.createVectorOfTables(nodes);
+        builder_.startTable();
+        builder_.addOffset(wire::field::Uniform_nodes, nodesRef);
+        builder_.addScalar<uint8_t>(wire::field::Uniform_quantization_levels, quantizationLevels_);
+        return builder_.endTable();
+    }
+
+private:
+    wire::BufferBuilder& builder_;
+    uint8_t quantizationLevels_;
+    std::map<std::string, wire::BufferBuilder::Ref> embeddings_;
+};
+
+class FullCompressedStorage : public CompressedStorage {
+public:
+    FullCompressedStorage(const wire::TableView& flatStorage, size_t dim):
+        dim_(dim)
+    {
+        auto nodes = flatStorage.vector<uint32_t>(wire::field::Full_nodes);
+        words_.reserve(nodes.size);
+        rows_.reserve(nodes.size);
+        for (size_t i = 0; i < nodes.size; ++i) {
+            wire::TableView node = flatStorage.tableAt(nodes, i);
+            words_.push_back(node.string(wire::field::FullNode_word).data);
+            auto values = node.vector<float>(wire::field::FullNode_values);
+            memb_hip_full_row row{};
+            row.values = values.data;
+            row.n_values = static_cast<uint32_t>(values.size);
+            rows_.push_back(row);
+        }
+    }
+
+    size_t dim() const override { return dim_; }
+    size_t rowCount() const override { return rows_.size(); }
+    bool resolve(const char* word, uint32_t* row) const override { return lookupByKey(words_, word, row); }
+
+    std::vector<std::string> keys() const override
+    {
+        return std::vector<std::string>(words_.begin(), words_.end());
+    }
+
+protected:
+    memb_hip_ctx* createDeviceContext(int device) const override
+    {
+        memb_hip_full_desc desc{};
+        desc.dim = static_cast<uint32_t>(dim_);
+        desc.n_rows = rows_.size();
+        desc.rows = rows_.data();
+        memb_hip_ctx* context = nullptr;
+        if (memb_hip_ctx_create_full(&context, device, &desc) != MEMB_HIP_OK) {
+            throwDeviceError("Cannot stage full storage on the HIP device");
+        }
+        return context;
+    }
+
+private:
+    size_t dim_;
+    std::vector<const char*> words_;
+    std::vector<memb_hip_full_row> rows_;
+};
+
+// reference src/full_compression.cpp:5-31
+class FullCompressor : public Compressor {
+public:
+    explicit FullCompressor(wire::BufferBuilder& builder): builder_(builder) {}
+
+    void add(const std::string& word, const float* source, size_t dim) override
+    {
+        embeddings_.emplace(word, builder_.createVector(source, dim));
+    }
+
+    wire::BufferBuilder::Ref finalize() override
+    {
+        std::vector<wire::BufferBuilder::Ref> nodes;
+        for (const auto& item : embeddings_) {
+            auto wordRef = builder_.createString(item.first.c_str(), std::strlen(item.first.c_str()));
+            builder_.startTable();
+            builder_.addOffset(wire::field::FullNode_word, wordRef);
+            builder_.addOffset(wire::field::FullNode_values, item.second);
+            nodes.push_back(builder_.endTable());
+        }
+        auto nodesRef = builder_.createVectorOfTables(nodes);
+        builder_.startTable();
+        builder_.addOffset(wire::field::Full_nodes, nodesRef);
+        return builder_.endTable();
+    }
+
+private:
+    wire::BufferBuilder& builder_;
+    std::map<std::string, wire::BufferBuilder::Ref> embeddings_;
+};
+
+}  // namespace
+
+std::shared_ptr<Compressor> UniformCompressionStrategy::createCompressor(
+    wire::BufferBuilder& builder, size_t bitsPerWeight) const
+{
+    return std::make_shared<UniformCompressor>(builder, bitsPerWeight);
+}
+
+std::shared_ptr<CompressedStorage> UniformCompressionStrategy::createCompressedStorage(
+    const wire::TableView& flatStorage, size_t dim) const
+{
+    return std::make_shared<UniformCompressedStorage>(flatStorage, dim);
+}
+
+std::shared_ptr<Compressor> FullCompressionStrategy::createCompressor(
+    wire::BufferBuilder& builder, size_t /*bitsPerWeight*/) const
+{
+    return std::make_shared<FullCompressor>(builder);
+}
+
+std::shared_ptr<CompressedStorage> FullCompressionStrategy::createCompressedStorage(
+    const wire::TableView& flatStorage, size_t dim) const
+{
+    return std::make_shared<FullCompressedStorage>(flatStorage, dim);
+}
+
+}  // namespace memb

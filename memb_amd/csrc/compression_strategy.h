@@ -1,0 +1,119 @@
+// Strategy plugin interface of the read and write side, mirroring the
+// reference's (src/compression_strategy.h:7-43): three abstract classes and a
+// registry looked up by wire::Storage tag or by name.
+//
+// Difference that the GPU path forces: the reference's plugin decodes one word
+// at a time on the CPU (CompressedStorage::extract). Here a storage resolves
+// words to row ids on the host (`resolve`) and decodes whole batches of rows on
+// the device (`decodeRows`, through the C ABI in include/memb_hip.h);
+// `extract` is kept with the reference's signature and is a batch of one.
+// There is no CPU decode path: without a HIP device every lookup throws.
+#pragma once
+
+#include "wire.h"
+#include "../../include/memb_hip.h"
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace memb {
+
+class CompressedStorage {
+public:
+    virtual ~CompressedStorage();
+
+    // reference src/compression_strategy.h:9-10
+    bool extract(const std::string& word, float* destination) const;
+    virtual std::vector<std::string> keys() const = 0;
+
+    virtual size_t dim() const = 0;
+    virtual size_t rowCount() const = 0;
+
+    // Row id (position in sorted key order) of `word`, false if absent.
+    virtual bool resolve(const char* word, uint32_t* row) const = 0;
+
+    // Decode rows[0..n) into out[i * ld + colOff ..], host buffers.
+    void decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
+    // Same with device buffers, enqueued on `stream` (hipStream_t, may be null).
+    void decodeRowsDevice(
+        const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream) const;
+
+    void setDevice(int device);
+    int device() const { return device_; }
+    // The device context, created (payload staged to HBM) on first use.
+    memb_hip_ctx* deviceContext() const;
+
+protected:
+    virtual memb_hip_ctx* createDeviceContext(int device) const = 0;
+
+private:
+    int device_ = 0;
+    mutable std::mutex contextMutex_;
+    mutable memb_hip_ctx* context_ = nullptr;
+};
+
+class Compressor {
+public:
+    virtual void add(const std::string& word, const float* source, size_t dim) = 0;
+    // Writes the storage table, returns its handle (the union value of Index.storage).
+    virtual wire::BufferBuilder::Ref finalize() = 0;
+    virtual ~Compressor() {}
+};
+
+class CompressionStrategy {
+public:
+    virtual std::shared_ptr<Compressor> createCompressor(
+        wire::BufferBuilder& builder, size_t bitsPerWeight) const = 0;
+
+    virtual std::shared_ptr<CompressedStorage> createCompressedStorage(
+        const wire::TableView& flatStorage, size_t dim) const = 0;
+
+    virtual std::string storageName() const = 0;
+    virtual wire::Storage storageType() const = 0;
+    virtual ~CompressionStrategy() {}
+};
+
+std::shared_ptr<CompressionStrategy> createCompressionStrategy(wire::Storage storage);
+std::shared_ptr<CompressionStrategy> createCompressionStrategy(const std::string& storageName);
+std::vector<std::string> availableCompressionStrategies();
+
+// trained: k-means codebook + canonical Huffman (reference src/trained_compression.h)
+class TrainedCompressionStrategy : public CompressionStrategy {
+public:
+    // maxDirectDecodeBitLength: see memb_hip_trained_desc::max_direct_bits; 0 = default.
+    explicit TrainedCompressionStrategy(size_t maxDirectDecodeBitLength = 0):
+        maxDirectDecodeBitLength_(maxDirectDecodeBitLength)
+    {}
+    std::shared_ptr<Compressor> createCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight) const override;
+    std::shared_ptr<CompressedStorage> createCompressedStorage(
+        const wire::TableView& flatStorage, size_t dim) const override;
+    std::string storageName() const override { return "trained"; }
+    wire::Storage storageType() const override { return wire::Storage_Trained; }
+
+private:
+    size_t maxDirectDecodeBitLength_;
+};
+
+// uniform: per-word min/max + one byte per weight (reference src/uniform_compression.h)
+class UniformCompressionStrategy : public CompressionStrategy {
+public:
+    std::shared_ptr<Compressor> createCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight) const override;
+    std::shared_ptr<CompressedStorage> createCompressedStorage(
+        const wire::TableView& flatStorage, size_t dim) const override;
+    std::string storageName() const override { return "uniform"; }
+    wire::Storage storageType() const override { return wire::Storage_Uniform; }
+};
+
+// full: raw fp32 (reference src/full_compression.h)
+class FullCompressionStrategy : public CompressionStrategy {
+public:
+    std::shared_ptr<Compressor> createCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight) const override;
+    std::shared_ptr<CompressedStorage> createCompressedStorage(
+        const wire::TableView& flatStorage, size_t dim) const override;
+    std::string storageName() const override { return "full"; }
+    wire::Storage storageType() const override { return wire::Storage_Full; }
+};
+
+}  // namespace memb

@@ -1,0 +1,1144 @@
+// HIP (gfx950 / CDNA4) implementation of the memb batch-lookup path behind the
+// C ABI in include/memb_hip.h.
+//
+// Kernels
+//   decode_trained : canonical-Huffman bitstream decode + k-means codebook gather
+//                    (reference src/trained_compression.cpp:129-135,
+//                     src/huffman_table_decoder.h:102-118, src/bit_stream_reader.h:16-31)
+//   dequant_uniform: min + (max - min) * v / levels, four IEEE fp32 operations
+//                    (reference src/uniform_compression.cpp:64-72)
+//   gather_full    : raw fp32 row copy (reference src/full_compression.cpp:37-47)
+// A row id of MEMB_HIP_MISSING_ROW yields a zero row (reference src/reader.cpp:43-46).
+//
+// Work decomposition of decode_trained (the serial part is the bitstream of one
+// word, so parallelism is across words): one wavefront owns a tile of 64
+// consecutive batch entries, lane l decodes word l. The lookup table and the
+// codebook sit in LDS; the 64 bitstreams are first copied into LDS with wide
+// coalesced loads (one 16-byte piece per lane), decoded from there, the decoded
+// symbols are staged in LDS one byte each, and the tile is written out row
+// contiguous, 16 bytes per lane, so every store instruction covers whole
+// 16-byte-aligned runs of output rows.
+#include <hip/hip_runtime.h>
+
+#include "../../include/memb_hip.h"
+#include "codec.h"
+#include "wire.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr uint32_t MISSING = MEMB_HIP_MISSING_ROW;
+constexpr uint32_t ZERO_KEY = 255;  // codebook slot that always holds 0.0f: at most 255 centroids exist
+                                    // (reference src/trained_compression.cpp:29)
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& message)
+{
+    g_lastError = message;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t status_ = (expr);                                                             \
+        if (status_ != hipSuccess) {                                                             \
+            return fail(                                                                         \
+                MEMB_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(status_));   \
+        }                                                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// decode_trained
+// ---------------------------------------------------------------------------
+
+struct TrainedParams {
+    const uint32_t* rows;
+    float* out;
+    unsigned long long n;
+    unsigned long long ld;
+    unsigned long long colOff;
+    const uint8_t* packed;
+    const uint32_t* valueOffsets;
+    const uint32_t* table;
+    const float* centroids;
+    unsigned long long nRows;
+    uint32_t tableDwords;   // multiple of 4
+    uint32_t rootBits;
+    uint32_t dim;
+    uint32_t slotDwords;    // LDS bytes/4 reserved per bitstream, multiple of 4
+    uint32_t chunk;         // symbols decoded between two output phases, multiple of 4
+    uint32_t keyStride;     // dwords per word in the symbol tile, odd
+    uint32_t chunkMagic;    // ceil(2^32 / (chunk / 4))
+    uint32_t slotMagic;     // ceil(2^32 / (slotDwords / 4))
+};
+
+enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2 };
+
+// 16-byte load from an address that is only 4-byte aligned (bitstreams start
+// on arbitrary bytes; the staging copy starts at the enclosing dword).
+typedef uint4 __attribute__((aligned(4))) uint4_align4;
+
+__device__ __forceinline__ uint32_t byteSwap(uint32_t v)
+{
+    return __builtin_bswap32(v);
+}
+
+// Orders this wave's LDS writes before its later LDS reads (and vice versa).
+// LDS operations of one wave execute in order; the fence makes the compiler
+// wait for them and keeps it from moving accesses across.
+__device__ __forceinline__ void waveLdsFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool HAS_SUB, int MODE>
+__global__ void decode_trained(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t wavesPerBlock = blockDim.x / WAVE;
+
+    uint32_t* tableLds = lds;
+    float* centroidLds = reinterpret_cast<float*>(lds + p.tableDwords);
+    const uint32_t perWave = WAVE * (p.slotDwords + p.keyStride);
+    uint32_t* slots = lds + p.tableDwords + 256 + wave * perWave;
+    uint32_t* keyTile = slots + WAVE * p.slotDwords;
+
+    for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
+        reinterpret_cast<uint4*>(tableLds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        centroidLds[i] = p.centroids[i];
+    }
+    __syncthreads();
+
+    const unsigned long long tileBase =
+        (static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave) * WAVE;
+    if (tileBase >= p.n) {
+        return;
+    }
+    const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(WAVE), p.n - tileBase));
+
+    uint32_t row = MISSING;
+    if (lane < tileWords) {
+        row = p.rows[tileBase + lane];
+    }
+    const bool present = row < p.nRows;
+    const uint32_t offset = present ? p.valueOffsets[row] : 0;
+    const uint32_t alignedOffset = offset & ~3u;
+
+    // Stage the 64 bitstreams: piece q = (word, 16-byte piece) -> one lane.
+    // All loads of a batch are issued before the first one is waited for.
+    // Absent words read the start of the array (always mapped: the guard is a
+    // slot long) and never emit what they decode.
+    {
+        const uint32_t piecesPerWord = p.slotDwords / 4;
+        const uint32_t totalPieces = WAVE * piecesPerWord;
+        const uint32_t sourceOffset = present ? alignedOffset : 0u;
+        constexpr int BATCH = 8;
+        for (uint32_t q0 = lane; q0 < totalPieces; q0 += WAVE * BATCH) {
+            uint4 v[BATCH];
+            uint32_t destination[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const uint32_t q = q0 + WAVE * b;
+                if (q < totalPieces) {
+                    const uint32_t w = __umulhi(q, p.slotMagic);
+                    const uint32_t piece = q - w * piecesPerWord;
+                    const uint32_t wordOffset = __shfl(sourceOffset, w);
+                    v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
+                    destination[b] = w * p.slotDwords + 4 * piece;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const uint32_t q = q0 + WAVE * b;
+                if (q < totalPieces) {
+                    uint4 t = v[b];
+                    t.x = byteSwap(t.x);
+                    t.y = byteSwap(t.y);
+                    t.z = byteSwap(t.z);
+                    t.w = byteSwap(t.w);
+                    *reinterpret_cast<uint4*>(slots + destination[b]) = t;
+                }
+            }
+        }
+    }
+    waveLdsFence();
+
+    const uint32_t* slot = slots + lane * p.slotDwords;
+    uint32_t* keyRow = keyTile + lane * p.keyStride;
+    const uint32_t lastWindow = p.slotDwords - 3;
+    const uint32_t rootShift = 32 - p.rootBits;
+    uint32_t bitPos = (offset & 3u) * 8;
+
+    for (uint32_t chunkStart = 0; chunkStart < p.dim; chunkStart += p.chunk) {
+        const uint32_t chunkSymbols = min(p.chunk, p.dim - chunkStart);
+
+        for (uint32_t j = 0; j < chunkSymbols; j += 4) {
+            const uint32_t d = min(bitPos >> 5, lastWindow);
+            const uint32_t shift = bitPos & 31;
+            const uint32_t w0 = slot[d];
+            const uint32_t w1 = slot[d + 1];
+            const uint32_t w2 = slot[d + 2];
+            // 64 valid bits starting at the current bit position, MSB first.
+            unsigned long long window =
+                (((static_cast<unsigned long long>(w0) << 32) | w1) << shift) |
+                (static_cast<unsigned long long>(w2) >> (32 - shift));
+            uint32_t keys = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uint32_t entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
+                if (HAS_SUB) {
+                    if (entry & memb::TABLE_POINTER_FLAG) {
+                        const uint32_t subBits = entry & 0xff;
+                        const uint32_t base = (entry & ~memb::TABLE_POINTER_FLAG) >> 8;
+                        const uint32_t subIndex =
+                            static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
+                        entry = tableLds[base + subIndex];
+                    }
+                }
+                const uint32_t length = entry & 0xff;
+                window <<= length;
+                bitPos += length;
+                keys |= ((entry >> 8) & 0xff) << (8 * s);
+            }
+            keyRow[j >> 2] = present ? keys : 0xFFFFFFFFu;
+        }
+        waveLdsFence();
+
+        if (MODE == OUT_FLAT) {
+            // ld == dim, one chunk, keyStride == dim / 4: tile and output are both linear.
+            const uint32_t pieces = tileWords * (p.dim / 4);
+            float4* dst = reinterpret_cast<float4*>(p.out + tileBase * p.ld);
+            for (uint32_t q = lane; q < pieces; q += WAVE) {
+                const uint32_t k = keyTile[q];
+                float4 f;
+                f.x = centroidLds[k & 0xff];
+                f.y = centroidLds[(k >> 8) & 0xff];
+                f.z = centroidLds[(k >> 16) & 0xff];
+                f.w = centroidLds[k >> 24];
+                dst[q] = f;
+            }
+        } else if (MODE == OUT_VEC4) {
+            const uint32_t piecesPerWord = chunkSymbols / 4;
+            const uint32_t magic = (chunkSymbols == p.chunk) ? p.chunkMagic : 0;
+            const uint32_t pieces = tileWords * piecesPerWord;
+            for (uint32_t q = lane; q < pieces; q += WAVE) {
+                const uint32_t w = magic ? __umulhi(q, magic) : q / piecesPerWord;
+                const uint32_t c = q - w * piecesPerWord;
+                const uint32_t k = keyTile[w * p.keyStride + c];
+                float4 f;
+                f.x = centroidLds[k & 0xff];
+                f.y = centroidLds[(k >> 8) & 0xff];
+                f.z = centroidLds[(k >> 16) & 0xff];
+                f.w = centroidLds[k >> 24];
+                float* dst = p.out + (tileBase + w) * p.ld + p.colOff + chunkStart + 4 * c;
+                *reinterpret_cast<float4*>(dst) = f;
+            }
+        } else {
+            const uint32_t total = tileWords * chunkSymbols;
+            const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
+            for (uint32_t q = lane; q < total; q += WAVE) {
+                const uint32_t w = q / chunkSymbols;
+                const uint32_t c = q - w * chunkSymbols;
+                const uint32_t k = keyBytes[w * p.keyStride * 4 + c];
+                p.out[(tileBase + w) * p.ld + p.colOff + chunkStart + c] = centroidLds[k];
+            }
+        }
+        waveLdsFence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dequant_uniform / gather_full
+// ---------------------------------------------------------------------------
+
+struct UniformParams {
+    const uint32_t* rows;
+    float* out;
+    unsigned long long n;
+    unsigned long long ld;
+    unsigned long long colOff;
+    const uint8_t* values;   // dense [nRows][dim]
+    const float2* minMax;    // [nRows]
+    unsigned long long nRows;
+    uint32_t dim;
+    uint32_t wordsPerBlock;
+    uint32_t pieceMagic;     // ceil(2^32 / (dim / 4)), vector path
+    float levels;
+};
+
+// reference src/uniform_compression.cpp:70-71, evaluated left to right in fp32:
+// sub, mul, div, add -- each correctly rounded, nothing fused.
+__device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels)
+{
+    const float scaled = __fmul_rn(range, static_cast<float>(v));
+    return __fadd_rn(minValue, __fdiv_rn(scaled, levels));
+}
+
+template <bool VEC4>
+__global__ void dequant_uniform(UniformParams p)
+{
+    const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
+    const uint32_t blockWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
+
+    if (VEC4) {
+        const uint32_t piecesPerWord = p.dim / 4;
+        const uint32_t pieces = blockWords * piecesPerWord;
+        for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
+            const uint32_t w = __umulhi(q, p.pieceMagic);
+            const uint32_t c = q - w * piecesPerWord;
+            const uint32_t row = p.rows[blockBase + w];
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.nRows) {
+                const float2 mm = p.minMax[row];
+                const float range = __fsub_rn(mm.y, mm.x);
+                const uint32_t v =
+                    *reinterpret_cast<const uint32_t*>(p.values + static_cast<unsigned long long>(row) * p.dim + 4 * c);
+                f.x = dequant(mm.x, range, v & 0xff, p.levels);
+                f.y = dequant(mm.x, range, (v >> 8) & 0xff, p.levels);
+                f.z = dequant(mm.x, range, (v >> 16) & 0xff, p.levels);
+                f.w = dequant(mm.x, range, v >> 24, p.levels);
+            }
+            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + 4 * c;
+            *reinterpret_cast<float4*>(dst) = f;
+        }
+    } else {
+        const uint32_t total = blockWords * p.dim;
+        for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+            const uint32_t w = q / p.dim;
+            const uint32_t c = q - w * p.dim;
+            const uint32_t row = p.rows[blockBase + w];
+            float f = 0.f;
+            if (row < p.nRows) {
+                const float2 mm = p.minMax[row];
+                const float range = __fsub_rn(mm.y, mm.x);
+                f = dequant(mm.x, range, p.values[static_cast<unsigned long long>(row) * p.dim + c], p.levels);
+            }
+            p.out[(blockBase + w) * p.ld + p.colOff + c] = f;
+        }
+    }
+}
+
+struct FullParams {
+    const uint32_t* rows;
+    float* out;
+    unsigned long long n;
+    unsigned long long ld;
+    unsigned long long colOff;
+    const float* values;     // dense [nRows][dim]
+    unsigned long long nRows;
+    uint32_t dim;
+    uint32_t wordsPerBlock;
+    uint32_t pieceMagic;
+};
+
+template <bool VEC4>
+__global__ void gather_full(FullParams p)
+{
+    const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
+    const uint32_t blockWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
+    if (VEC4) {
+        const uint32_t piecesPerWord = p.dim / 4;
+        const uint32_t pieces = blockWords * piecesPerWord;
+        for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
+            const uint32_t w = __umulhi(q, p.pieceMagic);
+            const uint32_t c = q - w * piecesPerWord;
+            const uint32_t row = p.rows[blockBase + w];
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.nRows) {
+                f = *reinterpret_cast<const float4*>(p.values + static_cast<unsigned long long>(row) * p.dim + 4 * c);
+            }
+            *reinterpret_cast<float4*>(p.out + (blockBase + w) * p.ld + p.colOff + 4 * c) = f;
+        }
+    } else {
+        const uint32_t total = blockWords * p.dim;
+        for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
+            const uint32_t w = q / p.dim;
+            const uint32_t c = q - w * p.dim;
+            const uint32_t row = p.rows[blockBase + w];
+            p.out[(blockBase + w) * p.ld + p.colOff + c] =
+                row < p.nRows ? p.values[static_cast<unsigned long long>(row) * p.dim + c] : 0.f;
+        }
+    }
+}
+
+// ceil(2^32 / d); __umulhi(q, magic) == q / d while q * d < 2^32.
+uint32_t magicFor(uint32_t d)
+{
+    return static_cast<uint32_t>(((1ull << 32) + d - 1) / d);
+}
+
+uint32_t envUint(const char* name, uint32_t fallback)
+{
+    const char* text = std::getenv(name);
+    if (!text || !*text) {
+        return fallback;
+    }
+    return static_cast<uint32_t>(std::strtoul(text, nullptr, 10));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------
+
+struct memb_hip_ctx {
+    int device = 0;
+    uint32_t storage = 0;
+    uint32_t dim = 0;
+    uint64_t nRows = 0;
+    uint64_t deviceBytes = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocations;
+
+    // trained
+    uint8_t* packed = nullptr;
+    uint32_t* valueOffsets = nullptr;
+    uint32_t* table = nullptr;
+    float* centroids = nullptr;
+    memb::DecodeTable hostTable;
+    uint32_t tableDwords = 0;
+    uint32_t maxStreamBytes = 0;
+    uint32_t slotDwords = 0;
+    std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
+    uint32_t ldsLimit = 0;
+    uint32_t cuCount = 0;
+
+    // uniform / full
+    uint8_t* uniformValues = nullptr;
+    float2* minMax = nullptr;
+    float levels = 0.f;
+    float* fullValues = nullptr;
+
+    // staging for the host-buffer entry point
+    uint32_t* stagedRows = nullptr;
+    float* stagedOut = nullptr;
+    size_t stagedCapacity = 0;   // words
+    size_t stagedLd = 0;
+    std::mutex mutex;
+};
+
+namespace {
+
+struct TrainedGeometry {
+    uint32_t waves;
+    uint32_t chunk;
+    uint32_t keyStride;
+    uint32_t ldsBytes;
+    int mode;
+};
+
+uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t keyStride)
+{
+    return 4u * (ctx->tableDwords + 256u + waves * WAVE * (ctx->slotDwords + keyStride));
+}
+
+// Pick waves per block and the symbols decoded between output phases so that
+// as many wavefronts as possible are resident per CU (LDS is the limiter).
+TrainedGeometry chooseGeometry(const memb_hip_ctx* ctx, size_t ld, size_t colOff, const float* out)
+{
+    const uint32_t dim = ctx->dim;
+    const bool vec = (dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
+        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const uint32_t symbolsRounded = (dim + 3) / 4 * 4;
+
+    TrainedGeometry best{};
+    double bestScore = -1;
+    const uint32_t forcedWaves = envUint("MEMB_HIP_WAVES", 0);
+    const uint32_t forcedChunk = envUint("MEMB_HIP_CHUNK", 0);
+    const uint32_t waveOptions[] = {4, 2, 1};
+    std::vector<uint32_t> chunkOptions = {symbolsRounded};
+    if (forcedChunk) {
+        chunkOptions[0] = std::max<uint32_t>(4, std::min(forcedChunk / 4 * 4, symbolsRounded));
+    } else {
+        // keep every output phase at least 128 bytes long per word
+        for (uint32_t parts = 2; parts <= 16; ++parts) {
+            uint32_t chunk = ((symbolsRounded + parts - 1) / parts + 3) / 4 * 4;
+            if (chunk >= 32 && chunk < symbolsRounded) {
+                chunkOptions.push_back(chunk);
+            }
+        }
+    }
+    for (uint32_t waves : waveOptions) {
+        if (forcedWaves && waves != forcedWaves) {
+            continue;
+        }
+        for (uint32_t chunk : chunkOptions) {
+            uint32_t keyStride = (chunk / 4) | 1u;
+            uint32_t ldsBytes = trainedLdsBytes(ctx, waves, keyStride);
+            if (ldsBytes > ctx->ldsLimit) {
+                continue;
+            }
+            // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU.
+            uint32_t blocksPerCu = std::min<uint32_t>(ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), 32 / waves);
+            double residentWaves = blocksPerCu * waves;
+            // More resident waves hide the serial decode latency; fewer output
+            // phases keep stores long and contiguous. Past ~12 waves per CU
+            // occupancy stops paying.
+            double score = std::min(residentWaves, 12.0) * 8.0 - (symbolsRounded + chunk - 1) / chunk;
+            if (score > bestScore) {
+                bestScore = score;
+                best.waves = waves;
+                best.chunk = chunk;
+                best.keyStride = keyStride;
+                best.ldsBytes = ldsBytes;
+            }
+        }
+    }
+    if (bestScore < 0) {
+        best.waves = 0;
+        return best;
+    }
+    if (!vec) {
+        best.mode = OUT_SCALAR;
+    } else if (ld == dim && colOff == 0 && best.chunk == dim && best.keyStride == dim / 4) {
+        best.mode = OUT_FLAT;
+    } else {
+        best.mode = OUT_VEC4;
+    }
+    return best;
+}
+
+template <bool HAS_SUB, int MODE>
+hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    static thread_local int configuredDevice = -1;
+    int device = 0;
+    hipGetDevice(&device);
+    if (configuredDevice != device) {
+        hipError_t status = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&decode_trained<HAS_SUB, MODE>),
+            hipFuncAttributeMaxDynamicSharedMemorySize,
+            160 * 1024);
+        if (status != hipSuccess) {
+            return status;
+        }
+        configuredDevice = device;
+    }
+    hipLaunchKernelGGL(
+        (decode_trained<HAS_SUB, MODE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+    return hipGetLastError();
+}
+
+int launchTrained(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    TrainedGeometry geometry = chooseGeometry(ctx, ld, colOff, out);
+    if (!geometry.waves) {
+        return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
+    }
+    TrainedParams params{};
+    params.rows = rows;
+    params.out = out;
+    params.n = n;
+    params.ld = ld;
+    params.colOff = colOff;
+    params.packed = ctx->packed;
+    params.valueOffsets = ctx->valueOffsets;
+    params.table = ctx->table;
+    params.centroids = ctx->centroids;
+    params.nRows = ctx->nRows;
+    params.tableDwords = ctx->tableDwords;
+    params.rootBits = ctx->hostTable.rootBits;
+    params.dim = ctx->dim;
+    params.slotDwords = ctx->slotDwords;
+    params.chunk = geometry.chunk;
+    params.keyStride = geometry.keyStride;
+    params.slotMagic = magicFor(ctx->slotDwords / 4);  // q < 64 * pieces, pieces <= 2^12
+    {
+        uint32_t piecesPerWord = geometry.chunk / 4;
+        // exact while q * piecesPerWord < 2^32 with q < 64 * piecesPerWord
+        params.chunkMagic = (64ull * piecesPerWord * piecesPerWord < (1ull << 32)) ? magicFor(piecesPerWord) : 0;
+    }
+
+    const size_t tiles = (n + WAVE - 1) / WAVE;
+    const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
+    const uint32_t threads = geometry.waves * WAVE;
+    const bool sub = ctx->hostTable.hasSubTables;
+    hipError_t status;
+    switch (geometry.mode) {
+        case OUT_FLAT:
+            status = sub ? launchTrainedVariant<true, OUT_FLAT>(params, blocks, threads, geometry.ldsBytes, stream)
+                         : launchTrainedVariant<false, OUT_FLAT>(params, blocks, threads, geometry.ldsBytes, stream);
+            break;
+        case OUT_VEC4:
+            status = sub ? launchTrainedVariant<true, OUT_VEC4>(params, blocks, threads, geometry.ldsBytes, stream)
+                         : launchTrainedVariant<false, OUT_VEC4>(params, blocks, threads, geometry.ldsBytes, stream);
+            break;
+        default:
+            status = sub ? launchTrainedVariant<true, OUT_SCALAR>(params, blocks, threads, geometry.ldsBytes, stream)
+                         : launchTrainedVariant<false, OUT_SCALAR>(params, blocks, threads, geometry.ldsBytes, stream);
+            break;
+    }
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+constexpr uint32_t ROWWISE_THREADS = 256;
+
+uint32_t rowwiseWordsPerBlock(uint32_t dim)
+{
+    // about 16 KiB of output per block, at least one word
+    return std::max<uint32_t>(1, std::min<uint32_t>(64, 4096 / std::max<uint32_t>(dim, 1)));
+}
+
+int launchUniform(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    UniformParams params{};
+    params.rows = rows;
+    params.out = out;
+    params.n = n;
+    params.ld = ld;
+    params.colOff = colOff;
+    params.values = ctx->uniformValues;
+    params.minMax = ctx->minMax;
+    params.nRows = ctx->nRows;
+    params.dim = ctx->dim;
+    params.wordsPerBlock = rowwiseWordsPerBlock(ctx->dim);
+    params.levels = ctx->levels;
+    const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
+        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const uint32_t blocks = static_cast<uint32_t>((n + params.wordsPerBlock - 1) / params.wordsPerBlock);
+    if (vec) {
+        params.pieceMagic = magicFor(ctx->dim / 4);
+        hipLaunchKernelGGL(dequant_uniform<true>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
+    } else {
+        hipLaunchKernelGGL(dequant_uniform<false>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
+    }
+    hipError_t status = hipGetLastError();
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("dequant_uniform launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+int launchFull(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    FullParams params{};
+    params.rows = rows;
+    params.out = out;
+    params.n = n;
+    params.ld = ld;
+    params.colOff = colOff;
+    params.values = ctx->fullValues;
+    params.nRows = ctx->nRows;
+    params.dim = ctx->dim;
+    params.wordsPerBlock = rowwiseWordsPerBlock(ctx->dim);
+    const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
+        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const uint32_t blocks = static_cast<uint32_t>((n + params.wordsPerBlock - 1) / params.wordsPerBlock);
+    if (vec) {
+        params.pieceMagic = magicFor(ctx->dim / 4);
+        hipLaunchKernelGGL(gather_full<true>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
+    } else {
+        hipLaunchKernelGGL(gather_full<false>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
+    }
+    hipError_t status = hipGetLastError();
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("gather_full launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+int launch(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    if (n == 0) {
+        return MEMB_HIP_OK;
+    }
+    if (n > (size_t(1) << 37)) {
+        return fail(MEMB_HIP_ERR_INVALID, "batch too large");
+    }
+    switch (ctx->storage) {
+        case memb::wire::Storage_Trained:
+            return launchTrained(ctx, rows, n, out, ld, colOff, stream);
+        case memb::wire::Storage_Uniform:
+            return launchUniform(ctx, rows, n, out, ld, colOff, stream);
+        case memb::wire::Storage_Full:
+            return launchFull(ctx, rows, n, out, ld, colOff, stream);
+        default:
+            return fail(MEMB_HIP_ERR_INVALID, "context has no storage");
+    }
+}
+
+template <typename T>
+int deviceAlloc(memb_hip_ctx* ctx, T** pointer, size_t bytes)
+{
+    void* raw = nullptr;
+    HIP_TRY(hipMalloc(&raw, std::max<size_t>(bytes, 16)));
+    ctx->allocations.push_back(raw);
+    ctx->deviceBytes += std::max<size_t>(bytes, 16);
+    *pointer = static_cast<T*>(raw);
+    return MEMB_HIP_OK;
+}
+
+// Host -> device copy of a (possibly file-mapped) range. Pinning the mapped
+// pages first lets the copy run at the PCIe rate; registration of a read-only
+// mapping can be refused, in which case the plain copy is used.
+int copyToDevice(void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) {
+        return MEMB_HIP_OK;
+    }
+    bool registered = false;
+    if (bytes >= (8u << 20)) {
+        hipError_t status = hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterReadOnly);
+        if (status == hipSuccess) {
+            registered = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    hipError_t status = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (registered) {
+        hipHostUnregister(const_cast<void*>(src));
+    }
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("hipMemcpy to device: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+int openDevice(memb_hip_ctx* ctx, int device)
+{
+    int count = 0;
+    hipError_t status = hipGetDeviceCount(&count);
+    if (status != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(MEMB_HIP_ERR_DEVICE, "no HIP device available");
+    }
+    if (device < 0 || device >= count) {
+        return fail(MEMB_HIP_ERR_INVALID, "device index out of range");
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t properties;
+    HIP_TRY(hipGetDeviceProperties(&properties, device));
+    ctx->device = device;
+    ctx->cuCount = properties.multiProcessorCount;
+    ctx->ldsLimit = static_cast<uint32_t>(std::min<size_t>(properties.sharedMemPerBlock, 160 * 1024));
+    if (properties.maxSharedMemoryPerMultiProcessor >= 160 * 1024) {
+        ctx->ldsLimit = 160 * 1024;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    return MEMB_HIP_OK;
+}
+
+void destroy(memb_hip_ctx* ctx)
+{
+    if (!ctx) {
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    for (void* allocation : ctx->allocations) {
+        (void)hipFree(allocation);
+    }
+    if (ctx->stagedRows) {
+        (void)hipFree(ctx->stagedRows);
+    }
+    if (ctx->stagedOut) {
+        (void)hipFree(ctx->stagedOut);
+    }
+    if (ctx->stream) {
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* memb_hip_last_error(void)
+{
+    return g_lastError.c_str();
+}
+
+int memb_hip_device_count(int* count)
+{
+    if (!count) {
+        return fail(MEMB_HIP_ERR_INVALID, "count is null");
+    }
+    *count = 0;
+    hipError_t status = hipGetDeviceCount(count);
+    if (status != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
+{
+    if (!out || !desc) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    *out = nullptr;
+    if (desc->dim == 0 || desc->n_keys == 0 || desc->n_keys > 256 || desc->n_centroids > 255 ||
+        (desc->n_rows && !desc->value_offsets) || (desc->packed_values_bytes && !desc->packed_values)) {
+        return fail(MEMB_HIP_ERR_INVALID, "inconsistent trained storage description");
+    }
+
+    memb_hip_ctx* ctx = new memb_hip_ctx();
+    ctx->storage = memb::wire::Storage_Trained;
+    ctx->dim = desc->dim;
+    ctx->nRows = desc->n_rows;
+    int code = MEMB_HIP_OK;
+    try {
+        auto lengths = memb::codeLengthsFromSizeOffsets(
+            desc->keys, desc->n_keys, desc->size_offsets, desc->n_size_offsets);
+        for (const auto& info : lengths) {
+            if (info.key >= desc->n_centroids) {
+                throw std::runtime_error("Huffman symbol without a centroid");
+            }
+        }
+        uint32_t limit = desc->max_direct_bits ? desc->max_direct_bits : envUint("MEMB_HIP_ROOT_BITS", 11);
+        ctx->hostTable = memb::buildDecodeTable(lengths, std::min<uint32_t>(limit, 12));
+    } catch (const std::exception& error) {
+        delete ctx;
+        return fail(MEMB_HIP_ERR_INVALID, error.what());
+    }
+
+    // Per-row stream length: streams are laid out back to back, so a stream
+    // ends where the next one (in storage order) begins.
+    {
+        std::vector<uint64_t> order(desc->n_rows);
+        for (uint64_t r = 0; r < desc->n_rows; ++r) {
+            if (desc->value_offsets[r] > desc->packed_values_bytes) {
+                delete ctx;
+                return fail(MEMB_HIP_ERR_INVALID, "value offset beyond packed values");
+            }
+            order[r] = (static_cast<uint64_t>(desc->value_offsets[r]) << 32) | r;
+        }
+        std::sort(order.begin(), order.end());
+        ctx->streamBytes.assign(desc->n_rows, 0);
+        uint64_t nextStart = desc->packed_values_bytes;
+        uint64_t previousOffset = desc->packed_values_bytes;
+        for (size_t i = order.size(); i > 0; --i) {
+            uint64_t offset = order[i - 1] >> 32;
+            uint32_t rowIndex = static_cast<uint32_t>(order[i - 1]);
+            if (offset != previousOffset) {
+                nextStart = previousOffset;
+                previousOffset = offset;
+            }
+            uint64_t bytes = nextStart - offset;
+            // a stream never holds more than dim codes of the longest length
+            uint64_t bound = (static_cast<uint64_t>(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) + 7) / 8;
+            ctx->streamBytes[rowIndex] = static_cast<uint32_t>(std::min(bytes, bound));
+            ctx->maxStreamBytes = std::max(ctx->maxStreamBytes, ctx->streamBytes[rowIndex]);
+        }
+    }
+    // Slot: stream, up to 3 bytes of alignment slack in front, and the 12-byte
+    // window the decoder reads at its last position; whole 16-byte pieces.
+    ctx->slotDwords = ((ctx->maxStreamBytes + 3 + 12 + 15) / 16) * 4;
+    ctx->tableDwords = static_cast<uint32_t>((ctx->hostTable.entries.size() + 3) / 4 * 4);
+
+    code = openDevice(ctx, device);
+    if (code == MEMB_HIP_OK) {
+        // guard: a slot-sized read may start at the last byte
+        size_t guard = size_t(ctx->slotDwords) * 4 + 16;
+        code = deviceAlloc(ctx, &ctx->packed, desc->packed_values_bytes + guard);
+        if (code == MEMB_HIP_OK) {
+            hipError_t status = hipMemset(ctx->packed + desc->packed_values_bytes, 0, guard);
+            if (status != hipSuccess) {
+                code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(status));
+            }
+        }
+    }
+    if (code == MEMB_HIP_OK) {
+        code = copyToDevice(ctx->packed, desc->packed_values, desc->packed_values_bytes);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->valueOffsets, desc->n_rows * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = copyToDevice(ctx->valueOffsets, desc->value_offsets, desc->n_rows * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        std::vector<uint32_t> padded(ctx->tableDwords, 0);
+        std::copy(ctx->hostTable.entries.begin(), ctx->hostTable.entries.end(), padded.begin());
+        code = copyToDevice(ctx->table, padded.data(), padded.size() * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->centroids, 256 * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        std::vector<float> codebook(256, 0.f);
+        std::copy(desc->centroids, desc->centroids + desc->n_centroids, codebook.begin());
+        codebook[ZERO_KEY] = 0.f;
+        code = copyToDevice(ctx->centroids, codebook.data(), 256 * 4);
+    }
+    if (code == MEMB_HIP_OK) {
+        TrainedGeometry geometry = chooseGeometry(ctx, ctx->dim, 0, nullptr);
+        if (!geometry.waves) {
+            code = fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
+        }
+    }
+    if (code != MEMB_HIP_OK) {
+        std::string message = g_lastError;
+        destroy(ctx);
+        g_lastError = message;
+        return code;
+    }
+    *out = ctx;
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_ctx_create_uniform(memb_hip_ctx** out, int device, const memb_hip_uniform_desc* desc)
+{
+    if (!out || !desc) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    *out = nullptr;
+    if (desc->dim == 0 || (desc->n_rows && !desc->rows)) {
+        return fail(MEMB_HIP_ERR_INVALID, "inconsistent uniform storage description");
+    }
+    memb_hip_ctx* ctx = new memb_hip_ctx();
+    ctx->storage = memb::wire::Storage_Uniform;
+    ctx->dim = desc->dim;
+    ctx->nRows = desc->n_rows;
+    ctx->levels = static_cast<float>(desc->quantization_levels);
+
+    // HBM layout: dense [n_rows][dim] bytes plus one {min, max} pair per row.
+    // The file scatters each row in its own table; rows shorter than dim are
+    // zero padded (the reference writes only values->size() outputs there).
+    std::vector<uint8_t> values(size_t(desc->n_rows) * desc->dim, 0);
+    std::vector<float2> minMax(desc->n_rows);
+    for (uint64_t r = 0; r < desc->n_rows; ++r) {
+        const memb_hip_uniform_row& row = desc->rows[r];
+        size_t count = std::min<size_t>(row.n_values, desc->dim);
+        if (count) {
+            std::memcpy(values.data() + r * desc->dim, row.values, count);
+        }
+        minMax[r] = make_float2(row.min_value, row.max_value);
+    }
+
+    int code = openDevice(ctx, device);
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->uniformValues, values.size() + 16);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = copyToDevice(ctx->uniformValues, values.data(), values.size());
+    }
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->minMax, minMax.size() * sizeof(float2));
+    }
+    if (code == MEMB_HIP_OK) {
+        code = copyToDevice(ctx->minMax, minMax.data(), minMax.size() * sizeof(float2));
+    }
+    if (code != MEMB_HIP_OK) {
+        std::string message = g_lastError;
+        destroy(ctx);
+        g_lastError = message;
+        return code;
+    }
+    *out = ctx;
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full_desc* desc)
+{
+    if (!out || !desc) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    *out = nullptr;
+    if (desc->dim == 0 || (desc->n_rows && !desc->rows)) {
+        return fail(MEMB_HIP_ERR_INVALID, "inconsistent full storage description");
+    }
+    memb_hip_ctx* ctx = new memb_hip_ctx();
+    ctx->storage = memb::wire::Storage_Full;
+    ctx->dim = desc->dim;
+    ctx->nRows = desc->n_rows;
+
+    std::vector<float> values(size_t(desc->n_rows) * desc->dim, 0.f);
+    for (uint64_t r = 0; r < desc->n_rows; ++r) {
+        const memb_hip_full_row& row = desc->rows[r];
+        size_t count = std::min<size_t>(row.n_values, desc->dim);
+        if (count) {
+            std::memcpy(values.data() + r * desc->dim, row.values, count * sizeof(float));
+        }
+    }
+    int code = openDevice(ctx, device);
+    if (code == MEMB_HIP_OK) {
+        code = deviceAlloc(ctx, &ctx->fullValues, values.size() * sizeof(float) + 16);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = copyToDevice(ctx->fullValues, values.data(), values.size() * sizeof(float));
+    }
+    if (code != MEMB_HIP_OK) {
+        std::string message = g_lastError;
+        destroy(ctx);
+        g_lastError = message;
+        return code;
+    }
+    *out = ctx;
+    return MEMB_HIP_OK;
+}
+
+void memb_hip_ctx_destroy(memb_hip_ctx* ctx)
+{
+    destroy(ctx);
+}
+
+int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
+{
+    if (!ctx || !info) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    std::memset(info, 0, sizeof(*info));
+    info->device = ctx->device;
+    info->storage = ctx->storage;
+    info->dim = ctx->dim;
+    info->n_rows = ctx->nRows;
+    info->device_bytes = ctx->deviceBytes;
+    if (ctx->storage == memb::wire::Storage_Trained) {
+        info->root_bits = ctx->hostTable.rootBits;
+        info->max_code_bits = ctx->hostTable.maxCodeBits;
+        info->table_entries = static_cast<uint32_t>(ctx->hostTable.entries.size());
+        info->max_stream_bytes = ctx->maxStreamBytes;
+        TrainedGeometry geometry = chooseGeometry(ctx, ctx->dim, 0, nullptr);
+        info->waves_per_block = geometry.waves;
+        info->chunk_symbols = geometry.chunk;
+        info->lds_bytes_per_block = geometry.ldsBytes;
+    } else {
+        info->waves_per_block = ROWWISE_THREADS / WAVE;
+    }
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_decode_rows_device(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream)
+{
+    if (!ctx || (n && (!rows || !out))) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    if (ld < col_off + ctx->dim) {
+        return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t target = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    return launch(ctx, rows, n, out, ld, col_off, target);
+}
+
+int memb_hip_decode_rows(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
+{
+    if (!ctx || (n && (!rows || !out))) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    if (ld < col_off + ctx->dim) {
+        return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
+    }
+    if (n == 0) {
+        return MEMB_HIP_OK;
+    }
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // Device staging holds dense [words][dim] rows; batches larger than the
+    // staging area are processed in slices.
+    const size_t dim = ctx->dim;
+    const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, (size_t(512) << 20) / (dim * sizeof(float))));
+    if (ctx->stagedCapacity < sliceWords) {
+        if (ctx->stagedRows) {
+            (void)hipFree(ctx->stagedRows);
+            ctx->stagedRows = nullptr;
+        }
+        if (ctx->stagedOut) {
+            (void)hipFree(ctx->stagedOut);
+            ctx->stagedOut = nullptr;
+        }
+        ctx->stagedCapacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedRows), sliceWords * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedOut), sliceWords * dim * sizeof(float)));
+        ctx->stagedCapacity = sliceWords;
+    }
+    for (size_t start = 0; start < n; start += sliceWords) {
+        const size_t words = std::min(sliceWords, n - start);
+        HIP_TRY(hipMemcpyAsync(
+            ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        int code = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
+        if (code != MEMB_HIP_OK) {
+            return code;
+        }
+        HIP_TRY(hipMemcpy2DAsync(
+            out + start * ld + col_off,
+            ld * sizeof(float),
+            ctx->stagedOut,
+            dim * sizeof(float),
+            dim * sizeof(float),
+            words,
+            hipMemcpyDeviceToHost,
+            ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_sync(memb_hip_ctx* ctx)
+{
+    if (!ctx) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MEMB_HIP_OK;
+}
+
+int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes)
+{
+    if (!ctx || !bytes || (n && !rows)) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    uint64_t total = 0;
+    const uint64_t rowBytes = 4ull * ctx->dim;
+    for (size_t i = 0; i < n; ++i) {
+        total += 4 + rowBytes;
+        if (rows[i] >= ctx->nRows) {
+            continue;
+        }
+        switch (ctx->storage) {
+            case memb::wire::Storage_Trained:
+                total += 4 + ctx->streamBytes[rows[i]];
+                break;
+            case memb::wire::Storage_Uniform:
+                total += 12 + ctx->dim;
+                break;
+            case memb::wire::Storage_Full:
+                total += 4 + rowBytes;
+                break;
+            default:
+                break;
+        }
+    }
+    *bytes = total;
+    return MEMB_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+#include "reader.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <stdexcept>
+#include <thread>
+
+namespace memb {
+
+namespace {
+
+const size_t THREADED_DECODER_THRESHOLD = 1024;  // reference src/reader.cpp:9
+
+int deviceFromEnvironment()
+{
+    const char* text = std::getenv("MEMB_HIP_DEVICE");
+    if (!text || !*text) {
+        // one process per GPU under torchrun: follow the launcher's rank
+        text = std::getenv("LOCAL_RANK");
+        if (!text || !*text || !std::getenv("MEMB_HIP_FOLLOW_LOCAL_RANK")) {
+            return 0;
+        }
+    }
+    return std::atoi(text);
+}
+
+}  // namespace
+
+MappedFile::MappedFile(const std::string& filename)
+{
+    int descriptor = ::open(filename.c_str(), O_RDONLY);
+    if (descriptor < 0) {
+        throw std::runtime_error("failed opening file: " + filename + ": " + std::strerror(errno));
+    }
+    struct stat info;
+    if (::fstat(descriptor, &info) != 0) {
+        int error = errno;
+        ::close(descriptor);
+        throw std::runtime_error("failed reading file size: " + filename + ": " + std::strerror(error));
+    }
+    size_ = static_cast<size_t>(info.st_size);
+    if (size_ > 0) {
+        void* mapping = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, descriptor, 0);
+        if (mapping == MAP_FAILED) {
+            int error = errno;
+            ::close(descriptor);
+            throw std::runtime_error("failed mapping file: " + filename + ": " + std::strerror(error));
+        }
+        data_ = static_cast<const uint8_t*>(mapping);
+    }
+    ::close(descriptor);
+}
+
+MappedFile::~MappedFile()
+{
+    if (data_) {
+        ::munmap(const_cast<uint8_t*>(data_), size_);
+    }
+}
+
+// reference src/reader.cpp:13-29
+Reader::Reader(
+        const std::string& filename,
+        std::shared_ptr<CompressionStrategy> compressionStrategy,
+        size_t numThreads,
+        int device):
+    numThreads_(adjustedNumThreads(numThreads)),
+    mappedFile_(filename),
+    flatIndex_(getIndexChecked())
+{
+    init(compressionStrategy, device);
+}
+
+Reader::Reader(const std::string& filename, size_t numThreads, int device):
+    numThreads_(adjustedNumThreads(numThreads)),
+    mappedFile_(filename),
+    flatIndex_(getIndexChecked())
+{
+    auto storageType = static_cast<wire::Storage>(
+        flatIndex_.scalar<uint8_t>(wire::field::Index_storage_type, wire::Storage_NONE));
+    init(createCompressionStrategy(storageType), device);
+}
+
+void Reader::init(std::shared_ptr<CompressionStrategy> compressionStrategy, int device)
+{
+    dim_ = flatIndex_.scalar<uint32_t>(wire::field::Index_dim, 0);
+    storageName_ = compressionStrategy->storageName();
+    compressedStorage_ = compressionStrategy->createCompressedStorage(
+        flatIndex_.table(wire::field::Index_storage), dim_);
+    compressedStorage_->setDevice(device >= 0 ? device : deviceFromEnvironment());
+}
+
+size_t Reader::dim() const
+{
+    return dim_;
+}
+
+size_t Reader::size() const
+{
+    return compressedStorage_->rowCount();
+}
+
+int Reader::device() const
+{
+    return compressedStorage_->device();
+}
+
+std::string Reader::storageName() const
+{
+    return storageName_;
+}
+
+std::vector<std::string> Reader::keys() const
+{
+    return compressedStorage_->keys();
+}
+
+memb_hip_ctx* Reader::deviceContext() const
+{
+    return compressedStorage_->deviceContext();
+}
+
+// reference src/reader.cpp:41-47
+void Reader::wordEmbeddingToBuffer(const std::string& word, float* buffer) const
+{
+    auto extractResult = compressedStorage_->extract(word, buffer);
+    if (!extractResult) {
+        std::fill(buffer, buffer + dim(), 0);
+    }
+}
+
+// Host half of the batch driver. The reference splits a batch of >= 1024
+// words over numThreads_ std::async jobs that search and decode
+// (src/reader.cpp:59-86); here the jobs only search, the decode of the whole
+// batch is one kernel launch.
+void Reader::resolveRows(const std::vector<std::string>& words, uint32_t* rows) const
+{
+    const CompressedStorage* storage = compressedStorage_.get();
+    auto resolveRange = [storage, &words, rows](size_t first, size_t last) {
+        for (size_t idx = first; idx < last; ++idx) {
+            uint32_t row = MEMB_HIP_MISSING_ROW;
+            rows[idx] = storage->resolve(words[idx].c_str(), &row) ? row : MEMB_HIP_MISSING_ROW;
+        }
+    };
+
+    if (words.size() < THREADED_DECODER_THRESHOLD || numThreads_ == 1) {
+        resolveRange(0, words.size());
+        return;
+    }
+    size_t jobSize = (words.size() + numThreads_ - 1) / numThreads_;
+    std::vector<std::future<void>> results;
+    for (size_t startIndex = 0; startIndex < words.size(); startIndex += jobSize) {
+        size_t endIndex = std::min(startIndex + jobSize, words.size());
+        results.push_back(std::async(std::launch::async, resolveRange, startIndex, endIndex));
+    }
+    for (auto& future : results) {
+        future.get();
+    }
+}
+
+void Reader::batchEmbeddingToStridedBuffer(
+    const std::vector<std::string>& words, float* buffer, size_t ld, size_t colOff) const
+{
+    if (words.empty()) {
+        return;
+    }
+    std::vector<uint32_t> rows(words.size());
+    resolveRows(words, rows.data());
+    compressedStorage_->decodeRows(rows.data(), rows.size(), buffer, ld, colOff);
+}
+
+void Reader::batchEmbeddingToBuffer(const std::vector<std::string>& words, float* buffer) const
+{
+    batchEmbeddingToStridedBuffer(words, buffer, dim(), 0);
+}
+
+void Reader::rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff) const
+{
+    compressedStorage_->decodeRows(rows, n, buffer, ld, colOff);
+}
+
+void Reader::rowsToDeviceBuffer(
+    const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream) const
+{
+    compressedStorage_->decodeRowsDevice(rows, n, buffer, ld, colOff, stream);
+}
+
+std::vector<float> Reader::wordEmbedding(const std::string& word) const
+{
+    std::vector<float> result(dim());
+    wordEmbeddingToBuffer(word, result.data());
+    return result;
+}
+
+std::vector<float> Reader::batchEmbedding(const std::vector<std::string>& words) const
+{
+    std::vector<float> result(dim() * words.size());
+    batchEmbeddingToBuffer(words, result.data());
+    return result;
+}
+
+// reference src/reader.cpp:104-111
+wire::TableView Reader::getIndexChecked() const
+{
+    wire::Blob blob;
+    blob.data = mappedFile_.data();
+    blob.size = mappedFile_.size();
+    return wire::getIndexChecked(blob);
+}
+
+// reference src/reader.cpp:113-120
+size_t Reader::adjustedNumThreads(size_t numThreads) const
+{
+    if (numThreads > 0) {
+        return numThreads;
+    }
+    return std::max(std::thread::hardware_concurrency(), 2u);
+}
+
+}  // namespace memb

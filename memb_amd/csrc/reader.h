@@ -1,0 +1,85 @@
+// memb::Reader -- the reference's public read API (src/reader.h:11-40) over
+// the HIP batch-lookup path: same constructors and methods, same semantics
+// (caller-owned row-major output, missing words give zero rows).
+#pragma once
+
+#include "compression_strategy.h"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace memb {
+
+// Read-only mapping of a whole file (the reference uses
+// boost::iostreams::mapped_file_source, src/reader.h:37).
+class MappedFile {
+public:
+    explicit MappedFile(const std::string& filename);
+    ~MappedFile();
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+
+    const uint8_t* data() const { return data_; }
+    size_t size() const { return size_; }
+
+private:
+    const uint8_t* data_ = nullptr;
+    size_t size_ = 0;
+};
+
+class Reader {
+public:
+    // device < 0: taken from the environment variable MEMB_HIP_DEVICE, default 0.
+    Reader(const std::string& filename, size_t numThreads = 0, int device = -1);
+    Reader(
+        const std::string& filename,
+        std::shared_ptr<CompressionStrategy> compressionStrategy,
+        size_t numThreads = 0,
+        int device = -1);
+
+    size_t dim() const;
+    std::vector<std::string> keys() const;
+
+    void wordEmbeddingToBuffer(const std::string& word, float* buffer) const;
+    void batchEmbeddingToBuffer(const std::vector<std::string>& words, float* buffer) const;
+
+    std::vector<float> wordEmbedding(const std::string& word) const;
+    std::vector<float> batchEmbedding(const std::vector<std::string>& words) const;
+
+    // --- additions for callers that keep data on the device or build wider rows ---
+
+    size_t size() const;  // number of words in the file
+    int device() const;
+    std::string storageName() const;
+
+    // Sorted-order row ids of `words` (MEMB_HIP_MISSING_ROW for unknown words),
+    // resolved on up to numThreads host threads.
+    void resolveRows(const std::vector<std::string>& words, uint32_t* rows) const;
+
+    // batchEmbeddingToBuffer into a wider row-major matrix: row i goes to
+    // buffer[i * ld + colOff .. + dim) (ReadersUnion 'concatenate').
+    void batchEmbeddingToStridedBuffer(
+        const std::vector<std::string>& words, float* buffer, size_t ld, size_t colOff) const;
+
+    // Lookup by row id with host or device buffers (see include/memb_hip.h).
+    void rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff) const;
+    void rowsToDeviceBuffer(
+        const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream) const;
+
+    memb_hip_ctx* deviceContext() const;
+
+private:
+    wire::TableView getIndexChecked() const;
+    size_t adjustedNumThreads(size_t numThreads) const;
+    void init(std::shared_ptr<CompressionStrategy> compressionStrategy, int device);
+
+    size_t numThreads_;
+    MappedFile mappedFile_;
+    wire::TableView flatIndex_;
+    size_t dim_ = 0;
+    std::string storageName_;
+    std::shared_ptr<CompressedStorage> compressedStorage_;
+};
+
+}  // namespace memb

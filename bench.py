@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the memb batch-lookup hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch: every word of a synthetic
+GloVe-840B-shaped model (2,196,017 words x 300, trained 4-bit) is looked up
+once, row ids and the fp32 output resident in HBM (BASELINE.json north_star:
+">= 50 % of HBM bandwidth on a 2.2M-word x 300-dim 4-bit batch lookup").
+With N > 1 (one process per GPU, launched by torch.distributed.run) every rank
+holds a replica of the model and looks up its own full-size batch -- shards of
+a vocabulary N times as large -- with no collective on the data path (weak
+scaling); value = words all ranks decoded / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy on MI355X (same guide)
+
+WORKLOADS = {
+    # name: (words, bits, batch) ; batch None = every key (full dump)
+    'glove840b-300d-4bit-fullvocab': (2196017, 4, None),     # north-star headline (SURVEY 8d "H")
+    'glove840b-300d-4bit-100k': (2196017, 4, 100000),        # BASELINE.json configs[1]
+    'small-4bit': (50000, 4, None),                          # quick functional run
+}
+
+
+def parse_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=20)
+    parser.add_argument('--warmup', type=int, default=5)
+    parser.add_argument('--workload', default='glove840b-300d-4bit-fullvocab', choices=sorted(WORKLOADS))
+    parser.add_argument('--cache-dir', default=os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench'))
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    return parser.parse_args()
+
+
+def cpu_baseline(path, rows_host, dim):
+    """The CPU restatement (oracle/memb_oracle.c), decode only, on this box's host cores."""
+    import numpy as np
+    import oracle
+    cores = os.cpu_count() or 1
+    reader = oracle.OracleReader(path, cores)
+    sample = rows_host
+    out = np.empty((len(sample), dim), dtype=np.float32)
+    best = float('inf')
+    deadline = time.time() + 20.0
+    passes = 0
+    while passes < 3 and time.time() < deadline:
+        start = time.time()
+        reader.rows_embedding(sample, out=out, num_threads=cores)
+        best = min(best, time.time() - start)
+        passes += 1
+    single = sample[:min(len(sample), 100000)]
+    start = time.time()
+    reader.rows_embedding(single, out=out[:len(single)], num_threads=1)
+    single_rate = len(single) / (time.time() - start)
+    return {
+        'value': len(sample) / best,
+        'unit': 'embeddings/s',
+        'cores': cores,
+        'kind': 'port',
+        'sample': '{} pre-resolved rows of the same batch, decode only, best of {} passes; single thread: {:.0f} embeddings/s on {} rows'.format(
+            len(sample), passes, single_rate, len(single)),
+    }, out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit('--gpus {} needs torch.distributed.run with one process per GPU'.format(args.gpus))
+        args.gpus = world_size
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    distributed = world_size > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist.barrier()
+    import memb_amd
+
+    words, bits, batch = WORKLOADS[args.workload]
+    from memb_amd import synthetic
+    os.environ['MEMB_BENCH_CACHE'] = args.cache_dir
+    build_seconds = 0.0
+    if rank == 0:
+        path, build_seconds = synthetic.cached_model(words, 300, 'trained', bits)   # written once per box
+    if distributed:
+        dist.barrier()
+    path, _ = synthetic.cached_model(words, 300, 'trained', bits)
+
+    open_start = time.time()
+    reader = memb_amd.Reader(path, device=local_rank)
+    info = reader.info()   # stages the model to HBM
+    open_seconds = time.time() - open_start
+    dim = reader.dim
+    count = len(reader)
+
+    if batch is None:
+        rows_host = np.arange(count, dtype=np.uint32)   # batch = keys(): rows in sorted-word order
+    else:
+        rng = np.random.default_rng(11)
+        rows_host = rng.integers(0, count, size=batch).astype(np.uint32)
+        rows_host[rng.integers(0, batch, size=batch // 100)] = 0xFFFFFFFF   # 1 % misses
+    n = len(rows_host)
+
+    import ctypes
+    library = ctypes.CDLL(memb_amd.HIP_LIBRARY_PATH)
+    algorithmic = ctypes.c_uint64(0)
+    library.memb_hip_algorithmic_bytes(
+        ctypes.c_void_p(reader._impl.context_handle()), rows_host.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_size_t(n), ctypes.byref(algorithmic))
+    algorithmic_bytes = algorithmic.value
+
+    rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
+    out = torch.empty((n, dim), dtype=torch.float32, device='cuda')
+
+    def step():
+        reader.rows_embedding_device(rows, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # per-launch kernel durations from HIP events on the stream the kernel runs on
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall_start = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        stops[i].record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - wall_start
+    if distributed:
+        slowest = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        elapsed = float(slowest.item())
+    kernel_ms = sorted(starts[i].elapsed_time(stops[i]) for i in range(args.steps))
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # parity spot check of the timed output against the CPU checker, and the CPU baseline
+    baseline = None
+    parity = 'skipped'
+    if not args.no_cpu_baseline:
+        baseline, expected = cpu_baseline(path, rows_host, dim)
+        got = out.cpu().numpy()
+        parity = 'bit-exact' if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
+
+    achieved_gbps = algorithmic_bytes / (kernel_avg_ms * 1e-3) / 1e9
+    traffic = None
+    traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            traffic = json.load(f).get(args.workload)
+
+    result = {
+        'metric': 'embeddings/sec (and HBM GB/s vs roofline), 300-dim 4-bit batch lookup',
+        'value': args.gpus * n * args.steps / elapsed,
+        'unit': 'embeddings/s',
+        'n_gpus': args.gpus,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'u32',
+        'data': 'synthetic',
+        'config': {
+            'workload': args.workload,
+            'vocabulary': count,
+            'dim': dim,
+            'storage': 'trained',
+            'bits_per_weight': bits,
+            'batch_per_gpu': n,
+            'batch': 'keys() full dump' if batch is None else 'uniform random rows, 1% misses, seed 11',
+            'vectors': 'N(0, 0.4^2) seed 1234, written by memb_amd.Builder',
+            'parallelism': 'batch shards, model replicated per GPU, no collective',
+        },
+        'roofline': {
+            'bound': 'hbm',
+            'achieved': achieved_gbps,
+            'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s',
+            'frac': achieved_gbps / HBM_PEAK_GBPS,
+            'traffic': traffic,
+            'kernel': 'decode_trained',
+            'kernel_avg_ms': kernel_avg_ms,
+            'kernel_min_ms': kernel_ms[0],
+            'algorithmic_bytes_per_launch': algorithmic_bytes,
+            'algorithmic_bytes_per_word': algorithmic_bytes / n,
+            'frac_of_copy_ceiling': achieved_gbps / HBM_COPY_CEILING_GBPS,
+        },
+        'cpu_baseline': baseline,
+        'parity_vs_cpu_checker': parity,
+        'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
+        'geometry': {k: info[k] for k in ('waves_per_block', 'chunk_symbols', 'lds_bytes_per_block', 'root_bits',
+                                          'max_code_bits', 'max_stream_bytes', 'device_bytes')},
+        'model_build_s': build_seconds,
+        'reader_open_s': open_seconds,
+    }
+    print(json.dumps(result))
+    sys.stdout.flush()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -136,13 +136,13 @@ int memb_hip_decode_rows(
 
 /*
  * Batch lookup, device buffers: `rows` and `out` are device pointers on the
- * context's device; the kernel is enqueued on `stream` (a hipStream_t, NULL =
- * the context's own stream) and the call returns without waiting.
+ * context's device; the kernel is enqueued on `stream` (a hipStream_t; NULL is
+ * HIP's default stream) and the call returns without waiting.
  */
 int memb_hip_decode_rows_device(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream);
 
-/* Wait for everything enqueued on the context's own stream. */
+/* Wait for the context's own stream (used by memb_hip_decode_rows). */
 int memb_hip_sync(memb_hip_ctx* ctx);
 
 /*

@@ -7,6 +7,41 @@ built (`python build_native.py`) and a HIP device must be present.
 """
 import os as _os
 
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7,
+    like the system one in /opt/rocm). If libmemb_hip.so pulled in the system
+    copy first and torch were imported later, the process would hold two HIP/HSA
+    runtimes: torch then finds no GPU, and streams or events made by one runtime
+    mean nothing to the other. Loading torch's copy first makes the dynamic
+    loader resolve libmemb_hip.so's dependency to it (same soname). Without
+    torch the system runtime is used. MEMB_HIP_RUNTIME overrides the choice.
+    """
+    import ctypes
+    import importlib.util
+    candidates = []
+    if _os.environ.get('MEMB_HIP_RUNTIME'):
+        candidates.append(_os.environ['MEMB_HIP_RUNTIME'])
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        candidates.append(_os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so'))
+    for candidate in candidates:
+        if _os.path.exists(candidate):
+            try:
+                ctypes.CDLL(candidate, mode=ctypes.RTLD_GLOBAL)
+                return candidate
+            except OSError:
+                continue
+    return None
+
+
+HIP_RUNTIME_PRELOADED = _preload_hip_runtime()
+
 try:
     from . import _memb
 except ImportError as error:  # fail loudly: nothing here works without the native code

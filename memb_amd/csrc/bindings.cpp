@@ -6,6 +6,7 @@
 #include "builder.h"
 #include "reader.h"
 #include "compression_strategy.h"
+#include "codec.h"
 
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -208,6 +209,37 @@ PYBIND11_MODULE(_memb, m) {
             py::arg("stream") = 0);
 
     m.def("available_compression_strategies", &memb::availableCompressionStrategies);
+
+    // Hooks for the reference's unit tests of the Builder's pieces
+    // (src/kmeans_tests.cpp:9-38, src/bit_stream_tests.cpp:31-59).
+    m.def("_kmeans_fit_predict", [](const std::vector<float>& data, size_t levels) {
+        memb::KMeansClusterizer clusterizer(levels);
+        clusterizer.fit(data);
+        std::vector<uint8_t> assignments;
+        clusterizer.predict(data.data(), data.size(), &assignments);
+        return py::make_tuple(clusterizer.centroids(), std::vector<int>(assignments.begin(), assignments.end()));
+    });
+    m.def("_bit_pack", [](const std::vector<std::pair<uint32_t, uint32_t>>& codes) {
+        memb::BitWriter writer;
+        for (const auto& code : codes) {
+            writer.push(code.first, code.second);
+        }
+        writer.flushToByte();
+        return py::bytes(reinterpret_cast<const char*>(writer.bytes().data()), writer.bytes().size());
+    });
+    m.def("_huffman_description", [](const std::vector<uint64_t>& counts) {
+        auto lengths = memb::huffmanCodeLengths(counts);
+        std::vector<uint8_t> keys;
+        std::vector<uint32_t> sizeOffsets;
+        memb::decoderDescription(lengths, &keys, &sizeOffsets);
+        return py::make_tuple(std::vector<int>(keys.begin(), keys.end()), sizeOffsets);
+    });
+    m.def("_decode_table", [](const std::vector<int>& keys, const std::vector<uint32_t>& sizeOffsets, uint32_t rootBitsLimit) {
+        std::vector<uint8_t> narrow(keys.begin(), keys.end());
+        auto lengths = memb::codeLengthsFromSizeOffsets(narrow.data(), narrow.size(), sizeOffsets.data(), sizeOffsets.size());
+        auto table = memb::buildDecodeTable(lengths, rootBitsLimit);
+        return py::make_tuple(table.rootBits, table.maxCodeBits, table.hasSubTables, table.entries);
+    });
 
     m.def("hip_device_count", []() {
         int count = 0;

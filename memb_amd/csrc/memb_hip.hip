@@ -87,6 +87,13 @@ enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2 };
 // on arbitrary bytes; the staging copy starts at the enclosing dword).
 typedef uint4 __attribute__((aligned(4))) uint4_align4;
 
+// q / d with a host-computed magic = ceil(2^32 / d) (exact while q * d < 2^32);
+// magic == 0 means "no magic" (d == 1, or the range is too large): plain division.
+__device__ __forceinline__ uint32_t fastDivide(uint32_t q, uint32_t magic, uint32_t d)
+{
+    return magic ? __umulhi(q, magic) : q / d;
+}
+
 __device__ __forceinline__ uint32_t byteSwap(uint32_t v)
 {
     return __builtin_bswap32(v);
@@ -155,7 +162,7 @@ __global__ void decode_trained(TrainedParams p)
             for (int b = 0; b < BATCH; ++b) {
                 const uint32_t q = q0 + WAVE * b;
                 if (q < totalPieces) {
-                    const uint32_t w = __umulhi(q, p.slotMagic);
+                    const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
                     const uint32_t piece = q - w * piecesPerWord;
                     const uint32_t wordOffset = __shfl(sourceOffset, w);
                     v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
@@ -237,7 +244,7 @@ __global__ void decode_trained(TrainedParams p)
             const uint32_t magic = (chunkSymbols == p.chunk) ? p.chunkMagic : 0;
             const uint32_t pieces = tileWords * piecesPerWord;
             for (uint32_t q = lane; q < pieces; q += WAVE) {
-                const uint32_t w = magic ? __umulhi(q, magic) : q / piecesPerWord;
+                const uint32_t w = fastDivide(q, magic, piecesPerWord);
                 const uint32_t c = q - w * piecesPerWord;
                 const uint32_t k = keyTile[w * p.keyStride + c];
                 float4 f;
@@ -281,12 +288,37 @@ struct UniformParams {
     float levels;
 };
 
+// Single-lane-op IEEE fp32 add / sub / mul. Written as instructions because the
+// optimiser otherwise pairs neighbouring operations into v_pk_add_f32 /
+// v_pk_mul_f32, and the packed forms flush subnormal values on gfx950 (measured:
+// min = 1e-40 came back as 0), which would break bit parity with the CPU.
+__device__ __forceinline__ float addRn(float a, float b)
+{
+    float r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float subRn(float a, float b)
+{
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float mulRn(float a, float b)
+{
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // reference src/uniform_compression.cpp:70-71, evaluated left to right in fp32:
-// sub, mul, div, add -- each correctly rounded, nothing fused.
+// sub, mul, div, add -- each correctly rounded, nothing fused, subnormals kept.
 __device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels)
 {
-    const float scaled = __fmul_rn(range, static_cast<float>(v));
-    return __fadd_rn(minValue, __fdiv_rn(scaled, levels));
+    const float scaled = mulRn(range, static_cast<float>(v));
+    return addRn(minValue, __fdiv_rn(scaled, levels));
 }
 
 template <bool VEC4>
@@ -300,13 +332,13 @@ __global__ void dequant_uniform(UniformParams p)
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = blockWords * piecesPerWord;
         for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
-            const uint32_t w = __umulhi(q, p.pieceMagic);
+            const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
             const uint32_t c = q - w * piecesPerWord;
             const uint32_t row = p.rows[blockBase + w];
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < p.nRows) {
                 const float2 mm = p.minMax[row];
-                const float range = __fsub_rn(mm.y, mm.x);
+                const float range = subRn(mm.y, mm.x);
                 const uint32_t v =
                     *reinterpret_cast<const uint32_t*>(p.values + static_cast<unsigned long long>(row) * p.dim + 4 * c);
                 f.x = dequant(mm.x, range, v & 0xff, p.levels);
@@ -326,7 +358,7 @@ __global__ void dequant_uniform(UniformParams p)
             float f = 0.f;
             if (row < p.nRows) {
                 const float2 mm = p.minMax[row];
-                const float range = __fsub_rn(mm.y, mm.x);
+                const float range = subRn(mm.y, mm.x);
                 f = dequant(mm.x, range, p.values[static_cast<unsigned long long>(row) * p.dim + c], p.levels);
             }
             p.out[(blockBase + w) * p.ld + p.colOff + c] = f;
@@ -357,7 +389,7 @@ __global__ void gather_full(FullParams p)
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = blockWords * piecesPerWord;
         for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
-            const uint32_t w = __umulhi(q, p.pieceMagic);
+            const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
             const uint32_t c = q - w * piecesPerWord;
             const uint32_t row = p.rows[blockBase + w];
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -378,9 +410,14 @@ __global__ void gather_full(FullParams p)
     }
 }
 
-// ceil(2^32 / d); __umulhi(q, magic) == q / d while q * d < 2^32.
-uint32_t magicFor(uint32_t d)
+// ceil(2^32 / d) for fastDivide: exact for every q <= maxQ when maxQ * d < 2^32.
+// Returns 0 (plain division) for d == 1, where the magic does not fit 32 bits,
+// and when the range is too large.
+uint32_t magicFor(uint32_t d, uint64_t maxQ)
 {
+    if (d <= 1 || maxQ * d >= (1ull << 32)) {
+        return 0;
+    }
     return static_cast<uint32_t>(((1ull << 32) + d - 1) / d);
 }
 
@@ -561,12 +598,8 @@ int launchTrained(
     params.slotDwords = ctx->slotDwords;
     params.chunk = geometry.chunk;
     params.keyStride = geometry.keyStride;
-    params.slotMagic = magicFor(ctx->slotDwords / 4);  // q < 64 * pieces, pieces <= 2^12
-    {
-        uint32_t piecesPerWord = geometry.chunk / 4;
-        // exact while q * piecesPerWord < 2^32 with q < 64 * piecesPerWord
-        params.chunkMagic = (64ull * piecesPerWord * piecesPerWord < (1ull << 32)) ? magicFor(piecesPerWord) : 0;
-    }
+    params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4));
+    params.chunkMagic = magicFor(geometry.chunk / 4, 64ull * (geometry.chunk / 4));
 
     const size_t tiles = (n + WAVE - 1) / WAVE;
     const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
@@ -620,7 +653,7 @@ int launchUniform(
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const uint32_t blocks = static_cast<uint32_t>((n + params.wordsPerBlock - 1) / params.wordsPerBlock);
     if (vec) {
-        params.pieceMagic = magicFor(ctx->dim / 4);
+        params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(params.wordsPerBlock) * (ctx->dim / 4));
         hipLaunchKernelGGL(dequant_uniform<true>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
     } else {
         hipLaunchKernelGGL(dequant_uniform<false>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
@@ -649,7 +682,7 @@ int launchFull(
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const uint32_t blocks = static_cast<uint32_t>((n + params.wordsPerBlock - 1) / params.wordsPerBlock);
     if (vec) {
-        params.pieceMagic = magicFor(ctx->dim / 4);
+        params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(params.wordsPerBlock) * (ctx->dim / 4));
         hipLaunchKernelGGL(gather_full<true>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
     } else {
         hipLaunchKernelGGL(gather_full<false>, dim3(blocks), dim3(ROWWISE_THREADS), 0, stream, params);
@@ -1042,8 +1075,7 @@ int memb_hip_decode_rows_device(
         return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t target = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    return launch(ctx, rows, n, out, ld, col_off, target);
+    return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream));
 }
 
 int memb_hip_decode_rows(

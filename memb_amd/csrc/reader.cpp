@@ -22,14 +22,7 @@ const size_t THREADED_DECODER_THRESHOLD = 1024;  // reference src/reader.cpp:9
 int deviceFromEnvironment()
 {
     const char* text = std::getenv("MEMB_HIP_DEVICE");
-    if (!text || !*text) {
-        // one process per GPU under torchrun: follow the launcher's rank
-        text = std::getenv("LOCAL_RANK");
-        if (!text || !*text || !std::getenv("MEMB_HIP_FOLLOW_LOCAL_RANK")) {
-            return 0;
-        }
-    }
-    return std::atoi(text);
+    return (text && *text) ? std::atoi(text) : 0;
 }
 
 }  // namespace

@@ -49,3 +49,21 @@ def build_file(path, count, dim=300, storage_type='trained', bits_per_weight=4,
     builder.save(tmp)
     os.replace(tmp, str(path))
     return words
+
+
+def cache_dir():
+    return os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench')
+
+
+def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed=1234, distribution='normal'):
+    '''Path of a synthetic model in the per-box cache, written on first use.
+    Returns (path, seconds spent building; 0.0 when it was already there)'''
+    import time
+    name = 'synthetic_{}w_{}d_{}{}bit_{}_{}.bin'.format(count, dim, storage_type, bits_per_weight, distribution, seed)
+    path = os.path.join(cache_dir(), name)
+    if os.path.exists(path):
+        return path, 0.0
+    os.makedirs(cache_dir(), exist_ok=True)
+    start = time.time()
+    build_file(path, count, dim, storage_type, bits_per_weight, seed=seed, distribution=distribution)
+    return path, time.time() - start

@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads and exports what include/memb_hip.h declares.
+No compute here: that needs the GPU (test_gpu_*.py)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def declared_functions():
+    text = open(os.path.join(REPO, 'include', 'memb_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(memb_hip_[a-z_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert declared_functions() == sorted([
+        'memb_hip_device_count', 'memb_hip_ctx_create_trained', 'memb_hip_ctx_create_uniform',
+        'memb_hip_ctx_create_full', 'memb_hip_ctx_destroy', 'memb_hip_ctx_get_info', 'memb_hip_decode_rows',
+        'memb_hip_decode_rows_device', 'memb_hip_sync', 'memb_hip_algorithmic_bytes', 'memb_hip_last_error',
+    ])
+
+
+def test_library_exports_every_declared_symbol(native):
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    for name in declared_functions():
+        assert hasattr(library, name), name
+
+
+def test_error_reporting_without_compute(native):
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+    count = ctypes.c_int(-1)
+    code = library.memb_hip_device_count(ctypes.byref(count))
+    assert (code == 0 and count.value > 0) or (code != 0 and count.value == 0)
+    assert library.memb_hip_device_count(None) == 1  # MEMB_HIP_ERR_INVALID
+    assert b'null' in library.memb_hip_last_error()
+    context = ctypes.c_void_p()
+    assert library.memb_hip_ctx_create_trained(ctypes.byref(context), 0, None) == 1
+    assert not context.value
+    assert library.memb_hip_sync(None) == 1
+    library.memb_hip_ctx_destroy(None)  # harmless
+    if count.value == 0:
+        # a well-formed description still cannot be staged without a device
+        import numpy as np
+
+        class Desc(ctypes.Structure):
+            _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64), ('packed_values', ctypes.c_void_p),
+                        ('packed_values_bytes', ctypes.c_uint64), ('value_offsets', ctypes.c_void_p),
+                        ('keys', ctypes.c_void_p), ('n_keys', ctypes.c_uint32), ('size_offsets', ctypes.c_void_p),
+                        ('n_size_offsets', ctypes.c_uint32), ('centroids', ctypes.c_void_p),
+                        ('n_centroids', ctypes.c_uint32), ('max_direct_bits', ctypes.c_uint32)]
+        packed = np.array([0b01000000], dtype=np.uint8)
+        offsets = np.zeros(1, dtype=np.uint32)
+        keys = np.array([0, 1], dtype=np.uint8)
+        size_offsets = np.array([0, 2], dtype=np.uint32)
+        centroids = np.array([-1.0, 1.0], dtype=np.float32)
+        desc = Desc(2, 1, packed.ctypes.data, 1, offsets.ctypes.data, keys.ctypes.data, 2,
+                    size_offsets.ctypes.data, 2, centroids.ctypes.data, 2, 0)
+        assert library.memb_hip_ctx_create_trained(ctypes.byref(context), 0, ctypes.byref(desc)) == 2  # ERR_DEVICE
+        assert b'no HIP device' in library.memb_hip_last_error()

@@ -1,0 +1,61 @@
+"""BASELINE.json's full-size configuration (GloVe-840B shape: 2,196,017 words x
+300, trained 4-bit) on the GPU: the whole dump is compared with the CPU checker
+slice by slice, plus size-independent properties (every value is a centroid,
+permutation consistency, idempotence)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+FULL_VOCAB = 2196017
+
+
+@pytest.fixture(scope='module')
+def full_model(native, tmp_path_factory):
+    from memb_amd import synthetic
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    path, _ = synthetic.cached_model(count, 300, 'trained', 4)   # shared with bench.py on the same box
+    return path, count
+
+
+def test_full_vocabulary_dump(native, full_model):
+    import torch
+    path, count = full_model
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    assert len(reader) == count
+
+    rows = torch.arange(count, dtype=torch.int32, device='cuda')
+    out = reader.rows_embedding_device(rows)
+    torch.cuda.synchronize()
+
+    # (1) slice-by-slice bit comparison with the checker over the whole vocabulary
+    step = 200000
+    for start in range(0, count, step):
+        stop = min(count, start + step)
+        expected = checker.rows_embedding(np.arange(start, stop, dtype=np.uint32))
+        assert bits_equal(out[start:stop].cpu().numpy(), expected), (start, stop)
+
+    # (2) every decoded value is one of the <= 16 centroids
+    assert torch.unique(out).numel() <= 16
+
+    # (3) idempotence: a second launch into a fresh buffer gives the same bits
+    again = reader.rows_embedding_device(rows)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), again.view(torch.int32))
+    del again
+
+    # (4) permutation consistency: decode(rows[perm]) == decode(rows)[perm], misses stay zero
+    generator = torch.Generator(device='cuda').manual_seed(11)
+    perm = torch.randperm(count, device='cuda', generator=generator)[:500000].to(torch.int32)
+    perm[::1000] = -1  # 0xFFFFFFFF
+    shuffled = reader.rows_embedding_device(perm)
+    torch.cuda.synchronize()
+    valid = perm >= 0
+    assert torch.equal(shuffled[valid].view(torch.int32), out[perm[valid].long()].view(torch.int32))
+    assert not bool(shuffled[~valid].any())

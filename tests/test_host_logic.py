@@ -1,0 +1,207 @@
+"""Host side of the product on CPU: container format, Builder, word search,
+Python surface. Lookups themselves need the GPU and are in test_gpu_*.py."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, SIX_WORDS, golden_json
+
+
+def test_strategies_listed_like_reference(native):
+    # reference src/compression_strategy.cpp:13-18,63-78
+    assert native.available_compression_strategies() == ['full', 'uniform', 'trained']
+
+
+def test_unknown_strategy_message(native):
+    # reference src/compression_strategy.cpp:11,55-58
+    with pytest.raises(RuntimeError, match='Storage strategy bogus is not supported'):
+        native.Builder(3, 'bogus', 4)
+
+
+def test_builder_rejects_wrong_dimension_and_duplicates(native):
+    # reference src/tests.cpp:115-132, messages src/builder.cpp:12-16
+    builder = native.Builder(15, 'full', 8)
+    with pytest.raises(RuntimeError, match=re.escape("Vector dimension (3) for word the doesn't match builder dimension (15)")):
+        builder.add_word('the', np.array([0.0, 1.0, 2.0], dtype=np.float32))
+    builder = native.Builder(3, 'full', 8)
+    builder.add_word('the', np.array([0.0, 1.0, 2.0], dtype=np.float32))
+    with pytest.raises(RuntimeError, match='Attempt to add duplicate word the to index'):
+        builder.add_word('the', np.array([2.0, 1.0, 2.0], dtype=np.float32))
+    with pytest.raises(RuntimeError, match='Word vector must be 1-dimensional'):
+        builder.add_word('x', np.zeros((1, 3), dtype=np.float32))  # reference python/memb_bindings.cpp:19-21
+
+
+def test_missing_and_invalid_files(native, tmp_path):
+    # reference src/tests.cpp:134-153
+    with pytest.raises(RuntimeError):
+        native.Reader(str(tmp_path / 'missing.bin'))
+    invalid = tmp_path / 'invalid.bin'
+    invalid.write_bytes(b'0123456789')
+    with pytest.raises(RuntimeError, match='File format verification failed'):
+        native.Reader(invalid)  # pathlib.Path accepted, reference python/memb/reader.py:66
+    truncated = tmp_path / 'truncated.bin'
+    truncated.write_bytes(open(os.path.join(GOLDEN, 'six_words_trained.bin'), 'rb').read()[:60])
+    with pytest.raises(RuntimeError, match='File format verification failed'):
+        native.Reader(truncated)
+
+
+@pytest.mark.parametrize('storage', ['full', 'uniform', 'trained'])
+def test_keys_dim_and_rows_agree_with_checker(native, storage):
+    path = os.path.join(GOLDEN, 'six_words_{}.bin'.format(storage))
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    assert reader.dim == checker.dim == 3
+    assert len(reader) == 6
+    assert reader.keys() == checker.keys() == sorted(SIX_WORDS)  # reference src/tests.cpp:38-43
+    probes = sorted(SIX_WORDS) + ['o', '', 'zzzz', 'ab', 'abcd', 'thee', 'été']
+    assert np.array_equal(reader.resolve_rows(probes), checker.resolve_rows(probes))
+
+
+def test_word_search_on_a_larger_vocabulary(native, make_model):
+    path, words = make_model(5000, dim=8, storage='trained', bits=4)
+    reader = native.Reader(path, num_threads=4)
+    checker = oracle.OracleReader(path)
+    assert reader.keys() == sorted(words) == checker.keys()
+    rng = np.random.default_rng(3)
+    probes = [words[i] for i in rng.integers(0, len(words), size=3000)]
+    probes += [w + 'x' for w in probes[:200]] + [w[:-1] for w in probes[:200]] + ['', '~~~~', '0']
+    rows = reader.resolve_rows(probes)  # >= 1024 words: threaded search, reference src/reader.cpp:61-84
+    assert np.array_equal(rows, checker.resolve_rows(probes))
+    serial = native.Reader(path, num_threads=1).resolve_rows(probes)
+    assert np.array_equal(rows, serial)
+    order = {w: i for i, w in enumerate(sorted(words))}
+    assert all(rows[i] == order[probes[i]] for i in range(3000))
+
+
+def test_builder_files_are_read_by_the_checker(native, tmp_path):
+    # container written by memb_amd.Builder, parsed by an independent C parser
+    for storage in ('full', 'uniform', 'trained'):
+        builder = native.Builder(3, storage, 8)
+        for word, vector in SIX_WORDS.items():
+            builder.add_word(word, np.array(vector, dtype=np.float32))
+        path = tmp_path / (storage + '.bin')
+        builder.save(path)
+        assert path.read_bytes() == open(os.path.join(GOLDEN, 'six_words_{}.bin'.format(storage)), 'rb').read()
+        checker = oracle.OracleReader(str(path))
+        assert checker.keys() == sorted(SIX_WORDS)
+        if storage == 'full':
+            for word, vector in SIX_WORDS.items():
+                assert checker.word_embedding(word).tolist() == vector
+
+
+def test_kmeans_known_answer(native):
+    # reference src/kmeans_tests.cpp:9-38
+    data = [-0.5 + i * 0.125 for i in range(8)] + [-9 + i * 0.125 for i in range(16)] + [11.75 + i * 0.125 for i in range(4)]
+    centroids, assignments = native._memb._kmeans_fit_predict(data, 3)
+    assert assignments == [1] * 8 + [0] * 16 + [2] * 4
+    assert centroids == sorted(centroids) and len(centroids) == 3
+
+
+def test_bit_packer_known_answer(native):
+    # reference src/bit_stream_tests.cpp:31-59
+    known = golden_json('bit_stream.json')
+    assert native._memb._bit_pack([tuple(c) for c in known['codes']]).hex() == known['bytes']
+
+
+def test_encoder_description_and_device_table_decode_like_reference(native):
+    """Builder's Huffman description -> (a) accepted by the reference decoder,
+    (b) the product's own lookup table (memb_amd/csrc/codec.h) resolves every
+    code to the same symbol and length, for one- and two-level layouts."""
+    rng = np.random.default_rng(11)
+    checker = oracle.Codec('reference' if oracle.reference_available() else 'oracle')
+    for trial in range(40):
+        symbols = int(rng.integers(1, 255))
+        counts = [0] * 256
+        for key in rng.permutation(255)[:symbols]:
+            counts[int(key)] = int(rng.integers(1, 10 ** int(rng.integers(1, 7))))
+        keys, size_offsets = native._memb._huffman_description(counts)
+        lengths = []
+        for i in range(len(keys)):
+            lengths.append(next(k for k, bound in enumerate(size_offsets) if i < bound))
+        if max(lengths) > 16:
+            continue
+        codes, bits = checker.canonical_codes(keys, lengths)
+        message = np.array(keys, dtype=np.uint8)[rng.integers(0, len(keys), size=200)]
+        stream = checker.bitstream_pack(codes[message], bits[message])
+        assert np.array_equal(checker.decode_symbols(keys, size_offsets, 10, stream, 200), message)
+        for limit in (1, 4, 11, 12):
+            root_bits, max_bits, has_sub, table = native._memb._decode_table(keys, size_offsets, limit)
+            assert max_bits == max(lengths) and root_bits == max(1, min(limit, max_bits))
+            assert has_sub == (max_bits > root_bits)
+            for key, length in zip(keys, lengths):
+                code = int(codes[key])
+                padded = code << (16 - length) if length <= 16 else 0
+                entry = table[padded >> (16 - root_bits)]
+                if entry & 0x80000000:
+                    sub_bits = entry & 0xff
+                    base = (entry & 0x7fffffff) >> 8
+                    entry = table[base + ((padded >> (16 - root_bits - sub_bits)) & ((1 << sub_bits) - 1))]
+                assert entry & 0xff == length and (entry >> 8) & 0xff == key
+
+
+def test_lookup_without_device_fails_loudly(native):
+    if native.hip_device_count() > 0:
+        pytest.skip('a HIP device is present')
+    reader = native.Reader(os.path.join(GOLDEN, 'six_words_trained.bin'))
+    with pytest.raises(RuntimeError, match='no HIP device available'):
+        reader['the']
+    with pytest.raises(RuntimeError, match='no HIP device available'):
+        reader[['the', 'of']]
+
+
+def test_getitem_dispatch_and_tokenizer_layout(native):
+    # reference python/memb/reader.py:6-17,94-111
+    from memb_amd.reader import BaseReader, tokenizer_word_list
+
+    class Echo(BaseReader):
+        dim = 2
+
+        def keys(self):
+            return []
+
+        def word_embedding(self, word):
+            return ('word', word)
+
+        def batch_embedding(self, words):
+            return ('batch', words)
+
+        def tokenizer_embedding(self, tokenizer):
+            return self.batch_embedding(tokenizer_word_list(tokenizer))
+
+    echo = Echo()
+    assert echo['a'] == ('word', 'a')
+    assert echo[['a', 'b']] == ('batch', ['a', 'b'])
+    with pytest.raises(TypeError, match='Key type is not supported'):
+        echo[('a', 'b')]
+
+    class Tokenizer:
+        word_index = {'the': 1, 'of': 2, 'rare': 5}
+        num_words = None
+
+    assert tokenizer_word_list(Tokenizer) == ['', 'the', 'of', '', '', 'rare']
+    Tokenizer.num_words = 3
+    assert tokenizer_word_list(Tokenizer) == ['', 'the', 'of']  # idx < num_words
+
+
+def test_readers_union_argument_checks(native):
+    # reference python/memb/readers_union.py:59-65,8-10
+    class Fake:
+        def __init__(self, dim):
+            self.dim = dim
+
+        def keys(self):
+            return ['b', 'a'] if self.dim == 3 else ['c', 'a']
+
+    with pytest.raises(AssertionError, match='at least 2 readers'):
+        native.ReadersUnion([Fake(3)], 'concatenate')
+    with pytest.raises(KeyError):
+        native.ReadersUnion([Fake(3), Fake(3)], 'sum')
+    with pytest.raises(AssertionError, match='must be equal for average mode'):
+        native.ReadersUnion([Fake(3), Fake(4)], 'average')
+    union = native.ReadersUnion([Fake(3), Fake(4)], 'concatenate')
+    assert union.dim == 7
+    assert union.keys() == ['a', 'b', 'c']
+    assert native.ReadersUnion([Fake(3), Fake(3)], 'average').dim == 3

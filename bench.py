@@ -229,7 +229,7 @@ def main():
         'cpu_baseline': baseline,
         'parity_vs_cpu_checker': parity,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
-        'geometry': {k: info[k] for k in ('waves_per_block', 'chunk_symbols', 'lds_bytes_per_block', 'root_bits',
+        'geometry': {k: info[k] for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
                                           'max_code_bits', 'max_stream_bytes', 'device_bytes')},
         'model_build_s': build_seconds,
         'reader_open_s': open_seconds,

@@ -109,7 +109,8 @@ typedef struct memb_hip_ctx_info {
     uint32_t table_entries;      /* trained: entries of the device lookup table */
     uint32_t max_stream_bytes;   /* trained: longest per-word bitstream */
     uint32_t waves_per_block;    /* launch geometry chosen for the decode kernel */
-    uint32_t chunk_symbols;
+    uint32_t lanes_per_word;     /* trained: lanes that decode one word side by side */
+    uint32_t segment_symbols;    /* trained: symbols decoded by each of those lanes */
     uint32_t lds_bytes_per_block;
 } memb_hip_ctx_info;
 

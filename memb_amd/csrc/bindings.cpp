@@ -45,7 +45,8 @@ py::dict contextInfo(memb::Reader& reader)
     result["table_entries"] = info.table_entries;
     result["max_stream_bytes"] = info.max_stream_bytes;
     result["waves_per_block"] = info.waves_per_block;
-    result["chunk_symbols"] = info.chunk_symbols;
+    result["lanes_per_word"] = info.lanes_per_word;
+    result["segment_symbols"] = info.segment_symbols;
     result["lds_bytes_per_block"] = info.lds_bytes_per_block;
     return result;
 }

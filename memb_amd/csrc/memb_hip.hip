@@ -10,14 +10,18 @@
 //   gather_full    : raw fp32 row copy (reference src/full_compression.cpp:37-47)
 // A row id of MEMB_HIP_MISSING_ROW yields a zero row (reference src/reader.cpp:43-46).
 //
-// Work decomposition of decode_trained (the serial part is the bitstream of one
-// word, so parallelism is across words): one wavefront owns a tile of 64
-// consecutive batch entries, lane l decodes word l. The lookup table and the
-// codebook sit in LDS; the 64 bitstreams are first copied into LDS with wide
-// coalesced loads (one 16-byte piece per lane), decoded from there, the decoded
-// symbols are staged in LDS one byte each, and the tile is written out row
-// contiguous, 16 bytes per lane, so every store instruction covers whole
-// 16-byte-aligned runs of output rows.
+// Work decomposition of decode_trained. A Huffman bitstream is serial, so the
+// parallelism is across words and across SEGMENTS of a word: when a model is
+// staged, one pass over all rows records the bit position at which every
+// S-th symbol of each row starts (a side index, derived data: the file is
+// unchanged). A wavefront then owns a tile of 64 / G consecutive batch entries
+// and G = ceil(dim / S) lanes decode one word, each its own segment of S
+// symbols. Lookup table and codebook sit in LDS; the tile's bitstreams are
+// first copied into LDS with wide loads (one 16-byte piece per lane), decoded
+// from there, the symbols are staged in LDS one byte each, and the tile is
+// written out row contiguous, 16 bytes per lane, so every store instruction
+// covers whole 16-byte-aligned runs of output rows. G lanes per word divide
+// the LDS needed per lane in flight by G, which is what bounds occupancy.
 #include <hip/hip_runtime.h>
 
 #include "../../include/memb_hip.h"
@@ -61,27 +65,34 @@ int fail(int code, const std::string& message)
 // ---------------------------------------------------------------------------
 
 struct TrainedParams {
-    const uint32_t* rows;
+    const uint32_t* rows;        // batch -> row id; null = identity (row = batch position)
     float* out;
     unsigned long long n;
     unsigned long long ld;
     unsigned long long colOff;
     const uint8_t* packed;
     const uint32_t* valueOffsets;
+    const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
+    uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
     const uint32_t* table;
     const float* centroids;
     unsigned long long nRows;
-    uint32_t tableDwords;   // multiple of 4
+    uint32_t tableDwords;     // multiple of 4
     uint32_t rootBits;
     uint32_t dim;
-    uint32_t slotDwords;    // LDS bytes/4 reserved per bitstream, multiple of 4
-    uint32_t chunk;         // symbols decoded between two output phases, multiple of 4
-    uint32_t keyStride;     // dwords per word in the symbol tile, odd
-    uint32_t chunkMagic;    // ceil(2^32 / (chunk / 4))
-    uint32_t slotMagic;     // ceil(2^32 / (slotDwords / 4))
+    uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
+    uint32_t slotMagic;       // fastDivide magic for slotDwords / 4
+    uint32_t lanesPerWord;    // G
+    uint32_t laneMagic;       // fastDivide magic for G
+    uint32_t wordsPerWave;    // 64 / G
+    uint32_t segmentSymbols;  // S, multiple of 4
+    uint32_t keyStride;       // dwords per word in the symbol tile = ceil(dim / 4)
+    uint32_t keyMagic;        // fastDivide magic for keyStride (vector output)
+    uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
+    uint32_t indexSegmentSymbols;
 };
 
-enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2 };
+enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3 };
 
 // 16-byte load from an address that is only 4-byte aligned (bitstreams start
 // on arbitrary bytes; the staging copy starts at the enclosing dword).
@@ -119,59 +130,72 @@ __global__ void decode_trained(TrainedParams p)
 
     uint32_t* tableLds = lds;
     float* centroidLds = reinterpret_cast<float*>(lds + p.tableDwords);
-    const uint32_t perWave = WAVE * (p.slotDwords + p.keyStride);
+    const uint32_t perWave = p.wordsPerWave * (p.slotDwords + p.keyStride);
     uint32_t* slots = lds + p.tableDwords + 256 + wave * perWave;
-    uint32_t* keyTile = slots + WAVE * p.slotDwords;
+    uint32_t* keyTile = slots + p.wordsPerWave * p.slotDwords;
 
     for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(tableLds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
     }
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-        centroidLds[i] = p.centroids[i];
+    if (MODE != OUT_INDEX) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+            centroidLds[i] = p.centroids[i];
+        }
     }
     __syncthreads();
 
     const unsigned long long tileBase =
-        (static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave) * WAVE;
+        (static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave) * p.wordsPerWave;
     if (tileBase >= p.n) {
         return;
     }
-    const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(WAVE), p.n - tileBase));
+    const uint32_t tileWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+
+    // lane -> (word of the tile, segment of the word)
+    // (64 % G spare lanes at the top get word == wordsPerWave: they decode word 0's slot and store nothing)
+    const uint32_t laneWord = fastDivide(lane, p.laneMagic, p.lanesPerWord);
+    const uint32_t segment = lane - laneWord * p.lanesPerWord;
+    const bool spare = laneWord >= p.wordsPerWave;
+    const uint32_t word = spare ? 0 : laneWord;
 
     uint32_t row = MISSING;
-    if (lane < tileWords) {
-        row = p.rows[tileBase + lane];
+    if (!spare && word < tileWords) {
+        row = p.rows ? p.rows[tileBase + word] : static_cast<uint32_t>(tileBase + word);
     }
     const bool present = row < p.nRows;
     const uint32_t offset = present ? p.valueOffsets[row] : 0;
-    const uint32_t alignedOffset = offset & ~3u;
+    uint32_t segmentBits = 0;
+    if (present && segment > 0) {
+        segmentBits = p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + segment - 1];
+    }
 
-    // Stage the 64 bitstreams: piece q = (word, 16-byte piece) -> one lane.
+    // Stage the tile's bitstreams: piece q = (word, 16-byte piece) -> one lane.
     // All loads of a batch are issued before the first one is waited for.
     // Absent words read the start of the array (always mapped: the guard is a
     // slot long) and never emit what they decode.
     {
         const uint32_t piecesPerWord = p.slotDwords / 4;
-        const uint32_t totalPieces = WAVE * piecesPerWord;
-        const uint32_t sourceOffset = present ? alignedOffset : 0u;
-        constexpr int BATCH = 8;
-        for (uint32_t q0 = lane; q0 < totalPieces; q0 += WAVE * BATCH) {
+        const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
+        const uint32_t sourceOffset = present ? (offset & ~3u) : 0u;
+        constexpr int BATCH = 4;
+        for (uint32_t q0 = 0; q0 < totalPieces; q0 += WAVE * BATCH) {
             uint4 v[BATCH];
             uint32_t destination[BATCH];
 #pragma unroll
             for (int b = 0; b < BATCH; ++b) {
-                const uint32_t q = q0 + WAVE * b;
+                const uint32_t q = q0 + WAVE * b + lane;
+                const uint32_t w = min(fastDivide(q, p.slotMagic, piecesPerWord), p.wordsPerWave - 1);
+                const uint32_t piece = q - w * piecesPerWord;
+                const uint32_t wordOffset = __shfl(sourceOffset, w * p.lanesPerWord);
+                destination[b] = w * p.slotDwords + 4 * piece;
                 if (q < totalPieces) {
-                    const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
-                    const uint32_t piece = q - w * piecesPerWord;
-                    const uint32_t wordOffset = __shfl(sourceOffset, w);
                     v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
-                    destination[b] = w * p.slotDwords + 4 * piece;
                 }
             }
 #pragma unroll
             for (int b = 0; b < BATCH; ++b) {
-                const uint32_t q = q0 + WAVE * b;
+                const uint32_t q = q0 + WAVE * b + lane;
                 if (q < totalPieces) {
                     uint4 t = v[b];
                     t.x = byteSwap(t.x);
@@ -185,87 +209,103 @@ __global__ void decode_trained(TrainedParams p)
     }
     waveLdsFence();
 
-    const uint32_t* slot = slots + lane * p.slotDwords;
-    uint32_t* keyRow = keyTile + lane * p.keyStride;
+    const uint32_t* slot = slots + word * p.slotDwords;
+    uint32_t* keyRow = keyTile + word * p.keyStride;
     const uint32_t lastWindow = p.slotDwords - 3;
     const uint32_t rootShift = 32 - p.rootBits;
-    uint32_t bitPos = (offset & 3u) * 8;
+    const uint32_t startBit = (offset & 3u) * 8;
+    uint32_t bitPos = startBit + segmentBits;
+    const uint32_t firstColumn = segment * (p.segmentSymbols / 4);
+    uint32_t nextIndexSymbol = p.indexSegmentSymbols;
+    uint32_t indexSlot = 0;
 
-    for (uint32_t chunkStart = 0; chunkStart < p.dim; chunkStart += p.chunk) {
-        const uint32_t chunkSymbols = min(p.chunk, p.dim - chunkStart);
-
-        for (uint32_t j = 0; j < chunkSymbols; j += 4) {
-            const uint32_t d = min(bitPos >> 5, lastWindow);
-            const uint32_t shift = bitPos & 31;
-            const uint32_t w0 = slot[d];
-            const uint32_t w1 = slot[d + 1];
-            const uint32_t w2 = slot[d + 2];
-            // 64 valid bits starting at the current bit position, MSB first.
-            unsigned long long window =
-                (((static_cast<unsigned long long>(w0) << 32) | w1) << shift) |
-                (static_cast<unsigned long long>(w2) >> (32 - shift));
-            uint32_t keys = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint32_t entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
-                if (HAS_SUB) {
-                    if (entry & memb::TABLE_POINTER_FLAG) {
-                        const uint32_t subBits = entry & 0xff;
-                        const uint32_t base = (entry & ~memb::TABLE_POINTER_FLAG) >> 8;
-                        const uint32_t subIndex =
-                            static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
-                        entry = tableLds[base + subIndex];
-                    }
+    for (uint32_t j = 0; j < p.segmentSymbols; j += 4) {
+        if (MODE == OUT_INDEX) {
+            // one lane per word here; record where every indexSegmentSymbols-th symbol starts
+            if (j == nextIndexSymbol) {
+                if (present && indexSlot + 1 < p.indexLanes) {
+                    p.segmentIndexOut[static_cast<unsigned long long>(row) * (p.indexLanes - 1) + indexSlot] =
+                        static_cast<uint16_t>(bitPos - startBit);
                 }
-                const uint32_t length = entry & 0xff;
-                window <<= length;
-                bitPos += length;
-                keys |= ((entry >> 8) & 0xff) << (8 * s);
+                ++indexSlot;
+                nextIndexSymbol += p.indexSegmentSymbols;
             }
-            keyRow[j >> 2] = present ? keys : 0xFFFFFFFFu;
         }
-        waveLdsFence();
+        const uint32_t d = min(bitPos >> 5, lastWindow);
+        const uint32_t shift = bitPos & 31;
+        const uint32_t w0 = slot[d];
+        const uint32_t w1 = slot[d + 1];
+        const uint32_t w2 = slot[d + 2];
+        // 64 valid bits starting at the current bit position, MSB first.
+        unsigned long long window =
+            (((static_cast<unsigned long long>(w0) << 32) | w1) << shift) |
+            (static_cast<unsigned long long>(w2) >> (32 - shift));
+        uint32_t keys = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint32_t entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
+            if (HAS_SUB) {
+                if (entry & memb::TABLE_POINTER_FLAG) {
+                    const uint32_t subBits = entry & 0xff;
+                    const uint32_t base = (entry & ~memb::TABLE_POINTER_FLAG) >> 8;
+                    const uint32_t subIndex =
+                        static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
+                    entry = tableLds[base + subIndex];
+                }
+            }
+            const uint32_t length = entry & 0xff;
+            window <<= length;
+            bitPos += length;
+            keys |= ((entry >> 8) & 0xff) << (8 * s);
+        }
+        if (MODE != OUT_INDEX) {
+            const uint32_t column = firstColumn + (j >> 2);
+            if (column < p.keyStride && !spare) {
+                keyRow[column] = present ? keys : 0xFFFFFFFFu;
+            }
+        }
+    }
+    if (MODE == OUT_INDEX) {
+        return;
+    }
+    waveLdsFence();
 
-        if (MODE == OUT_FLAT) {
-            // ld == dim, one chunk, keyStride == dim / 4: tile and output are both linear.
-            const uint32_t pieces = tileWords * (p.dim / 4);
-            float4* dst = reinterpret_cast<float4*>(p.out + tileBase * p.ld);
-            for (uint32_t q = lane; q < pieces; q += WAVE) {
-                const uint32_t k = keyTile[q];
-                float4 f;
-                f.x = centroidLds[k & 0xff];
-                f.y = centroidLds[(k >> 8) & 0xff];
-                f.z = centroidLds[(k >> 16) & 0xff];
-                f.w = centroidLds[k >> 24];
-                dst[q] = f;
-            }
-        } else if (MODE == OUT_VEC4) {
-            const uint32_t piecesPerWord = chunkSymbols / 4;
-            const uint32_t magic = (chunkSymbols == p.chunk) ? p.chunkMagic : 0;
-            const uint32_t pieces = tileWords * piecesPerWord;
-            for (uint32_t q = lane; q < pieces; q += WAVE) {
-                const uint32_t w = fastDivide(q, magic, piecesPerWord);
-                const uint32_t c = q - w * piecesPerWord;
-                const uint32_t k = keyTile[w * p.keyStride + c];
-                float4 f;
-                f.x = centroidLds[k & 0xff];
-                f.y = centroidLds[(k >> 8) & 0xff];
-                f.z = centroidLds[(k >> 16) & 0xff];
-                f.w = centroidLds[k >> 24];
-                float* dst = p.out + (tileBase + w) * p.ld + p.colOff + chunkStart + 4 * c;
-                *reinterpret_cast<float4*>(dst) = f;
-            }
-        } else {
-            const uint32_t total = tileWords * chunkSymbols;
-            const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
-            for (uint32_t q = lane; q < total; q += WAVE) {
-                const uint32_t w = q / chunkSymbols;
-                const uint32_t c = q - w * chunkSymbols;
-                const uint32_t k = keyBytes[w * p.keyStride * 4 + c];
-                p.out[(tileBase + w) * p.ld + p.colOff + chunkStart + c] = centroidLds[k];
-            }
+    if (MODE == OUT_FLAT) {
+        // ld == dim: the symbol tile [tileWords][dim / 4] and the output tile are both linear.
+        const uint32_t pieces = tileWords * p.keyStride;
+        float4* dst = reinterpret_cast<float4*>(p.out + tileBase * p.ld);
+        for (uint32_t q = lane; q < pieces; q += WAVE) {
+            const uint32_t k = keyTile[q];
+            float4 f;
+            f.x = centroidLds[k & 0xff];
+            f.y = centroidLds[(k >> 8) & 0xff];
+            f.z = centroidLds[(k >> 16) & 0xff];
+            f.w = centroidLds[k >> 24];
+            dst[q] = f;
         }
-        waveLdsFence();
+    } else if (MODE == OUT_VEC4) {
+        const uint32_t pieces = tileWords * p.keyStride;
+        for (uint32_t q = lane; q < pieces; q += WAVE) {
+            const uint32_t w = fastDivide(q, p.keyMagic, p.keyStride);
+            const uint32_t c = q - w * p.keyStride;
+            const uint32_t k = keyTile[q];
+            float4 f;
+            f.x = centroidLds[k & 0xff];
+            f.y = centroidLds[(k >> 8) & 0xff];
+            f.z = centroidLds[(k >> 16) & 0xff];
+            f.w = centroidLds[k >> 24];
+            float* dst = p.out + (tileBase + w) * p.ld + p.colOff + 4 * c;
+            *reinterpret_cast<float4*>(dst) = f;
+        }
+    } else {
+        const uint32_t total = tileWords * p.dim;
+        const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
+        for (uint32_t q = lane; q < total; q += WAVE) {
+            const uint32_t w = q / p.dim;
+            const uint32_t c = q - w * p.dim;
+            const uint32_t k = keyBytes[w * p.keyStride * 4 + c];
+            p.out[(tileBase + w) * p.ld + p.colOff + c] = centroidLds[k];
+        }
     }
 }
 
@@ -454,6 +494,9 @@ struct memb_hip_ctx {
     uint32_t tableDwords = 0;
     uint32_t maxStreamBytes = 0;
     uint32_t slotDwords = 0;
+    uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]
+    uint32_t lanesPerWord = 1;           // G: lanes that share one word
+    uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
     uint32_t ldsLimit = 0;
     uint32_t cuCount = 0;
@@ -475,77 +518,52 @@ struct memb_hip_ctx {
 namespace {
 
 struct TrainedGeometry {
-    uint32_t waves;
-    uint32_t chunk;
-    uint32_t keyStride;
-    uint32_t ldsBytes;
+    uint32_t waves;      // wavefronts per block
+    uint32_t ldsBytes;   // dynamic LDS per block
     int mode;
 };
 
-uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t keyStride)
+uint32_t roundUp4(uint32_t v)
 {
-    return 4u * (ctx->tableDwords + 256u + waves * WAVE * (ctx->slotDwords + keyStride));
+    return (v + 3) / 4 * 4;
 }
 
-// Pick waves per block and the symbols decoded between output phases so that
-// as many wavefronts as possible are resident per CU (LDS is the limiter).
-TrainedGeometry chooseGeometry(const memb_hip_ctx* ctx, size_t ld, size_t colOff, const float* out)
+uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, uint32_t keyStride)
 {
-    const uint32_t dim = ctx->dim;
-    const bool vec = (dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
-        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    const uint32_t symbolsRounded = (dim + 3) / 4 * 4;
+    return 4u * (ctx->tableDwords + 256u + waves * wordsPerWave * (ctx->slotDwords + keyStride));
+}
 
+// Waves per block: as many resident wavefronts per CU as LDS allows (the
+// decode is a chain of dependent LDS lookups, so occupancy is what hides it),
+// larger blocks on ties (fewer copies of the lookup table).
+TrainedGeometry chooseGeometry(
+    const memb_hip_ctx* ctx, uint32_t wordsPerWave, uint32_t keyStride, size_t ld, size_t colOff, const float* out)
+{
     TrainedGeometry best{};
-    double bestScore = -1;
+    double bestWaves = -1;
     const uint32_t forcedWaves = envUint("MEMB_HIP_WAVES", 0);
-    const uint32_t forcedChunk = envUint("MEMB_HIP_CHUNK", 0);
-    const uint32_t waveOptions[] = {4, 2, 1};
-    std::vector<uint32_t> chunkOptions = {symbolsRounded};
-    if (forcedChunk) {
-        chunkOptions[0] = std::max<uint32_t>(4, std::min(forcedChunk / 4 * 4, symbolsRounded));
-    } else {
-        // keep every output phase at least 128 bytes long per word
-        for (uint32_t parts = 2; parts <= 16; ++parts) {
-            uint32_t chunk = ((symbolsRounded + parts - 1) / parts + 3) / 4 * 4;
-            if (chunk >= 32 && chunk < symbolsRounded) {
-                chunkOptions.push_back(chunk);
-            }
-        }
-    }
-    for (uint32_t waves : waveOptions) {
+    for (uint32_t waves : {8u, 4u, 2u, 1u}) {
         if (forcedWaves && waves != forcedWaves) {
             continue;
         }
-        for (uint32_t chunk : chunkOptions) {
-            uint32_t keyStride = (chunk / 4) | 1u;
-            uint32_t ldsBytes = trainedLdsBytes(ctx, waves, keyStride);
-            if (ldsBytes > ctx->ldsLimit) {
-                continue;
-            }
-            // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU.
-            uint32_t blocksPerCu = std::min<uint32_t>(ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), 32 / waves);
-            double residentWaves = blocksPerCu * waves;
-            // More resident waves hide the serial decode latency; fewer output
-            // phases keep stores long and contiguous. Past ~12 waves per CU
-            // occupancy stops paying.
-            double score = std::min(residentWaves, 12.0) * 8.0 - (symbolsRounded + chunk - 1) / chunk;
-            if (score > bestScore) {
-                bestScore = score;
-                best.waves = waves;
-                best.chunk = chunk;
-                best.keyStride = keyStride;
-                best.ldsBytes = ldsBytes;
-            }
+        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, keyStride);
+        if (ldsBytes > ctx->ldsLimit) {
+            continue;
+        }
+        // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU.
+        uint32_t blocksPerCu = std::min<uint32_t>(ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), 32 / waves);
+        double residentWaves = blocksPerCu * waves;
+        if (residentWaves > bestWaves) {
+            bestWaves = residentWaves;
+            best.waves = waves;
+            best.ldsBytes = ldsBytes;
         }
     }
-    if (bestScore < 0) {
-        best.waves = 0;
-        return best;
-    }
+    const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
+        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     if (!vec) {
         best.mode = OUT_SCALAR;
-    } else if (ld == dim && colOff == 0 && best.chunk == dim && best.keyStride == dim / 4) {
+    } else if (ld == ctx->dim && colOff == 0) {
         best.mode = OUT_FLAT;
     } else {
         best.mode = OUT_VEC4;
@@ -558,7 +576,7 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
 {
     static thread_local int configuredDevice = -1;
     int device = 0;
-    hipGetDevice(&device);
+    (void)hipGetDevice(&device);
     if (configuredDevice != device) {
         hipError_t status = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&decode_trained<HAS_SUB, MODE>),
@@ -574,21 +592,20 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
     return hipGetLastError();
 }
 
-int launchTrained(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+template <int MODE>
+hipError_t launchTrainedMode(
+    bool hasSubTables, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
-    TrainedGeometry geometry = chooseGeometry(ctx, ld, colOff, out);
-    if (!geometry.waves) {
-        return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
-    }
+    return hasSubTables ? launchTrainedVariant<true, MODE>(params, blocks, threads, ldsBytes, stream)
+                        : launchTrainedVariant<false, MODE>(params, blocks, threads, ldsBytes, stream);
+}
+
+TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
+{
     TrainedParams params{};
-    params.rows = rows;
-    params.out = out;
-    params.n = n;
-    params.ld = ld;
-    params.colOff = colOff;
     params.packed = ctx->packed;
     params.valueOffsets = ctx->valueOffsets;
+    params.segmentIndex = ctx->segmentIndex;
     params.table = ctx->table;
     params.centroids = ctx->centroids;
     params.nRows = ctx->nRows;
@@ -596,32 +613,92 @@ int launchTrained(
     params.rootBits = ctx->hostTable.rootBits;
     params.dim = ctx->dim;
     params.slotDwords = ctx->slotDwords;
-    params.chunk = geometry.chunk;
-    params.keyStride = geometry.keyStride;
-    params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4));
-    params.chunkMagic = magicFor(geometry.chunk / 4, 64ull * (geometry.chunk / 4));
+    params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4) * 5);
+    return params;
+}
 
-    const size_t tiles = (n + WAVE - 1) / WAVE;
+int launchTrained(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    const uint32_t keyStride = (ctx->dim + 3) / 4;
+    TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, keyStride, ld, colOff, out);
+    if (!geometry.waves) {
+        return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
+    }
+    TrainedParams params = baseTrainedParams(ctx);
+    params.rows = rows;
+    params.out = out;
+    params.n = n;
+    params.ld = ld;
+    params.colOff = colOff;
+    params.lanesPerWord = ctx->lanesPerWord;
+    params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
+    params.wordsPerWave = wordsPerWave;
+    params.segmentSymbols = ctx->segmentSymbols;
+    params.keyStride = keyStride;
+    params.keyMagic = magicFor(keyStride, uint64_t(wordsPerWave) * keyStride);
+
+    const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;
     const bool sub = ctx->hostTable.hasSubTables;
     hipError_t status;
     switch (geometry.mode) {
         case OUT_FLAT:
-            status = sub ? launchTrainedVariant<true, OUT_FLAT>(params, blocks, threads, geometry.ldsBytes, stream)
-                         : launchTrainedVariant<false, OUT_FLAT>(params, blocks, threads, geometry.ldsBytes, stream);
+            status = launchTrainedMode<OUT_FLAT>(sub, params, blocks, threads, geometry.ldsBytes, stream);
             break;
         case OUT_VEC4:
-            status = sub ? launchTrainedVariant<true, OUT_VEC4>(params, blocks, threads, geometry.ldsBytes, stream)
-                         : launchTrainedVariant<false, OUT_VEC4>(params, blocks, threads, geometry.ldsBytes, stream);
+            status = launchTrainedMode<OUT_VEC4>(sub, params, blocks, threads, geometry.ldsBytes, stream);
             break;
         default:
-            status = sub ? launchTrainedVariant<true, OUT_SCALAR>(params, blocks, threads, geometry.ldsBytes, stream)
-                         : launchTrainedVariant<false, OUT_SCALAR>(params, blocks, threads, geometry.ldsBytes, stream);
+            status = launchTrainedMode<OUT_SCALAR>(sub, params, blocks, threads, geometry.ldsBytes, stream);
             break;
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+// One pass over every row with one lane per word: records the bit position at
+// which each segment of each row starts (segmentIndex), so that lanesPerWord
+// lanes can later decode a row side by side.
+int buildSegmentIndex(memb_hip_ctx* ctx)
+{
+    if (ctx->lanesPerWord <= 1 || ctx->nRows == 0) {
+        return MEMB_HIP_OK;
+    }
+    TrainedParams params = baseTrainedParams(ctx);
+    params.segmentIndex = nullptr;
+    params.segmentIndexOut = ctx->segmentIndex;
+    params.rows = nullptr;
+    params.n = ctx->nRows;
+    params.lanesPerWord = 1;
+    params.laneMagic = 0;
+    params.wordsPerWave = WAVE;
+    params.segmentSymbols = roundUp4(ctx->dim);
+    params.keyStride = 0;
+    params.indexLanes = ctx->lanesPerWord;
+    params.indexSegmentSymbols = ctx->segmentSymbols;
+
+    uint32_t waves = 4;
+    while (waves > 1 && trainedLdsBytes(ctx, waves, WAVE, 0) > ctx->ldsLimit) {
+        waves /= 2;
+    }
+    const uint32_t ldsBytes = trainedLdsBytes(ctx, waves, WAVE, 0);
+    if (ldsBytes > ctx->ldsLimit) {
+        return fail(MEMB_HIP_ERR_INVALID, "bitstream slots do not fit into LDS");
+    }
+    const size_t tiles = (ctx->nRows + WAVE - 1) / WAVE;
+    const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+    hipError_t status = launchTrainedMode<OUT_INDEX>(
+        ctx->hostTable.hasSubTables, params, blocks, waves * WAVE, ldsBytes, ctx->stream);
+    if (status == hipSuccess) {
+        status = hipStreamSynchronize(ctx->stream);
+    }
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("segment index build: ") + hipGetErrorString(status));
     }
     return MEMB_HIP_OK;
 }
@@ -885,9 +962,23 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         }
     }
     // Slot: stream, up to 3 bytes of alignment slack in front, and the 12-byte
-    // window the decoder reads at its last position; whole 16-byte pieces.
-    ctx->slotDwords = ((ctx->maxStreamBytes + 3 + 12 + 15) / 16) * 4;
+    // window the decoder reads at its last position; whole 16-byte pieces, an
+    // odd number of them so that equal positions in consecutive slots fall
+    // into different LDS banks.
+    ctx->slotDwords = (((ctx->maxStreamBytes + 3 + 12 + 15) / 16) | 1u) * 4;
     ctx->tableDwords = static_cast<uint32_t>((ctx->hostTable.entries.size() + 3) / 4 * 4);
+
+    // Lanes per word (G) and symbols per lane (S). The side index stores 16-bit
+    // bit offsets, so rows longer than 65535 bits keep one lane per word.
+    {
+        uint32_t lanes = envUint("MEMB_HIP_LANES", 8);
+        lanes = std::max<uint32_t>(1, std::min<uint32_t>(lanes, WAVE));
+        if (uint64_t(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) >= 65536 || desc->dim < 8) {
+            lanes = 1;
+        }
+        ctx->segmentSymbols = std::max<uint32_t>(4, roundUp4((desc->dim + lanes - 1) / lanes));
+        ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
+    }
 
     code = openDevice(ctx, device);
     if (code == MEMB_HIP_OK) {
@@ -928,10 +1019,16 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         code = copyToDevice(ctx->centroids, codebook.data(), 256 * 4);
     }
     if (code == MEMB_HIP_OK) {
-        TrainedGeometry geometry = chooseGeometry(ctx, ctx->dim, 0, nullptr);
+        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, (ctx->dim + 3) / 4, ctx->dim, 0, nullptr);
         if (!geometry.waves) {
             code = fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
         }
+    }
+    if (code == MEMB_HIP_OK && ctx->lanesPerWord > 1) {
+        code = deviceAlloc(ctx, &ctx->segmentIndex, size_t(desc->n_rows) * (ctx->lanesPerWord - 1) * sizeof(uint16_t));
+    }
+    if (code == MEMB_HIP_OK) {
+        code = buildSegmentIndex(ctx);
     }
     if (code != MEMB_HIP_OK) {
         std::string message = g_lastError;
@@ -1055,9 +1152,10 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->max_code_bits = ctx->hostTable.maxCodeBits;
         info->table_entries = static_cast<uint32_t>(ctx->hostTable.entries.size());
         info->max_stream_bytes = ctx->maxStreamBytes;
-        TrainedGeometry geometry = chooseGeometry(ctx, ctx->dim, 0, nullptr);
+        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, (ctx->dim + 3) / 4, ctx->dim, 0, nullptr);
         info->waves_per_block = geometry.waves;
-        info->chunk_symbols = geometry.chunk;
+        info->lanes_per_word = ctx->lanesPerWord;
+        info->segment_symbols = ctx->segmentSymbols;
         info->lds_bytes_per_block = geometry.ldsBytes;
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;

@@ -228,16 +228,23 @@ def test_batch_split_like_two_ranks(native, make_model):
     assert bits_equal(np.concatenate(pieces), reader.batch_embedding(batch))
 
 
-def test_chunked_geometries_give_identical_rows(native, make_model, monkeypatch):
-    # the kernel's tile geometry (waves per block, symbols per output phase) must not change results
-    path, words = make_model(20000, 300, 'trained', 4)
-    checker = oracle.OracleReader(path)
-    rows = np.arange(0, 20000, 3, dtype=np.uint32)
-    expected = checker.rows_embedding(rows)
-    for waves, chunk in ((4, 300), (2, 300), (1, 300), (4, 100), (4, 76), (2, 32), (1, 20), (4, 4)):
-        monkeypatch.setenv('MEMB_HIP_WAVES', str(waves))
-        monkeypatch.setenv('MEMB_HIP_CHUNK', str(chunk))
-        reader = native.Reader(path)
-        assert bits_equal(reader.rows_embedding(rows), expected), (waves, chunk)
-        info = reader.info()
-        assert info['waves_per_block'] == waves and info['chunk_symbols'] == chunk
+def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
+    # lanes per word (segments of the side index) and waves per block must not change results
+    for bits, distribution in ((4, 'normal'), (8, 'student')):
+        path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
+        checker = oracle.OracleReader(path)
+        rows = np.arange(0, 20000, 3, dtype=np.uint32)
+        rows[5::97] = 0xFFFFFFFF
+        expected = checker.rows_embedding(rows)
+        for lanes, waves in ((1, 1), (1, 4), (2, 4), (3, 2), (4, 8), (5, 4), (8, 4), (16, 2), (25, 1), (64, 1)):
+            monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
+            monkeypatch.setenv('MEMB_HIP_WAVES', str(waves))
+            reader = native.Reader(path)
+            assert bits_equal(reader.rows_embedding(rows), expected), (bits, lanes, waves)
+            wide = np.zeros((len(rows), 304), dtype=np.float32)
+            reader.batch_embedding_into([reader.keys()[r] if r < 20000 else '?' for r in rows[:500]], wide[:500], 4)
+            assert bits_equal(wide[:500, 4:], expected[:500]), (bits, lanes, waves)
+            info = reader.info()
+            assert info['waves_per_block'] == waves
+            assert info['lanes_per_word'] * info['segment_symbols'] >= 300
+            assert info['lanes_per_word'] == -(-300 // info['segment_symbols'])

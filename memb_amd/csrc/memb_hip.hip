@@ -74,10 +74,11 @@ struct TrainedParams {
     const uint32_t* valueOffsets;
     const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
-    const uint32_t* table;
-    const float* centroids;
+    const uint32_t* table;          // 8-byte entries, see TableEntry
+    const float* codebook;          // 256 centroids, or 256 centroid pairs (FAST)
     unsigned long long nRows;
     uint32_t tableDwords;     // multiple of 4
+    uint32_t codebookDwords;  // 256 or 512
     uint32_t rootBits;
     uint32_t dim;
     uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
@@ -85,14 +86,27 @@ struct TrainedParams {
     uint32_t lanesPerWord;    // G
     uint32_t laneMagic;       // fastDivide magic for G
     uint32_t wordsPerWave;    // 64 / G
-    uint32_t segmentSymbols;  // S, multiple of 4
-    uint32_t keyStride;       // dwords per word in the symbol tile = ceil(dim / 4)
-    uint32_t keyMagic;        // fastDivide magic for keyStride (vector output)
+    uint32_t segmentSymbols;  // S, multiple of the decode group (4, or 8 when FAST)
+    uint32_t keyRowBytes;     // bytes per word in the symbol tile
+    uint32_t keyTileDwords;   // dwords of the symbol tile of one wave
+    uint32_t pieceMagic;      // fastDivide magic for dim / 4 (vector output)
     uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
     uint32_t indexSegmentSymbols;
+    uint32_t debugFlags;      // measurement only (MEMB_HIP_DEBUG): 1 = skip decode, 2 = skip output
 };
 
 enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3 };
+
+// Device form of one lookup-table entry (logical layout: memb::DecodeTable).
+//   x: leaf    -> code length                       (bits 8..31 zero)
+//      pointer -> TABLE_POINTER_FLAG | extra bits | first sub-table entry << 8
+//   y: leaf    -> the symbol replicated into every byte (or every nibble, FAST),
+//                 so that packing symbol s of a group is one AND-OR with a
+//                 constant mask
+struct TableEntry {
+    uint32_t x;
+    uint32_t y;
+};
 
 // 16-byte load from an address that is only 4-byte aligned (bitstreams start
 // on arbitrary bytes; the staging copy starts at the enclosing dword).
@@ -119,112 +133,141 @@ __device__ __forceinline__ void waveLdsFence()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool HAS_SUB, int MODE>
-__global__ void decode_trained(TrainedParams p)
+// ---- building blocks shared by the one-shot and the persistent kernel ----
+
+struct LaneRole {
+    uint32_t word;      // word of the tile this lane works on
+    uint32_t segment;   // segment of that word
+    bool spare;         // 64 % G lanes at the top: decode word 0's slot, store nothing
+};
+
+__device__ __forceinline__ LaneRole laneRole(const TrainedParams& p, uint32_t lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const uint32_t wavesPerBlock = blockDim.x / WAVE;
-
-    uint32_t* tableLds = lds;
-    float* centroidLds = reinterpret_cast<float*>(lds + p.tableDwords);
-    const uint32_t perWave = p.wordsPerWave * (p.slotDwords + p.keyStride);
-    uint32_t* slots = lds + p.tableDwords + 256 + wave * perWave;
-    uint32_t* keyTile = slots + p.wordsPerWave * p.slotDwords;
-
-    for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
-        reinterpret_cast<uint4*>(tableLds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
-    }
-    if (MODE != OUT_INDEX) {
-        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-            centroidLds[i] = p.centroids[i];
-        }
-    }
-    __syncthreads();
-
-    const unsigned long long tileBase =
-        (static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave) * p.wordsPerWave;
-    if (tileBase >= p.n) {
-        return;
-    }
-    const uint32_t tileWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-
-    // lane -> (word of the tile, segment of the word)
-    // (64 % G spare lanes at the top get word == wordsPerWave: they decode word 0's slot and store nothing)
+    LaneRole role;
     const uint32_t laneWord = fastDivide(lane, p.laneMagic, p.lanesPerWord);
-    const uint32_t segment = lane - laneWord * p.lanesPerWord;
-    const bool spare = laneWord >= p.wordsPerWave;
-    const uint32_t word = spare ? 0 : laneWord;
+    role.segment = lane - laneWord * p.lanesPerWord;
+    role.spare = laneWord >= p.wordsPerWave;
+    role.word = role.spare ? 0 : laneWord;
+    return role;
+}
 
-    uint32_t row = MISSING;
-    if (!spare && word < tileWords) {
-        row = p.rows ? p.rows[tileBase + word] : static_cast<uint32_t>(tileBase + word);
+// Row id of the lane's word in tile `tile`; MISSING for padding lanes and past the batch end.
+__device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned long long tile, const LaneRole& role)
+{
+    const unsigned long long index = tile * p.wordsPerWave + role.word;
+    if (role.spare || index >= p.n) {
+        return MISSING;
     }
-    const bool present = row < p.nRows;
-    const uint32_t offset = present ? p.valueOffsets[row] : 0;
-    uint32_t segmentBits = 0;
-    if (present && segment > 0) {
-        segmentBits = p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + segment - 1];
-    }
+    return p.rows ? p.rows[index] : static_cast<uint32_t>(index);
+}
 
-    // Stage the tile's bitstreams: piece q = (word, 16-byte piece) -> one lane.
-    // All loads of a batch are issued before the first one is waited for.
-    // Absent words read the start of the array (always mapped: the guard is a
-    // slot long) and never emit what they decode.
-    {
-        const uint32_t piecesPerWord = p.slotDwords / 4;
-        const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-        const uint32_t sourceOffset = present ? (offset & ~3u) : 0u;
-        constexpr int BATCH = 4;
-        for (uint32_t q0 = 0; q0 < totalPieces; q0 += WAVE * BATCH) {
-            uint4 v[BATCH];
-            uint32_t destination[BATCH];
+struct WordMeta {
+    uint32_t row;
+    uint32_t offset;        // byte offset of the word's bitstream
+    uint32_t segmentBits;   // bit offset of the lane's segment inside that stream
+};
+
+__device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_t row, const LaneRole& role)
+{
+    WordMeta meta;
+    meta.row = row;
+    meta.offset = 0;
+    meta.segmentBits = 0;
+    if (row < p.nRows) {
+        meta.offset = p.valueOffsets[row];
+        if (role.segment > 0) {
+            meta.segmentBits =
+                p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1];
+        }
+    }
+    return meta;
+}
+
+constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
+
+// Issue the loads that copy a tile's bitstreams: piece q = (word, 16-byte piece) -> one lane.
+// Absent words read the start of the array (always mapped: the guard is a slot
+// long) and never emit what they decode. FIRST/COUNT select the piece rounds.
+template <int COUNT>
+__device__ __forceinline__ void issueStreamLoads(
+    const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, uint4 (&v)[COUNT])
+{
+    const uint32_t piecesPerWord = p.slotDwords / 4;
+    const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
+    const uint32_t sourceOffset = meta.row < p.nRows ? (meta.offset & ~3u) : 0u;
 #pragma unroll
-            for (int b = 0; b < BATCH; ++b) {
-                const uint32_t q = q0 + WAVE * b + lane;
-                const uint32_t w = min(fastDivide(q, p.slotMagic, piecesPerWord), p.wordsPerWave - 1);
-                const uint32_t piece = q - w * piecesPerWord;
-                const uint32_t wordOffset = __shfl(sourceOffset, w * p.lanesPerWord);
-                destination[b] = w * p.slotDwords + 4 * piece;
-                if (q < totalPieces) {
-                    v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < BATCH; ++b) {
-                const uint32_t q = q0 + WAVE * b + lane;
-                if (q < totalPieces) {
-                    uint4 t = v[b];
-                    t.x = byteSwap(t.x);
-                    t.y = byteSwap(t.y);
-                    t.z = byteSwap(t.z);
-                    t.w = byteSwap(t.w);
-                    *reinterpret_cast<uint4*>(slots + destination[b]) = t;
-                }
+    for (int b = 0; b < COUNT; ++b) {
+        if ((firstRound + b) * WAVE < totalPieces) {   // wave-uniform
+            const uint32_t q = (firstRound + b) * WAVE + lane;
+            const uint32_t w = min(fastDivide(q, p.slotMagic, piecesPerWord), p.wordsPerWave - 1);
+            const uint32_t piece = q - w * piecesPerWord;
+            const uint32_t wordOffset = __shfl(sourceOffset, w * p.lanesPerWord);
+            if (q < totalPieces) {
+                v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
             }
         }
     }
-    waveLdsFence();
+}
 
-    const uint32_t* slot = slots + word * p.slotDwords;
-    uint32_t* keyRow = keyTile + word * p.keyStride;
+// Big-endian dwords into the LDS slots, so that the decoder extracts bits with plain shifts.
+template <int COUNT>
+__device__ __forceinline__ void writeStreams(
+    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t firstRound, const uint4 (&v)[COUNT])
+{
+    const uint32_t piecesPerWord = p.slotDwords / 4;
+    const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
+#pragma unroll
+    for (int b = 0; b < COUNT; ++b) {
+        const uint32_t q = (firstRound + b) * WAVE + lane;
+        if (q < totalPieces) {
+            const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
+            const uint32_t piece = q - w * piecesPerWord;
+            uint4 t = v[b];
+            t.x = byteSwap(t.x);
+            t.y = byteSwap(t.y);
+            t.z = byteSwap(t.z);
+            t.w = byteSwap(t.w);
+            *reinterpret_cast<uint4*>(slots + w * p.slotDwords + 4 * piece) = t;
+        }
+    }
+}
+
+// FAST: codebook of at most 16 centroids and no code longer than 8 bits (2- and
+// 4-bit models). Eight symbols are decoded per 64-bit window (7 * 8 consumed bits
+// + 8 looked-ahead bits fit), symbols are staged as nibbles, and the output phase
+// fetches two centroids per LDS read from a 256-entry table of pairs.
+//
+// Decode the lane's segment from its word's LDS slot into the symbol tile
+// (or, OUT_INDEX, record segment start positions).
+template <bool HAS_SUB, int MODE, bool FAST>
+__device__ __forceinline__ void decodeSegment(
+    const TrainedParams& p, const TableEntry* tableLds, const uint32_t* slots, uint32_t* keyTile,
+    const LaneRole& role, const WordMeta& meta)
+{
+    constexpr int GROUP = FAST ? 8 : 4;
+    constexpr uint32_t KEY_BITS = FAST ? 4 : 8;
+    constexpr uint32_t KEY_MASK = FAST ? 0xFu : 0xFFu;
+
+    const bool present = meta.row < p.nRows;
+    const uint32_t* slot = slots + role.word * p.slotDwords;
+    uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
     const uint32_t lastWindow = p.slotDwords - 3;
     const uint32_t rootShift = 32 - p.rootBits;
-    const uint32_t startBit = (offset & 3u) * 8;
-    uint32_t bitPos = startBit + segmentBits;
-    const uint32_t firstColumn = segment * (p.segmentSymbols / 4);
+    const uint32_t startBit = (meta.offset & 3u) * 8;
+    uint32_t bitPos = startBit + meta.segmentBits;
+    // byte position of this lane's first group inside the symbol tile
+    uint32_t keyOffset = role.word * p.keyRowBytes + role.segment * (p.segmentSymbols * KEY_BITS / 8);
+    const uint32_t keyRowEnd = role.spare ? 0 : (role.word + 1) * p.keyRowBytes;
+    const uint32_t absentFill = present ? 0u : 0xFFFFFFFFu;   // byte keys: ZERO_KEY everywhere
     uint32_t nextIndexSymbol = p.indexSegmentSymbols;
     uint32_t indexSlot = 0;
 
-    for (uint32_t j = 0; j < p.segmentSymbols; j += 4) {
+    for (uint32_t j = 0; j < p.segmentSymbols; j += GROUP) {
         if (MODE == OUT_INDEX) {
             // one lane per word here; record where every indexSegmentSymbols-th symbol starts
             if (j == nextIndexSymbol) {
                 if (present && indexSlot + 1 < p.indexLanes) {
-                    p.segmentIndexOut[static_cast<unsigned long long>(row) * (p.indexLanes - 1) + indexSlot] =
+                    p.segmentIndexOut[static_cast<unsigned long long>(meta.row) * (p.indexLanes - 1) + indexSlot] =
                         static_cast<uint16_t>(bitPos - startBit);
                 }
                 ++indexSlot;
@@ -237,75 +280,261 @@ __global__ void decode_trained(TrainedParams p)
         const uint32_t w1 = slot[d + 1];
         const uint32_t w2 = slot[d + 2];
         // 64 valid bits starting at the current bit position, MSB first.
-        unsigned long long window =
-            (((static_cast<unsigned long long>(w0) << 32) | w1) << shift) |
-            (static_cast<unsigned long long>(w2) >> (32 - shift));
+        unsigned long long window = ((static_cast<unsigned long long>(w0) << 32) | w1) << shift;
+        window |= static_cast<uint32_t>(static_cast<unsigned long long>(w2) >> (32 - shift));
         uint32_t keys = 0;
+        uint32_t lengths = 0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint32_t entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
+        for (int s = 0; s < GROUP; ++s) {
+            TableEntry entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
             if (HAS_SUB) {
-                if (entry & memb::TABLE_POINTER_FLAG) {
-                    const uint32_t subBits = entry & 0xff;
-                    const uint32_t base = (entry & ~memb::TABLE_POINTER_FLAG) >> 8;
+                if (entry.x & memb::TABLE_POINTER_FLAG) {
+                    const uint32_t subBits = entry.x & 0xff;
+                    const uint32_t base = (entry.x & ~memb::TABLE_POINTER_FLAG) >> 8;
                     const uint32_t subIndex =
                         static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
                     entry = tableLds[base + subIndex];
                 }
             }
-            const uint32_t length = entry & 0xff;
-            window <<= length;
-            bitPos += length;
-            keys |= ((entry >> 8) & 0xff) << (8 * s);
+            window <<= (entry.x & 63);
+            lengths += entry.x;
+            keys |= entry.y & (KEY_MASK << (KEY_BITS * s));
         }
+        bitPos += lengths;
         if (MODE != OUT_INDEX) {
-            const uint32_t column = firstColumn + (j >> 2);
-            if (column < p.keyStride && !spare) {
-                keyRow[column] = present ? keys : 0xFFFFFFFFu;
+            keys |= absentFill;
+            if (FAST) {
+                // rows are dim / 2 bytes: 2-byte aligned only
+                if (keyOffset + 2 <= keyRowEnd) {
+                    *reinterpret_cast<uint16_t*>(keyBytes + keyOffset) = static_cast<uint16_t>(keys);
+                }
+                if (keyOffset + 4 <= keyRowEnd) {
+                    *reinterpret_cast<uint16_t*>(keyBytes + keyOffset + 2) = static_cast<uint16_t>(keys >> 16);
+                }
+            } else {
+                if (keyOffset + 4 <= keyRowEnd) {
+                    *reinterpret_cast<uint32_t*>(keyBytes + keyOffset) = keys;
+                }
+            }
+            keyOffset += 4;
+        }
+    }
+}
+
+// Symbol tile -> fp32 rows: codebook gather and row-contiguous stores.
+template <int MODE, bool FAST>
+__device__ __forceinline__ void outputTile(
+    const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
+    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
+{
+    const float* centroidLds = reinterpret_cast<const float*>(codebookLds);
+    const float2* pairLds = reinterpret_cast<const float2*>(codebookLds);
+    const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
+
+    if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
+        // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
+        // (byte keys: rows of dim bytes; nibble keys: rows of dim / 2 bytes).
+        const uint32_t piecesPerWord = p.dim / 4;
+        const uint32_t pieces = tileWords * piecesPerWord;
+        float* tileOut = p.out + tileBase * p.ld + p.colOff;
+        for (uint32_t q = lane; q < pieces; q += WAVE) {
+            float4 f;
+            if (FAST) {
+                const uint32_t k = reinterpret_cast<const uint16_t*>(keyTile)[q];
+                const float2 a = pairLds[k & 0xff];
+                const float2 b = pairLds[k >> 8];
+                f = make_float4(a.x, a.y, b.x, b.y);
+            } else {
+                const uint32_t k = keyTile[q];
+                f.x = centroidLds[k & 0xff];
+                f.y = centroidLds[(k >> 8) & 0xff];
+                f.z = centroidLds[(k >> 16) & 0xff];
+                f.w = centroidLds[k >> 24];
+            }
+            if (MODE == OUT_FLAT) {
+                reinterpret_cast<float4*>(tileOut)[q] = f;
+            } else {
+                const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
+                const uint32_t c = q - w * piecesPerWord;
+                *reinterpret_cast<float4*>(tileOut + w * p.ld + 4 * c) = f;
+            }
+        }
+    } else {
+        const uint32_t total = tileWords * p.dim;
+        for (uint32_t q = lane; q < total; q += WAVE) {
+            const uint32_t w = q / p.dim;
+            const uint32_t c = q - w * p.dim;
+            float value;
+            if (FAST) {
+                const uint32_t k = keyBytes[w * p.keyRowBytes + (c >> 1)];
+                value = pairLds[(k >> (4 * (c & 1))) & 15].x;
+            } else {
+                value = centroidLds[keyBytes[w * p.keyRowBytes + c]];
+            }
+            p.out[(tileBase + w) * p.ld + p.colOff + c] = value;
+        }
+    }
+
+    if (FAST) {
+        // Nibble keys have no spare code for "absent": zero the rows of absent
+        // words afterwards (same wave, same addresses: program order holds).
+        unsigned long long absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
+        while (absent) {
+            const uint32_t w = fastDivide(__ffsll(static_cast<long long>(absent)) - 1, p.laneMagic, p.lanesPerWord);
+            absent &= absent - 1;
+            float* rowOut = p.out + (tileBase + w) * p.ld + p.colOff;
+            for (uint32_t c = lane; c < p.dim; c += WAVE) {
+                rowOut[c] = 0.f;
             }
         }
     }
+}
+
+struct WaveLds {
+    const TableEntry* table;
+    const uint32_t* codebook;
+    uint32_t* slots;
+    uint32_t* keyTile;
+};
+
+// LDS layout: lookup table | codebook | per wave { bitstream slots | symbol tile }.
+// Loads table and codebook; ends with a block barrier.
+template <int MODE>
+__device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* lds)
+{
+    const uint32_t wave = threadIdx.x / WAVE;
+    uint32_t* codebookLds = lds + p.tableDwords;
+    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
+    WaveLds result;
+    result.table = reinterpret_cast<const TableEntry*>(lds);
+    result.codebook = codebookLds;
+    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
+    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
+
+    for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
+    }
+    if (MODE != OUT_INDEX) {
+        for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
+            codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
+        }
+    }
+    __syncthreads();
+    return result;
+}
+
+// One-shot kernel: one tile per wavefront. Used to build the segment index
+// (OUT_INDEX) and for tiles too wide for the persistent kernel's registers.
+template <bool HAS_SUB, int MODE, bool FAST>
+__global__ void decode_trained(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const WaveLds mem = setUpLds<MODE>(p, lds);
+
+    const unsigned long long tile =
+        static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const unsigned long long tileBase = tile * p.wordsPerWave;
+    if (tileBase >= p.n) {
+        return;
+    }
+    const uint32_t tileWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+
+    const LaneRole role = laneRole(p, lane);
+    const WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
+
+    const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
+    for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
+        uint4 v[STREAM_REGISTERS];
+        issueStreamLoads(p, meta, lane, round, v);
+        writeStreams(p, mem.slots, lane, round, v);
+    }
+    waveLdsFence();
+
+    decodeSegment<HAS_SUB, MODE, FAST>(p, mem.table, mem.slots, mem.keyTile, role, meta);
     if (MODE == OUT_INDEX) {
         return;
     }
     waveLdsFence();
+    outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+}
 
-    if (MODE == OUT_FLAT) {
-        // ld == dim: the symbol tile [tileWords][dim / 4] and the output tile are both linear.
-        const uint32_t pieces = tileWords * p.keyStride;
-        float4* dst = reinterpret_cast<float4*>(p.out + tileBase * p.ld);
-        for (uint32_t q = lane; q < pieces; q += WAVE) {
-            const uint32_t k = keyTile[q];
-            float4 f;
-            f.x = centroidLds[k & 0xff];
-            f.y = centroidLds[(k >> 8) & 0xff];
-            f.z = centroidLds[(k >> 16) & 0xff];
-            f.w = centroidLds[k >> 24];
-            dst[q] = f;
+// Persistent kernel: every wavefront walks tiles wave, wave + W, wave + 2W, ...
+// and keeps three tiles' worth of loads in flight, so that no decode waits for
+// global memory: while tile t is decoded, the bitstream bytes of tile t + 1 sit
+// in registers, the offsets / segment positions of tile t + 2 and the row ids
+// of tile t + 3 are on their way. Each of those hops depends on the previous
+// one (row id -> offset -> stream bytes); issued back to back they are what a
+// one-tile wavefront spends most of its life waiting for.
+template <bool HAS_SUB, int MODE, bool FAST>
+__global__ void decode_trained_persistent(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const WaveLds mem = setUpLds<MODE>(p, lds);
+
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
+    if (tile >= tiles) {
+        return;
+    }
+    const LaneRole role = laneRole(p, lane);
+
+    // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
+    uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
+    WordMeta meta0 = loadWordMeta(p, loadTileRow(p, tile, role), role);
+    WordMeta meta1 = loadWordMeta(p, loadTileRow(p, tile + stride, role), role);
+    WordMeta metaLoading = loadWordMeta(p, loadTileRow(p, tile + 2 * stride, role), role);
+    uint4 streams[STREAM_REGISTERS];
+    issueStreamLoads(p, meta0, lane, 0, streams);
+    writeStreams(p, mem.slots, lane, 0, streams);
+    issueStreamLoads(p, meta1, lane, 0, streams);
+    waveLdsFence();
+
+    // Invariant at the top, for the current tile t:
+    //   LDS slots hold the bitstreams of t;
+    //   in flight since the end of the previous round: `streams` = stream bytes of t + 1,
+    //   `metaLoading` = offsets of t + 2, `rowLoading` = row ids of t + 3.
+    // In-flight registers are touched at ONE point per round, right after the
+    // decode (which gave them a whole decode to land) and before this round's
+    // stores are issued, so that the wait there is only for loads; the new
+    // loads are the last memory instructions of the round.
+    for (; tile < tiles; tile += stride) {
+        const unsigned long long tileBase = tile * p.wordsPerWave;
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+
+        if (!(p.debugFlags & 1)) {
+            decodeSegment<HAS_SUB, MODE, FAST>(p, mem.table, mem.slots, mem.keyTile, role, meta0);
         }
-    } else if (MODE == OUT_VEC4) {
-        const uint32_t pieces = tileWords * p.keyStride;
-        for (uint32_t q = lane; q < pieces; q += WAVE) {
-            const uint32_t w = fastDivide(q, p.keyMagic, p.keyStride);
-            const uint32_t c = q - w * p.keyStride;
-            const uint32_t k = keyTile[q];
-            float4 f;
-            f.x = centroidLds[k & 0xff];
-            f.y = centroidLds[(k >> 8) & 0xff];
-            f.z = centroidLds[(k >> 16) & 0xff];
-            f.w = centroidLds[k >> 24];
-            float* dst = p.out + (tileBase + w) * p.ld + p.colOff + 4 * c;
-            *reinterpret_cast<float4*>(dst) = f;
+        waveLdsFence();
+
+        // consume point
+        writeStreams(p, mem.slots, lane, 0, streams);   // bitstreams of t + 1 replace those of t
+        // (copies pinned here: left to the register allocator they move to the loop
+        // header, and the wait for the loads moves with them)
+        WordMeta meta2;
+        uint32_t row3;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.offset) : "v"(metaLoading.offset));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (!(p.debugFlags & 2)) {
+            outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta0.row < p.nRows);
         }
-    } else {
-        const uint32_t total = tileWords * p.dim;
-        const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
-        for (uint32_t q = lane; q < total; q += WAVE) {
-            const uint32_t w = q / p.dim;
-            const uint32_t c = q - w * p.dim;
-            const uint32_t k = keyBytes[w * p.keyStride * 4 + c];
-            p.out[(tileBase + w) * p.ld + p.colOff + c] = centroidLds[k];
-        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // next round of loads; each uses what the previous round fetched
+        issueStreamLoads(p, meta2, lane, 0, streams);          // stream bytes of t + 2
+        metaLoading = loadWordMeta(p, row3, role);              // offsets of t + 3
+        rowLoading = loadTileRow(p, tile + 4 * stride, role);   // row ids of t + 4
+        meta0 = meta1;
+        meta1 = meta2;
+        waveLdsFence();
     }
 }
 
@@ -489,7 +718,8 @@ struct memb_hip_ctx {
     uint8_t* packed = nullptr;
     uint32_t* valueOffsets = nullptr;
     uint32_t* table = nullptr;
-    float* centroids = nullptr;
+    float* codebook = nullptr;
+    bool fast = false;                   // <= 16 centroids, codes <= 8 bits, one-level table
     memb::DecodeTable hostTable;
     uint32_t tableDwords = 0;
     uint32_t maxStreamBytes = 0;
@@ -528,16 +758,33 @@ uint32_t roundUp4(uint32_t v)
     return (v + 3) / 4 * 4;
 }
 
-uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, uint32_t keyStride)
+// symbol tile of one wave: rows of dim bytes (dword aligned) or dim / 2 bytes (FAST)
+uint32_t keyRowBytes(const memb_hip_ctx* ctx)
 {
-    return 4u * (ctx->tableDwords + 256u + waves * wordsPerWave * (ctx->slotDwords + keyStride));
+    return ctx->fast ? ((ctx->dim + 1) / 2 + 1) / 2 * 2 : roundUp4(ctx->dim);
+}
+
+uint32_t keyTileDwords(const memb_hip_ctx* ctx, uint32_t wordsPerWave)
+{
+    return wordsPerWave ? (wordsPerWave * keyRowBytes(ctx) + 3) / 4 + 1 : 0;
+}
+
+uint32_t codebookDwords(const memb_hip_ctx* ctx)
+{
+    return ctx->fast ? 512u : 256u;
+}
+
+uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys)
+{
+    uint32_t perWave = wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
+    return 4u * (ctx->tableDwords + codebookDwords(ctx) + waves * perWave);
 }
 
 // Waves per block: as many resident wavefronts per CU as LDS allows (the
 // decode is a chain of dependent LDS lookups, so occupancy is what hides it),
 // larger blocks on ties (fewer copies of the lookup table).
 TrainedGeometry chooseGeometry(
-    const memb_hip_ctx* ctx, uint32_t wordsPerWave, uint32_t keyStride, size_t ld, size_t colOff, const float* out)
+    const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out)
 {
     TrainedGeometry best{};
     double bestWaves = -1;
@@ -546,7 +793,7 @@ TrainedGeometry chooseGeometry(
         if (forcedWaves && waves != forcedWaves) {
             continue;
         }
-        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, keyStride);
+        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true);
         if (ldsBytes > ctx->ldsLimit) {
             continue;
         }
@@ -571,7 +818,7 @@ TrainedGeometry chooseGeometry(
     return best;
 }
 
-template <bool HAS_SUB, int MODE>
+template <bool HAS_SUB, int MODE, bool FAST>
 hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
     static thread_local int configuredDevice = -1;
@@ -579,7 +826,7 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
     (void)hipGetDevice(&device);
     if (configuredDevice != device) {
         hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&decode_trained<HAS_SUB, MODE>),
+            reinterpret_cast<const void*>(&decode_trained<HAS_SUB, MODE, FAST>),
             hipFuncAttributeMaxDynamicSharedMemorySize,
             160 * 1024);
         if (status != hipSuccess) {
@@ -588,16 +835,65 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
         configuredDevice = device;
     }
     hipLaunchKernelGGL(
-        (decode_trained<HAS_SUB, MODE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+        (decode_trained<HAS_SUB, MODE, FAST>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+    return hipGetLastError();
+}
+
+template <bool HAS_SUB, int MODE, bool FAST>
+hipError_t launchPersistentVariant(
+    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    static thread_local int configuredDevice = -1;
+    static thread_local int blocksPerCu = 0;
+    static thread_local uint32_t configuredThreads = 0;
+    static thread_local uint32_t configuredLds = 0;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const void* kernel = reinterpret_cast<const void*>(&decode_trained_persistent<HAS_SUB, MODE, FAST>);
+    if (configuredDevice != device || configuredThreads != threads || configuredLds != ldsBytes) {
+        hipError_t status = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (status != hipSuccess) {
+            return status;
+        }
+        status = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &blocksPerCu, decode_trained_persistent<HAS_SUB, MODE, FAST>, static_cast<int>(threads), ldsBytes);
+        if (status != hipSuccess) {
+            return status;
+        }
+        blocksPerCu = std::max(blocksPerCu, 1);
+        configuredDevice = device;
+        configuredThreads = threads;
+        configuredLds = ldsBytes;
+    }
+    // as many blocks as are resident at once; each wavefront strides over the tiles
+    const uint32_t resident = static_cast<uint32_t>(blocksPerCu) * ctx->cuCount;
+    const uint32_t blocks = std::min(tileBlocks, resident);
+    hipLaunchKernelGGL(
+        (decode_trained_persistent<HAS_SUB, MODE, FAST>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
 }
 
 template <int MODE>
-hipError_t launchTrainedMode(
-    bool hasSubTables, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+hipError_t launchPersistentMode(
+    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
-    return hasSubTables ? launchTrainedVariant<true, MODE>(params, blocks, threads, ldsBytes, stream)
-                        : launchTrainedVariant<false, MODE>(params, blocks, threads, ldsBytes, stream);
+    if (ctx->fast) {
+        return launchPersistentVariant<false, MODE, true>(ctx, params, blocks, threads, ldsBytes, stream);
+    }
+    return ctx->hostTable.hasSubTables
+        ? launchPersistentVariant<true, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream)
+        : launchPersistentVariant<false, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream);
+}
+
+template <int MODE>
+hipError_t launchTrainedMode(
+    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    if (ctx->fast) {
+        return launchTrainedVariant<false, MODE, true>(params, blocks, threads, ldsBytes, stream);
+    }
+    return ctx->hostTable.hasSubTables ? launchTrainedVariant<true, MODE, false>(params, blocks, threads, ldsBytes, stream)
+                                       : launchTrainedVariant<false, MODE, false>(params, blocks, threads, ldsBytes, stream);
 }
 
 TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
@@ -607,13 +903,15 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.valueOffsets = ctx->valueOffsets;
     params.segmentIndex = ctx->segmentIndex;
     params.table = ctx->table;
-    params.centroids = ctx->centroids;
+    params.codebook = ctx->codebook;
     params.nRows = ctx->nRows;
     params.tableDwords = ctx->tableDwords;
+    params.codebookDwords = codebookDwords(ctx);
     params.rootBits = ctx->hostTable.rootBits;
     params.dim = ctx->dim;
     params.slotDwords = ctx->slotDwords;
     params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4) * 5);
+    params.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
     return params;
 }
 
@@ -621,8 +919,7 @@ int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-    const uint32_t keyStride = (ctx->dim + 3) / 4;
-    TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, keyStride, ld, colOff, out);
+    TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out);
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
@@ -636,23 +933,30 @@ int launchTrained(
     params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
     params.wordsPerWave = wordsPerWave;
     params.segmentSymbols = ctx->segmentSymbols;
-    params.keyStride = keyStride;
-    params.keyMagic = magicFor(keyStride, uint64_t(wordsPerWave) * keyStride);
+    params.keyRowBytes = keyRowBytes(ctx);
+    params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
+    params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
 
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;
-    const bool sub = ctx->hostTable.hasSubTables;
+    // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
+    // (long streams with few lanes per word) take the one-shot kernel.
+    const uint32_t streamRounds = (wordsPerWave * (ctx->slotDwords / 4) + WAVE - 1) / WAVE;
+    const bool persistent = streamRounds <= STREAM_REGISTERS && envUint("MEMB_HIP_PERSISTENT", 1) != 0;
     hipError_t status;
     switch (geometry.mode) {
         case OUT_FLAT:
-            status = launchTrainedMode<OUT_FLAT>(sub, params, blocks, threads, geometry.ldsBytes, stream);
+            status = persistent ? launchPersistentMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
+                                : launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
             break;
         case OUT_VEC4:
-            status = launchTrainedMode<OUT_VEC4>(sub, params, blocks, threads, geometry.ldsBytes, stream);
+            status = persistent ? launchPersistentMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
+                                : launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
             break;
         default:
-            status = launchTrainedMode<OUT_SCALAR>(sub, params, blocks, threads, geometry.ldsBytes, stream);
+            status = persistent ? launchPersistentMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
+                                : launchTrainedMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
             break;
     }
     if (status != hipSuccess) {
@@ -677,23 +981,23 @@ int buildSegmentIndex(memb_hip_ctx* ctx)
     params.lanesPerWord = 1;
     params.laneMagic = 0;
     params.wordsPerWave = WAVE;
-    params.segmentSymbols = roundUp4(ctx->dim);
-    params.keyStride = 0;
+    params.segmentSymbols = (ctx->dim + 7) / 8 * 8;
+    params.keyRowBytes = 0;
+    params.keyTileDwords = 0;
     params.indexLanes = ctx->lanesPerWord;
     params.indexSegmentSymbols = ctx->segmentSymbols;
 
     uint32_t waves = 4;
-    while (waves > 1 && trainedLdsBytes(ctx, waves, WAVE, 0) > ctx->ldsLimit) {
+    while (waves > 1 && trainedLdsBytes(ctx, waves, WAVE, false) > ctx->ldsLimit) {
         waves /= 2;
     }
-    const uint32_t ldsBytes = trainedLdsBytes(ctx, waves, WAVE, 0);
+    const uint32_t ldsBytes = trainedLdsBytes(ctx, waves, WAVE, false);
     if (ldsBytes > ctx->ldsLimit) {
         return fail(MEMB_HIP_ERR_INVALID, "bitstream slots do not fit into LDS");
     }
     const size_t tiles = (ctx->nRows + WAVE - 1) / WAVE;
     const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
-    hipError_t status = launchTrainedMode<OUT_INDEX>(
-        ctx->hostTable.hasSubTables, params, blocks, waves * WAVE, ldsBytes, ctx->stream);
+    hipError_t status = launchTrainedMode<OUT_INDEX>(ctx, params, blocks, waves * WAVE, ldsBytes, ctx->stream);
     if (status == hipSuccess) {
         status = hipStreamSynchronize(ctx->stream);
     }
@@ -966,7 +1270,9 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
     // odd number of them so that equal positions in consecutive slots fall
     // into different LDS banks.
     ctx->slotDwords = (((ctx->maxStreamBytes + 3 + 12 + 15) / 16) | 1u) * 4;
-    ctx->tableDwords = static_cast<uint32_t>((ctx->hostTable.entries.size() + 3) / 4 * 4);
+    ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
+        !envUint("MEMB_HIP_NO_FAST", 0);
+    ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
 
     // Lanes per word (G) and symbols per lane (S). The side index stores 16-bit
     // bit offsets, so rows longer than 65535 bits keep one lane per word.
@@ -976,7 +1282,8 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         if (uint64_t(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) >= 65536 || desc->dim < 8) {
             lanes = 1;
         }
-        ctx->segmentSymbols = std::max<uint32_t>(4, roundUp4((desc->dim + lanes - 1) / lanes));
+        const uint32_t group = ctx->fast ? 8 : 4;
+        ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
         ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
     }
 
@@ -1005,21 +1312,41 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);
     }
     if (code == MEMB_HIP_OK) {
-        std::vector<uint32_t> padded(ctx->tableDwords, 0);
-        std::copy(ctx->hostTable.entries.begin(), ctx->hostTable.entries.end(), padded.begin());
-        code = copyToDevice(ctx->table, padded.data(), padded.size() * 4);
+        // device form of the table: {length or pointer, symbol replicated per byte / nibble}
+        std::vector<uint32_t> expanded(ctx->tableDwords, 0);
+        for (size_t i = 0; i < ctx->hostTable.entries.size(); ++i) {
+            const uint32_t entry = ctx->hostTable.entries[i];
+            if (entry & memb::TABLE_POINTER_FLAG) {
+                expanded[2 * i] = entry;
+            } else {
+                const uint32_t key = (entry >> 8) & 0xff;
+                expanded[2 * i] = entry & 0xff;
+                expanded[2 * i + 1] = ctx->fast ? key * 0x11111111u : key * 0x01010101u;
+            }
+        }
+        code = copyToDevice(ctx->table, expanded.data(), expanded.size() * 4);
     }
     if (code == MEMB_HIP_OK) {
-        code = deviceAlloc(ctx, &ctx->centroids, 256 * 4);
+        code = deviceAlloc(ctx, &ctx->codebook, 512 * 4);
     }
     if (code == MEMB_HIP_OK) {
-        std::vector<float> codebook(256, 0.f);
-        std::copy(desc->centroids, desc->centroids + desc->n_centroids, codebook.begin());
-        codebook[ZERO_KEY] = 0.f;
-        code = copyToDevice(ctx->centroids, codebook.data(), 256 * 4);
+        std::vector<float> centroids(256, 0.f);
+        std::copy(desc->centroids, desc->centroids + desc->n_centroids, centroids.begin());
+        centroids[ZERO_KEY] = 0.f;
+        std::vector<float> codebook(512, 0.f);
+        if (ctx->fast) {
+            // pair b = {centroid[low nibble], centroid[high nibble]}: two symbols per LDS read
+            for (uint32_t b = 0; b < 256; ++b) {
+                codebook[2 * b] = centroids[b & 15];
+                codebook[2 * b + 1] = centroids[b >> 4];
+            }
+        } else {
+            std::copy(centroids.begin(), centroids.end(), codebook.begin());
+        }
+        code = copyToDevice(ctx->codebook, codebook.data(), 512 * 4);
     }
     if (code == MEMB_HIP_OK) {
-        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, (ctx->dim + 3) / 4, ctx->dim, 0, nullptr);
+        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
         if (!geometry.waves) {
             code = fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
         }
@@ -1152,7 +1479,7 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->max_code_bits = ctx->hostTable.maxCodeBits;
         info->table_entries = static_cast<uint32_t>(ctx->hostTable.entries.size());
         info->max_stream_bytes = ctx->maxStreamBytes;
-        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, (ctx->dim + 3) / 4, ctx->dim, 0, nullptr);
+        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
         info->waves_per_block = geometry.waves;
         info->lanes_per_word = ctx->lanesPerWord;
         info->segment_symbols = ctx->segmentSymbols;

@@ -236,11 +236,13 @@ def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
         rows = np.arange(0, 20000, 3, dtype=np.uint32)
         rows[5::97] = 0xFFFFFFFF
         expected = checker.rows_embedding(rows)
-        for lanes, waves in ((1, 1), (1, 4), (2, 4), (3, 2), (4, 8), (5, 4), (8, 4), (16, 2), (25, 1), (64, 1)):
+        for lanes, waves, persistent in ((1, 1, 1), (1, 4, 0), (2, 4, 1), (3, 2, 0), (4, 8, 1), (5, 4, 1), (8, 4, 0),
+                                         (8, 8, 1), (16, 2, 1), (25, 1, 0), (64, 1, 1)):
             monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
             monkeypatch.setenv('MEMB_HIP_WAVES', str(waves))
+            monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(persistent))
             reader = native.Reader(path)
-            assert bits_equal(reader.rows_embedding(rows), expected), (bits, lanes, waves)
+            assert bits_equal(reader.rows_embedding(rows), expected), (bits, lanes, waves, persistent)
             wide = np.zeros((len(rows), 304), dtype=np.float32)
             reader.batch_embedding_into([reader.keys()[r] if r < 20000 else '?' for r in rows[:500]], wide[:500], 4)
             assert bits_equal(wide[:500, 4:], expected[:500]), (bits, lanes, waves)
@@ -248,3 +250,15 @@ def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
             assert info['waves_per_block'] == waves
             assert info['lanes_per_word'] * info['segment_symbols'] >= 300
             assert info['lanes_per_word'] == -(-300 // info['segment_symbols'])
+
+
+def test_generic_path_on_a_small_codebook(native, make_model, monkeypatch):
+    # <= 16 centroids normally take the nibble / pair-table variant; the byte-key variant must agree
+    path, words = make_model(20000, 300, 'trained', 4)
+    rows = np.arange(0, 20000, 7, dtype=np.uint32)
+    rows[3::50] = 0xFFFFFFFF
+    expected = oracle.OracleReader(path).rows_embedding(rows)
+    monkeypatch.setenv('MEMB_HIP_NO_FAST', '1')
+    assert bits_equal(native.Reader(path).rows_embedding(rows), expected)
+    monkeypatch.delenv('MEMB_HIP_NO_FAST')
+    assert bits_equal(native.Reader(path).rows_embedding(rows), expected)

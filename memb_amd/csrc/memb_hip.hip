@@ -351,6 +351,8 @@ __device__ __forceinline__ void outputTile(
                 f.z = centroidLds[(k >> 16) & 0xff];
                 f.w = centroidLds[k >> 24];
             }
+            // Plain stores: non-temporal ones measured 4-5 % slower here (0.68 vs 0.65 ms,
+            // interleaved A/B on the 2.2M-word dump).
             if (MODE == OUT_FLAT) {
                 reinterpret_cast<float4*>(tileOut)[q] = f;
             } else {

@@ -70,8 +70,8 @@ struct TrainedParams {
     unsigned long long n;
     unsigned long long ld;
     unsigned long long colOff;
-    const uint8_t* packed;
-    const uint32_t* valueOffsets;
+    const uint4* streams;           // re-packed bitstreams: big-endian dwords, one 16-byte aligned run per row
+    const uint32_t* streamStarts;   // [nRows + 1] first 16-byte piece of each row's run
     const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
     const uint32_t* table;          // 8-byte entries, see TableEntry
@@ -107,10 +107,6 @@ struct TableEntry {
     uint32_t x;
     uint32_t y;
 };
-
-// 16-byte load from an address that is only 4-byte aligned (bitstreams start
-// on arbitrary bytes; the staging copy starts at the enclosing dword).
-typedef uint4 __attribute__((aligned(4))) uint4_align4;
 
 // q / d with a host-computed magic = ceil(2^32 / d) (exact while q * d < 2^32);
 // magic == 0 means "no magic" (d == 1, or the range is too large): plain division.
@@ -163,7 +159,7 @@ __device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned
 
 struct WordMeta {
     uint32_t row;
-    uint32_t offset;        // byte offset of the word's bitstream
+    uint32_t start;         // first 16-byte piece of the word's bitstream
     uint32_t segmentBits;   // bit offset of the lane's segment inside that stream
 };
 
@@ -171,10 +167,10 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
 {
     WordMeta meta;
     meta.row = row;
-    meta.offset = 0;
+    meta.start = 0;
     meta.segmentBits = 0;
     if (row < p.nRows) {
-        meta.offset = p.valueOffsets[row];
+        meta.start = p.streamStarts[row];
         if (role.segment > 0) {
             meta.segmentBits =
                 p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1];
@@ -185,51 +181,64 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
 
 constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
 
-// Issue the loads that copy a tile's bitstreams: piece q = (word, 16-byte piece) -> one lane.
-// Absent words read the start of the array (always mapped: the guard is a slot
-// long) and never emit what they decode. FIRST/COUNT select the piece rounds.
-template <int COUNT>
-__device__ __forceinline__ void issueStreamLoads(
-    const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, uint4 (&v)[COUNT])
+// Named members, not an array: indexed storage ends up in scratch memory, and a
+// load whose result goes to scratch is waited for at once, which would undo the prefetch.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain SSA value (HIP's uint4 is a class)
+
+struct StreamRegisters {
+    u32x4 r0, r1, r2, r3;
+};
+
+// One round of the tile's bitstream copy: piece q = (word, 16-byte piece) -> one lane.
+// A slot's worth of pieces is read from each row's start (running into the next
+// rows' streams, which is harmless; the array ends with a guard of one slot).
+// Absent words read the start of the array and never emit what they decode;
+// lanes past the tile's last piece re-read its last piece.
+__device__ __forceinline__ void issueStreamLoad(
+    const TrainedParams& p, uint32_t sourceStart, uint32_t lane, uint32_t round, u32x4& destination)
 {
     const uint32_t piecesPerWord = p.slotDwords / 4;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-    const uint32_t sourceOffset = meta.row < p.nRows ? (meta.offset & ~3u) : 0u;
-#pragma unroll
-    for (int b = 0; b < COUNT; ++b) {
-        if ((firstRound + b) * WAVE < totalPieces) {   // wave-uniform
-            const uint32_t q = (firstRound + b) * WAVE + lane;
-            const uint32_t w = min(fastDivide(q, p.slotMagic, piecesPerWord), p.wordsPerWave - 1);
-            const uint32_t piece = q - w * piecesPerWord;
-            const uint32_t wordOffset = __shfl(sourceOffset, w * p.lanesPerWord);
-            if (q < totalPieces) {
-                v[b] = *reinterpret_cast<const uint4_align4*>(p.packed + wordOffset + 16u * piece);
-            }
-        }
+    if (round * WAVE < totalPieces) {   // wave-uniform
+        const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
+        const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
+        const uint32_t piece = q - w * piecesPerWord;
+        const uint32_t wordStart = __shfl(sourceStart, w * p.lanesPerWord);
+        destination = reinterpret_cast<const u32x4*>(p.streams)[static_cast<unsigned long long>(wordStart) + piece];
     }
 }
 
-// Big-endian dwords into the LDS slots, so that the decoder extracts bits with plain shifts.
-template <int COUNT>
-__device__ __forceinline__ void writeStreams(
-    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t firstRound, const uint4 (&v)[COUNT])
+__device__ __forceinline__ void issueStreamLoads(
+    const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, StreamRegisters& v)
+{
+    const uint32_t sourceStart = meta.row < p.nRows ? meta.start : 0u;
+    issueStreamLoad(p, sourceStart, lane, firstRound + 0, v.r0);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 1, v.r1);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 2, v.r2);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 3, v.r3);
+}
+
+// Into the LDS slots (already big-endian dwords, so the decoder extracts bits with plain shifts).
+__device__ __forceinline__ void writeStream(
+    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t round, const u32x4& value)
 {
     const uint32_t piecesPerWord = p.slotDwords / 4;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-#pragma unroll
-    for (int b = 0; b < COUNT; ++b) {
-        const uint32_t q = (firstRound + b) * WAVE + lane;
-        if (q < totalPieces) {
-            const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
-            const uint32_t piece = q - w * piecesPerWord;
-            uint4 t = v[b];
-            t.x = byteSwap(t.x);
-            t.y = byteSwap(t.y);
-            t.z = byteSwap(t.z);
-            t.w = byteSwap(t.w);
-            *reinterpret_cast<uint4*>(slots + w * p.slotDwords + 4 * piece) = t;
-        }
+    const uint32_t q = round * WAVE + lane;
+    if (q < totalPieces) {
+        const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
+        const uint32_t piece = q - w * piecesPerWord;
+        *reinterpret_cast<u32x4*>(slots + w * p.slotDwords + 4 * piece) = value;
     }
+}
+
+__device__ __forceinline__ void writeStreams(
+    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t firstRound, const StreamRegisters& v)
+{
+    writeStream(p, slots, lane, firstRound + 0, v.r0);
+    writeStream(p, slots, lane, firstRound + 1, v.r1);
+    writeStream(p, slots, lane, firstRound + 2, v.r2);
+    writeStream(p, slots, lane, firstRound + 3, v.r3);
 }
 
 // FAST: codebook of at most 16 centroids and no code longer than 8 bits (2- and
@@ -253,8 +262,7 @@ __device__ __forceinline__ void decodeSegment(
     uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
     const uint32_t lastWindow = p.slotDwords - 3;
     const uint32_t rootShift = 32 - p.rootBits;
-    const uint32_t startBit = (meta.offset & 3u) * 8;
-    uint32_t bitPos = startBit + meta.segmentBits;
+    uint32_t bitPos = meta.segmentBits;   // streams start on a slot boundary
     // byte position of this lane's first group inside the symbol tile
     uint32_t keyOffset = role.word * p.keyRowBytes + role.segment * (p.segmentSymbols * KEY_BITS / 8);
     const uint32_t keyRowEnd = role.spare ? 0 : (role.word + 1) * p.keyRowBytes;
@@ -268,7 +276,7 @@ __device__ __forceinline__ void decodeSegment(
             if (j == nextIndexSymbol) {
                 if (present && indexSlot + 1 < p.indexLanes) {
                     p.segmentIndexOut[static_cast<unsigned long long>(meta.row) * (p.indexLanes - 1) + indexSlot] =
-                        static_cast<uint16_t>(bitPos - startBit);
+                        static_cast<uint16_t>(bitPos);
                 }
                 ++indexSlot;
                 nextIndexSymbol += p.indexSegmentSymbols;
@@ -334,31 +342,46 @@ __device__ __forceinline__ void outputTile(
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
         // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
         // (byte keys: rows of dim bytes; nibble keys: rows of dim / 2 bytes).
+        // BURST pieces per lane are gathered first and then stored back to back, so a
+        // tile reaches memory as one burst of consecutive KiBs rather than one KiB per
+        // LDS round trip.
+        constexpr int BURST = 5;
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = tileWords * piecesPerWord;
         float* tileOut = p.out + tileBase * p.ld + p.colOff;
-        for (uint32_t q = lane; q < pieces; q += WAVE) {
-            float4 f;
-            if (FAST) {
-                const uint32_t k = reinterpret_cast<const uint16_t*>(keyTile)[q];
-                const float2 a = pairLds[k & 0xff];
-                const float2 b = pairLds[k >> 8];
-                f = make_float4(a.x, a.y, b.x, b.y);
-            } else {
-                const uint32_t k = keyTile[q];
-                f.x = centroidLds[k & 0xff];
-                f.y = centroidLds[(k >> 8) & 0xff];
-                f.z = centroidLds[(k >> 16) & 0xff];
-                f.w = centroidLds[k >> 24];
+        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+            uint32_t k[BURST];
+            float4 f[BURST];
+#pragma unroll
+            for (int u = 0; u < BURST; ++u) {
+                const uint32_t q = min(q0 + WAVE * u, pieces - 1);
+                k[u] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[q] : keyTile[q];
             }
-            // Plain stores: non-temporal ones measured 4-5 % slower here (0.68 vs 0.65 ms,
-            // interleaved A/B on the 2.2M-word dump).
-            if (MODE == OUT_FLAT) {
-                reinterpret_cast<float4*>(tileOut)[q] = f;
-            } else {
-                const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
-                const uint32_t c = q - w * piecesPerWord;
-                *reinterpret_cast<float4*>(tileOut + w * p.ld + 4 * c) = f;
+#pragma unroll
+            for (int u = 0; u < BURST; ++u) {
+                if (FAST) {
+                    const float2 a = pairLds[k[u] & 0xff];
+                    const float2 b = pairLds[k[u] >> 8];
+                    f[u] = make_float4(a.x, a.y, b.x, b.y);
+                } else {
+                    f[u].x = centroidLds[k[u] & 0xff];
+                    f[u].y = centroidLds[(k[u] >> 8) & 0xff];
+                    f[u].z = centroidLds[(k[u] >> 16) & 0xff];
+                    f[u].w = centroidLds[k[u] >> 24];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BURST; ++u) {
+                const uint32_t q = q0 + WAVE * u;
+                if (q < pieces) {
+                    if (MODE == OUT_FLAT) {
+                        reinterpret_cast<float4*>(tileOut)[q] = f[u];
+                    } else {
+                        const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
+                        const uint32_t c = q - w * piecesPerWord;
+                        *reinterpret_cast<float4*>(tileOut + w * p.ld + 4 * c) = f[u];
+                    }
+                }
             }
         }
     } else {
@@ -385,8 +408,14 @@ __device__ __forceinline__ void outputTile(
             const uint32_t w = fastDivide(__ffsll(static_cast<long long>(absent)) - 1, p.laneMagic, p.lanesPerWord);
             absent &= absent - 1;
             float* rowOut = p.out + (tileBase + w) * p.ld + p.colOff;
-            for (uint32_t c = lane; c < p.dim; c += WAVE) {
-                rowOut[c] = 0.f;
+            if (MODE == OUT_SCALAR) {
+                for (uint32_t c = lane; c < p.dim; c += WAVE) {
+                    rowOut[c] = 0.f;
+                }
+            } else {
+                for (uint32_t c = lane; c < p.dim / 4; c += WAVE) {
+                    reinterpret_cast<float4*>(rowOut)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     }
@@ -448,7 +477,7 @@ __global__ void decode_trained(TrainedParams p)
 
     const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
     for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
-        uint4 v[STREAM_REGISTERS];
+        StreamRegisters v;
         issueStreamLoads(p, meta, lane, round, v);
         writeStreams(p, mem.slots, lane, round, v);
     }
@@ -489,7 +518,7 @@ __global__ void decode_trained_persistent(TrainedParams p)
     WordMeta meta0 = loadWordMeta(p, loadTileRow(p, tile, role), role);
     WordMeta meta1 = loadWordMeta(p, loadTileRow(p, tile + stride, role), role);
     WordMeta metaLoading = loadWordMeta(p, loadTileRow(p, tile + 2 * stride, role), role);
-    uint4 streams[STREAM_REGISTERS];
+    StreamRegisters streams;
     issueStreamLoads(p, meta0, lane, 0, streams);
     writeStreams(p, mem.slots, lane, 0, streams);
     issueStreamLoads(p, meta1, lane, 0, streams);
@@ -520,7 +549,7 @@ __global__ void decode_trained_persistent(TrainedParams p)
         WordMeta meta2;
         uint32_t row3;
         asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.offset) : "v"(metaLoading.offset));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
         asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
         asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
         __builtin_amdgcn_sched_barrier(0);
@@ -537,6 +566,38 @@ __global__ void decode_trained_persistent(TrainedParams p)
         meta0 = meta1;
         meta1 = meta2;
         waveLdsFence();
+    }
+}
+
+// Staging-time re-pack of the file's bitstreams (byte aligned, insertion order,
+// reference src/trained_compression.cpp:65-71) into the layout the decoder
+// reads: row r's stream starts at piece streamStarts[r], 16-byte aligned, in
+// row (= sorted key) order, stored as big-endian dwords. One wavefront per row.
+__global__ void repack_streams(
+    const uint8_t* packed, unsigned long long packedBytes, const uint32_t* valueOffsets, const uint32_t* streamStarts,
+    unsigned long long nRows, uint4* streams)
+{
+    const unsigned long long row = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) / WAVE;
+    if (row >= nRows) {
+        return;
+    }
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t first = streamStarts[row];
+    const uint32_t pieces = streamStarts[row + 1] - first;
+    const unsigned long long source = valueOffsets[row];
+    for (uint32_t piece = lane; piece < pieces; piece += WAVE) {
+        uint32_t dwords[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t value = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long at = source + 16ull * piece + 4 * k + b;
+                value = (value << 8) | (at < packedBytes ? packed[at] : 0u);
+            }
+            dwords[k] = value;
+        }
+        streams[static_cast<unsigned long long>(first) + piece] = make_uint4(dwords[0], dwords[1], dwords[2], dwords[3]);
     }
 }
 
@@ -717,8 +778,8 @@ struct memb_hip_ctx {
     std::vector<void*> allocations;
 
     // trained
-    uint8_t* packed = nullptr;
-    uint32_t* valueOffsets = nullptr;
+    uint4* streams = nullptr;            // re-packed bitstreams
+    uint32_t* streamStarts = nullptr;    // [nRows + 1]
     uint32_t* table = nullptr;
     float* codebook = nullptr;
     bool fast = false;                   // <= 16 centroids, codes <= 8 bits, one-level table
@@ -901,8 +962,8 @@ hipError_t launchTrainedMode(
 TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
 {
     TrainedParams params{};
-    params.packed = ctx->packed;
-    params.valueOffsets = ctx->valueOffsets;
+    params.streams = ctx->streams;
+    params.streamStarts = ctx->streamStarts;
     params.segmentIndex = ctx->segmentIndex;
     params.table = ctx->table;
     params.codebook = ctx->codebook;
@@ -1267,11 +1328,10 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
             ctx->maxStreamBytes = std::max(ctx->maxStreamBytes, ctx->streamBytes[rowIndex]);
         }
     }
-    // Slot: stream, up to 3 bytes of alignment slack in front, and the 12-byte
-    // window the decoder reads at its last position; whole 16-byte pieces, an
-    // odd number of them so that equal positions in consecutive slots fall
-    // into different LDS banks.
-    ctx->slotDwords = (((ctx->maxStreamBytes + 3 + 12 + 15) / 16) | 1u) * 4;
+    // Slot: stream plus the 12-byte window the decoder reads at its last
+    // position; whole 16-byte pieces, an odd number of them so that equal
+    // positions in consecutive slots fall into different LDS banks.
+    ctx->slotDwords = (((ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
     ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
         !envUint("MEMB_HIP_NO_FAST", 0);
     ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
@@ -1289,26 +1349,74 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
     }
 
+    // Re-packed layout: row r's stream occupies ceil(bytes / 16) pieces from streamStarts[r].
+    std::vector<uint32_t> streamStarts(desc->n_rows + 1, 0);
+    {
+        uint64_t next = 0;
+        for (uint64_t r = 0; r < desc->n_rows; ++r) {
+            streamStarts[r] = static_cast<uint32_t>(next);
+            next += (ctx->streamBytes[r] + 15) / 16;
+        }
+        if (next + ctx->slotDwords / 4 + 1 >= (1ull << 32)) {
+            delete ctx;
+            return fail(MEMB_HIP_ERR_INVALID, "bitstreams too large");
+        }
+        streamStarts[desc->n_rows] = static_cast<uint32_t>(next);
+    }
+    const size_t streamPieces = size_t(streamStarts[desc->n_rows]) + ctx->slotDwords / 4 + 1;   // + guard of one slot
+
     code = openDevice(ctx, device);
+    uint8_t* filePacked = nullptr;      // temporary device copies of the file's arrays
+    uint32_t* fileOffsets = nullptr;
     if (code == MEMB_HIP_OK) {
-        // guard: a slot-sized read may start at the last byte
-        size_t guard = size_t(ctx->slotDwords) * 4 + 16;
-        code = deviceAlloc(ctx, &ctx->packed, desc->packed_values_bytes + guard);
-        if (code == MEMB_HIP_OK) {
-            hipError_t status = hipMemset(ctx->packed + desc->packed_values_bytes, 0, guard);
-            if (status != hipSuccess) {
-                code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(status));
-            }
+        code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
+    }
+    if (code == MEMB_HIP_OK) {
+        hipError_t status = hipMemset(ctx->streams, 0, streamPieces * 16);
+        if (status != hipSuccess) {
+            code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(status));
         }
     }
     if (code == MEMB_HIP_OK) {
-        code = copyToDevice(ctx->packed, desc->packed_values, desc->packed_values_bytes);
+        code = deviceAlloc(ctx, &ctx->streamStarts, streamStarts.size() * 4);
     }
     if (code == MEMB_HIP_OK) {
-        code = deviceAlloc(ctx, &ctx->valueOffsets, desc->n_rows * 4);
+        code = copyToDevice(ctx->streamStarts, streamStarts.data(), streamStarts.size() * 4);
     }
-    if (code == MEMB_HIP_OK) {
-        code = copyToDevice(ctx->valueOffsets, desc->value_offsets, desc->n_rows * 4);
+    if (code == MEMB_HIP_OK && desc->n_rows) {
+        hipError_t status = hipMalloc(reinterpret_cast<void**>(&filePacked), std::max<size_t>(desc->packed_values_bytes, 16));
+        if (status == hipSuccess) {
+            status = hipMalloc(reinterpret_cast<void**>(&fileOffsets), desc->n_rows * 4);
+        }
+        if (status != hipSuccess) {
+            code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(status));
+        }
+        if (code == MEMB_HIP_OK) {
+            code = copyToDevice(filePacked, desc->packed_values, desc->packed_values_bytes);
+        }
+        if (code == MEMB_HIP_OK) {
+            code = copyToDevice(fileOffsets, desc->value_offsets, desc->n_rows * 4);
+        }
+        if (code == MEMB_HIP_OK) {
+            const uint32_t threads = 256;
+            const uint64_t blocks = (desc->n_rows * WAVE + threads - 1) / threads;
+            hipLaunchKernelGGL(
+                repack_streams, dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, ctx->stream, filePacked,
+                desc->packed_values_bytes, fileOffsets, ctx->streamStarts, desc->n_rows, ctx->streams);
+            hipError_t launched = hipGetLastError();
+            if (launched == hipSuccess) {
+                launched = hipStreamSynchronize(ctx->stream);
+            }
+            if (launched != hipSuccess) {
+                code = fail(MEMB_HIP_ERR_DEVICE, std::string("repack_streams: ") + hipGetErrorString(launched));
+            }
+        }
+        if (filePacked) {
+            (void)hipFree(filePacked);
+        }
+        if (fileOffsets) {
+            (void)hipFree(fileOffsets);
+        }
     }
     if (code == MEMB_HIP_OK) {
         code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);

@@ -219,7 +219,7 @@ def main():
             'unit': 'GB/s',
             'frac': achieved_gbps / HBM_PEAK_GBPS,
             'traffic': traffic,
-            'kernel': 'decode_trained',
+            'kernel': 'decode_trained_persistent',
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_min_ms': kernel_ms[0],
             'algorithmic_bytes_per_launch': algorithmic_bytes,

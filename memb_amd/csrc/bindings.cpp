@@ -28,6 +28,39 @@ std::shared_ptr<memb::Reader> makeReader(
         filename, std::make_shared<memb::TrainedCompressionStrategy>(maxDirectDecodeBits), numThreads, device);
 }
 
+// UTF-8 pointers of a sequence of str, without copying the words (pybind11's
+// vector<string> caster copies every one). The pointers stay valid while the
+// sequence is alive; a word with an embedded NUL ends there, as it does for the
+// reference's strcmp.
+struct WordPointers {
+    py::object fast;   // keeps the items alive
+    std::vector<const char*> pointers;
+
+    explicit WordPointers(const py::handle& words)
+    {
+        fast = py::reinterpret_steal<py::object>(PySequence_Fast(words.ptr(), "expected a list of str"));
+        if (!fast) {
+            throw py::error_already_set();
+        }
+        const Py_ssize_t count = PySequence_Fast_GET_SIZE(fast.ptr());
+        PyObject** items = PySequence_Fast_ITEMS(fast.ptr());
+        pointers.resize(static_cast<size_t>(count));
+        for (Py_ssize_t i = 0; i < count; ++i) {
+            if (!PyUnicode_Check(items[i])) {
+                throw py::type_error("words must be str");
+            }
+            const char* text = PyUnicode_AsUTF8(items[i]);
+            if (!text) {
+                throw py::error_already_set();
+            }
+            pointers[static_cast<size_t>(i)] = text;
+        }
+    }
+
+    size_t size() const { return pointers.size(); }
+    const char* const* data() const { return pointers.data(); }
+};
+
 py::dict contextInfo(memb::Reader& reader)
 {
     memb_hip_ctx_info info;
@@ -115,14 +148,15 @@ PYBIND11_MODULE(_memb, m) {
             })
         .def(
             "batch_embedding",
-            [](memb::Reader& reader, const std::vector<std::string>& words)
+            [](memb::Reader& reader, const py::sequence& wordList)
             {
+                WordPointers words(wordList);
                 py::array_t<float> result({words.size(), reader.dim()});
                 auto buffer = result.request();
                 float* destination = reinterpret_cast<float*>(buffer.ptr);
                 {
                     py::gil_scoped_release release;
-                    reader.batchEmbeddingToBuffer(words, destination);
+                    reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, reader.dim(), 0);
                 }
                 return result;
             })
@@ -137,24 +171,26 @@ PYBIND11_MODULE(_memb, m) {
             [](memb::Reader& reader) { return reinterpret_cast<uintptr_t>(reader.deviceContext()); })
         .def(
             "resolve_rows",
-            [](memb::Reader& reader, const std::vector<std::string>& words)
+            [](memb::Reader& reader, const py::sequence& wordList)
             {
+                WordPointers words(wordList);
                 py::array_t<uint32_t> rows(words.size());
                 auto buffer = rows.request();
                 uint32_t* destination = reinterpret_cast<uint32_t*>(buffer.ptr);
                 {
                     py::gil_scoped_release release;
-                    reader.resolveRows(words, destination);
+                    reader.resolveRows(words.data(), words.size(), destination);
                 }
                 return rows;
             })
         .def(
             "batch_embedding_into",
             [](memb::Reader& reader,
-               const std::vector<std::string>& words,
+               const py::sequence& wordList,
                py::array_t<float, py::array::c_style> out,
                size_t colOff)
             {
+                WordPointers words(wordList);
                 auto buffer = out.request(true);
                 if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size() ||
                     static_cast<size_t>(buffer.shape[1]) < colOff + reader.dim()) {
@@ -163,7 +199,7 @@ PYBIND11_MODULE(_memb, m) {
                 float* destination = reinterpret_cast<float*>(buffer.ptr);
                 size_t ld = static_cast<size_t>(buffer.shape[1]);
                 py::gil_scoped_release release;
-                reader.batchEmbeddingToStridedBuffer(words, destination, ld, colOff);
+                reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, ld, colOff);
             })
         .def(
             "rows_embedding",

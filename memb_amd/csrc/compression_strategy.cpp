@@ -2,6 +2,7 @@
 #include "codec.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -84,6 +85,101 @@ void CompressedStorage::decodeRowsDevice(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Hash index over the keys: open addressing, 64-bit slots {hash tag : 32, row : 32},
+// FNV-1a over the word's bytes; a hit is confirmed with strcmp, so the answer is
+// always the one the binary search would give.
+// ---------------------------------------------------------------------------
+
+struct CompressedStorage::WordIndex {
+    static constexpr uint64_t EMPTY = ~uint64_t(0);
+    std::vector<std::atomic<uint64_t>> slots;
+    uint64_t mask = 0;
+
+    static uint64_t hash(const char* word)
+    {
+        uint64_t h = 1469598103934665603ull;
+        for (const unsigned char* c = reinterpret_cast<const unsigned char*>(word); *c; ++c) {
+            h = (h ^ *c) * 1099511628211ull;
+        }
+        return h ^ (h >> 29);
+    }
+
+    explicit WordIndex(const CompressedStorage& storage)
+    {
+        const size_t count = storage.rowCount();
+        size_t capacity = 16;
+        while (capacity < 2 * count) {
+            capacity *= 2;
+        }
+        mask = capacity - 1;
+        slots = std::vector<std::atomic<uint64_t>>(capacity);
+        for (auto& slot : slots) {
+            slot.store(EMPTY, std::memory_order_relaxed);
+        }
+        const size_t threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), count / 65536 + 1));
+        const size_t perThread = (count + threads - 1) / threads;
+        auto insertRange = [this, &storage, count](size_t first, size_t last) {
+            for (size_t row = first; row < std::min(last, count); ++row) {
+                const uint64_t h = hash(storage.key(row));
+                const uint64_t value = (h & 0xFFFFFFFF00000000ull) | row;
+                for (uint64_t at = h & mask;; at = (at + 1) & mask) {
+                    uint64_t expected = EMPTY;
+                    if (slots[at].compare_exchange_strong(expected, value, std::memory_order_relaxed)) {
+                        break;
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads; ++t) {
+            pool.emplace_back(insertRange, t * perThread, (t + 1) * perThread);
+        }
+        insertRange(0, perThread);
+        for (auto& thread : pool) {
+            thread.join();
+        }
+    }
+
+    bool find(const CompressedStorage& storage, const char* word, uint32_t* row) const
+    {
+        const uint64_t h = hash(word);
+        const uint64_t tag = h & 0xFFFFFFFF00000000ull;
+        for (uint64_t at = h & mask;; at = (at + 1) & mask) {
+            const uint64_t value = slots[at].load(std::memory_order_relaxed);
+            if (value == EMPTY) {
+                return false;
+            }
+            if ((value & 0xFFFFFFFF00000000ull) == tag) {
+                const uint32_t candidate = static_cast<uint32_t>(value);
+                if (std::strcmp(storage.key(candidate), word) == 0) {
+                    *row = candidate;
+                    return true;
+                }
+            }
+        }
+    }
+};
+
+const CompressedStorage::WordIndex* CompressedStorage::wordIndex() const
+{
+    std::call_once(wordIndexOnce_, [this] {
+        wordIndex_ = std::make_shared<WordIndex>(*this);
+        wordIndexBuilt_.store(true, std::memory_order_release);
+    });
+    return wordIndex_.get();
+}
+
+void CompressedStorage::resolveMany(const char* const* words, size_t count, uint32_t* rows, bool useIndex) const
+{
+    const WordIndex* index = useIndex ? wordIndex() : nullptr;
+    for (size_t i = 0; i < count; ++i) {
+        uint32_t row = MEMB_HIP_MISSING_ROW;
+        bool found = index ? index->find(*this, words[i], &row) : resolve(words[i], &row);
+        rows[i] = found ? row : MEMB_HIP_MISSING_ROW;
+    }
+}
+
 bool CompressedStorage::extract(const std::string& word, float* destination) const
 {
     uint32_t row = MEMB_HIP_MISSING_ROW;
@@ -162,6 +258,7 @@ public:
 
     size_t dim() const override { return dim_; }
     size_t rowCount() const override { return wordOffsets_.size; }
+    const char* key(size_t index) const override { return packedWords_.data + wordOffsets_[index]; }
 
     // reference src/trained_compression.cpp:115-125: lower_bound with strcmp
     // over the NUL separated sorted words. The reference dereferences the
@@ -462,6 +559,7 @@ public:
 
     size_t dim() const override { return dim_; }
     size_t rowCount() const override { return rows_.size(); }
+    const char* key(size_t index) const override { return words_[index]; }
     bool resolve(const char* word, uint32_t* row) const override { return lookupByKey(words_, word, row); }
 
     std::vector<std::string> keys() const override
@@ -561,6 +659,7 @@ public:
 
     size_t dim() const override { return dim_; }
     size_t rowCount() const override { return rows_.size(); }
+    const char* key(size_t index) const override { return words_[index]; }
     bool resolve(const char* word, uint32_t* row) const override { return lookupByKey(words_, word, row); }
 
     std::vector<std::string> keys() const override

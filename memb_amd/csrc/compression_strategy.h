@@ -13,6 +13,7 @@
 #include "wire.h"
 #include "../../include/memb_hip.h"
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -34,6 +35,16 @@ public:
     // Row id (position in sorted key order) of `word`, false if absent.
     virtual bool resolve(const char* word, uint32_t* row) const = 0;
 
+    // The i-th key (sorted order), NUL terminated, valid while the storage lives.
+    virtual const char* key(size_t index) const = 0;
+
+    // rows[i] = row id of words[i] or MEMB_HIP_MISSING_ROW. With useIndex the
+    // lookups go through a hash index over the keys that is built on first use
+    // (thread safe; the per-word binary search of `resolve` costs ~21 dependent
+    // cache misses on a 2.2 M-word vocabulary); results are identical.
+    void resolveMany(const char* const* words, size_t count, uint32_t* rows, bool useIndex) const;
+    bool hasWordIndex() const { return wordIndexBuilt_.load(std::memory_order_acquire); }
+
     // Decode rows[0..n) into out[i * ld + colOff ..], host buffers.
     void decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
     // Same with device buffers, enqueued on `stream` (hipStream_t, may be null).
@@ -49,9 +60,15 @@ protected:
     virtual memb_hip_ctx* createDeviceContext(int device) const = 0;
 
 private:
+    struct WordIndex;
+    const WordIndex* wordIndex() const;
+
     int device_ = 0;
     mutable std::mutex contextMutex_;
     mutable memb_hip_ctx* context_ = nullptr;
+    mutable std::once_flag wordIndexOnce_;
+    mutable std::shared_ptr<WordIndex> wordIndex_;
+    mutable std::atomic<bool> wordIndexBuilt_{false};
 };
 
 class Compressor {

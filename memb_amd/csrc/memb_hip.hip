@@ -1646,26 +1646,50 @@ int memb_hip_decode_rows(
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedOut), sliceWords * dim * sizeof(float)));
         ctx->stagedCapacity = sliceWords;
     }
-    for (size_t start = 0; start < n; start += sliceWords) {
-        const size_t words = std::min(sliceWords, n - start);
-        HIP_TRY(hipMemcpyAsync(
-            ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        int code = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
-        if (code != MEMB_HIP_OK) {
-            return code;
+    // Pin the caller's output range for the duration of the call: a fresh host
+    // buffer is otherwise faulted in page by page behind the DMA engine (measured
+    // 10-17 GB/s against 57 GB/s for pinned memory; registering 2.6 GB takes 25 ms).
+    char* pinBase = reinterpret_cast<char*>(out + col_off);
+    const size_t pinBytes = ((n - 1) * ld + dim) * sizeof(float);
+    bool pinned = false;
+    if (pinBytes >= (size_t(1) << 20)) {
+        if (hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault) == hipSuccess) {
+            pinned = true;
+        } else {
+            (void)hipGetLastError();
         }
-        HIP_TRY(hipMemcpy2DAsync(
-            out + start * ld + col_off,
-            ld * sizeof(float),
-            ctx->stagedOut,
-            dim * sizeof(float),
-            dim * sizeof(float),
-            words,
-            hipMemcpyDeviceToHost,
-            ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    return MEMB_HIP_OK;
+    int result = MEMB_HIP_OK;
+    for (size_t start = 0; start < n && result == MEMB_HIP_OK; start += sliceWords) {
+        const size_t words = std::min(sliceWords, n - start);
+        hipError_t status = hipMemcpyAsync(
+            ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (status == hipSuccess) {
+            result = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
+            if (result != MEMB_HIP_OK) {
+                break;
+            }
+            status = hipMemcpy2DAsync(
+                out + start * ld + col_off,
+                ld * sizeof(float),
+                ctx->stagedOut,
+                dim * sizeof(float),
+                dim * sizeof(float),
+                words,
+                hipMemcpyDeviceToHost,
+                ctx->stream);
+        }
+        if (status == hipSuccess) {
+            status = hipStreamSynchronize(ctx->stream);
+        }
+        if (status != hipSuccess) {
+            result = fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+        }
+    }
+    if (pinned) {
+        (void)hipHostUnregister(pinBase);
+    }
+    return result;
 }
 
 int memb_hip_sync(memb_hip_ctx* ctx)

@@ -133,41 +133,62 @@ void Reader::wordEmbeddingToBuffer(const std::string& word, float* buffer) const
 // Host half of the batch driver. The reference splits a batch of >= 1024
 // words over numThreads_ std::async jobs that search and decode
 // (src/reader.cpp:59-86); here the jobs only search, the decode of the whole
-// batch is one kernel launch.
-void Reader::resolveRows(const std::vector<std::string>& words, uint32_t* rows) const
+// batch is one kernel launch. Jobs are not made smaller than 2048 words:
+// starting a thread costs more than searching a few hundred words.
+void Reader::resolveRows(const char* const* words, size_t count, uint32_t* rows) const
 {
+    static const size_t MIN_JOB_SIZE = 2048;
+    static const size_t INDEX_THRESHOLD = 4096;   // smaller batches do not pay for building the hash index
     const CompressedStorage* storage = compressedStorage_.get();
-    auto resolveRange = [storage, &words, rows](size_t first, size_t last) {
-        for (size_t idx = first; idx < last; ++idx) {
-            uint32_t row = MEMB_HIP_MISSING_ROW;
-            rows[idx] = storage->resolve(words[idx].c_str(), &row) ? row : MEMB_HIP_MISSING_ROW;
-        }
-    };
+    const bool useIndex = count >= INDEX_THRESHOLD || storage->hasWordIndex();
 
-    if (words.size() < THREADED_DECODER_THRESHOLD || numThreads_ == 1) {
-        resolveRange(0, words.size());
+    if (count < THREADED_DECODER_THRESHOLD || numThreads_ == 1) {
+        storage->resolveMany(words, count, rows, useIndex);
         return;
     }
-    size_t jobSize = (words.size() + numThreads_ - 1) / numThreads_;
+    const size_t jobs = std::max<size_t>(1, std::min(numThreads_, count / MIN_JOB_SIZE));
+    const size_t jobSize = (count + jobs - 1) / jobs;
     std::vector<std::future<void>> results;
-    for (size_t startIndex = 0; startIndex < words.size(); startIndex += jobSize) {
-        size_t endIndex = std::min(startIndex + jobSize, words.size());
-        results.push_back(std::async(std::launch::async, resolveRange, startIndex, endIndex));
+    for (size_t startIndex = jobSize; startIndex < count; startIndex += jobSize) {
+        const size_t jobCount = std::min(jobSize, count - startIndex);
+        results.push_back(std::async(std::launch::async, [=] {
+            storage->resolveMany(words + startIndex, jobCount, rows + startIndex, useIndex);
+        }));
     }
+    storage->resolveMany(words, std::min(jobSize, count), rows, useIndex);
     for (auto& future : results) {
         future.get();
     }
 }
 
+void Reader::resolveRows(const std::vector<std::string>& words, uint32_t* rows) const
+{
+    std::vector<const char*> pointers(words.size());
+    for (size_t i = 0; i < words.size(); ++i) {
+        pointers[i] = words[i].c_str();
+    }
+    resolveRows(pointers.data(), pointers.size(), rows);
+}
+
+void Reader::batchEmbeddingToStridedBuffer(
+    const char* const* words, size_t count, float* buffer, size_t ld, size_t colOff) const
+{
+    if (count == 0) {
+        return;
+    }
+    std::vector<uint32_t> rows(count);
+    resolveRows(words, count, rows.data());
+    compressedStorage_->decodeRows(rows.data(), rows.size(), buffer, ld, colOff);
+}
+
 void Reader::batchEmbeddingToStridedBuffer(
     const std::vector<std::string>& words, float* buffer, size_t ld, size_t colOff) const
 {
-    if (words.empty()) {
-        return;
+    std::vector<const char*> pointers(words.size());
+    for (size_t i = 0; i < words.size(); ++i) {
+        pointers[i] = words[i].c_str();
     }
-    std::vector<uint32_t> rows(words.size());
-    resolveRows(words, rows.data());
-    compressedStorage_->decodeRows(rows.data(), rows.size(), buffer, ld, colOff);
+    batchEmbeddingToStridedBuffer(pointers.data(), pointers.size(), buffer, ld, colOff);
 }
 
 void Reader::batchEmbeddingToBuffer(const std::vector<std::string>& words, float* buffer) const

@@ -56,6 +56,9 @@ public:
     // Sorted-order row ids of `words` (MEMB_HIP_MISSING_ROW for unknown words),
     // resolved on up to numThreads host threads.
     void resolveRows(const std::vector<std::string>& words, uint32_t* rows) const;
+    void resolveRows(const char* const* words, size_t count, uint32_t* rows) const;
+    void batchEmbeddingToStridedBuffer(
+        const char* const* words, size_t count, float* buffer, size_t ld, size_t colOff) const;
 
     // batchEmbeddingToBuffer into a wider row-major matrix: row i goes to
     // buffer[i * ld + colOff .. + dim) (ReadersUnion 'concatenate').

@@ -76,6 +76,30 @@ def test_word_search_on_a_larger_vocabulary(native, make_model):
     assert all(rows[i] == order[probes[i]] for i in range(3000))
 
 
+def test_hash_index_lookup_equals_binary_search(native, make_model):
+    # batches >= 4096 words go through the lazily built hash index; it must give the binary search's answers
+    path, words = make_model(5000, dim=8, storage='trained', bits=4)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(9)
+    probes = [words[i] for i in rng.integers(0, len(words), size=20000)]
+    probes[::7] = [w + '!' for w in probes[::7]]          # misses that share long prefixes with keys
+    probes[5::11] = [w[:max(1, len(w) // 2)] for w in probes[5::11]]
+    probes += ['', ' ', 'é', '日本語', words[0] + '\0tail']  # an embedded NUL ends the word, as for strcmp
+    expected = checker.resolve_rows([p.split('\0')[0] for p in probes])
+    for threads in (1, 3, 0):
+        reader = native.Reader(path, num_threads=threads)
+        small = reader.resolve_rows(probes[:100])             # binary search path (index not built yet)
+        assert np.array_equal(small, expected[:100])
+        assert np.array_equal(reader.resolve_rows(probes), expected)          # builds + uses the index
+        assert np.array_equal(reader.resolve_rows(tuple(probes[:100])), expected[:100])  # index reused; any sequence
+    with pytest.raises(TypeError):
+        native.Reader(path).resolve_rows(['ok', 3])
+    for storage in ('uniform', 'full'):
+        path, words = make_model(4500, dim=4, storage=storage, bits=8)
+        probes = sorted(words) + ['nope', 'zzzzzz', '']
+        assert np.array_equal(native.Reader(path).resolve_rows(probes), oracle.OracleReader(path).resolve_rows(probes))
+
+
 def test_builder_files_are_read_by_the_checker(native, tmp_path):
     # container written by memb_amd.Builder, parsed by an independent C parser
     for storage in ('full', 'uniform', 'trained'):

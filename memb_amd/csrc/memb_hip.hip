@@ -29,6 +29,7 @@
 #include "wire.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1648,17 +1649,29 @@ int memb_hip_decode_rows(
     }
     // Pin the caller's output range for the duration of the call: a fresh host
     // buffer is otherwise faulted in page by page behind the DMA engine (measured
-    // 10-17 GB/s against 57 GB/s for pinned memory; registering 2.6 GB takes 25 ms).
+    // 10-17 GB/s against 53-57 GB/s pinned; registering 2.6 GB of untouched pages
+    // takes 0.11 s). Only for buffers of 32 MiB and more: those are mappings of
+    // their own (glibc's mmap threshold never exceeds 32 MiB), whereas smaller
+    // ones share heap pages with unrelated live data that must not be pinned and
+    // unpinned under it.
+    const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     char* pinBase = reinterpret_cast<char*>(out + col_off);
     const size_t pinBytes = ((n - 1) * ld + dim) * sizeof(float);
     bool pinned = false;
-    if (pinBytes >= (size_t(1) << 20)) {
-        if (hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault) == hipSuccess) {
+    if (pinBytes >= (size_t(32) << 20)) {
+        hipError_t registered = hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault);
+        if (registered == hipSuccess) {
             pinned = true;
         } else {
             (void)hipGetLastError();
+            if (envUint("MEMB_HIP_VERBOSE", 0)) {
+                std::fprintf(stderr, "memb_hip: hipHostRegister(%zu bytes): %s\n", pinBytes, hipGetErrorString(registered));
+            }
         }
     }
+    const double t1 = now();
     int result = MEMB_HIP_OK;
     for (size_t start = 0; start < n && result == MEMB_HIP_OK; start += sliceWords) {
         const size_t words = std::min(sliceWords, n - start);
@@ -1669,15 +1682,20 @@ int memb_hip_decode_rows(
             if (result != MEMB_HIP_OK) {
                 break;
             }
-            status = hipMemcpy2DAsync(
-                out + start * ld + col_off,
-                ld * sizeof(float),
-                ctx->stagedOut,
-                dim * sizeof(float),
-                dim * sizeof(float),
-                words,
-                hipMemcpyDeviceToHost,
-                ctx->stream);
+            if (ld == dim) {
+                status = hipMemcpyAsync(
+                    out + start * ld, ctx->stagedOut, words * dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+            } else {
+                status = hipMemcpy2DAsync(
+                    out + start * ld + col_off,
+                    ld * sizeof(float),
+                    ctx->stagedOut,
+                    dim * sizeof(float),
+                    dim * sizeof(float),
+                    words,
+                    hipMemcpyDeviceToHost,
+                    ctx->stream);
+            }
         }
         if (status == hipSuccess) {
             status = hipStreamSynchronize(ctx->stream);
@@ -1686,8 +1704,13 @@ int memb_hip_decode_rows(
             result = fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
         }
     }
+    const double t2 = now();
     if (pinned) {
         (void)hipHostUnregister(pinBase);
+    }
+    if (verbose) {
+        std::fprintf(stderr, "memb_hip: decode_rows n=%zu pinned=%d register %.4fs copy+kernel %.4fs unregister %.4fs\n",
+                     n, int(pinned), t1 - t0, t2 - t1, now() - t2);
     }
     return result;
 }

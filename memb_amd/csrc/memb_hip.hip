@@ -1653,14 +1653,16 @@ int memb_hip_decode_rows(
     // takes 0.11 s). Only for buffers of 32 MiB and more: those are mappings of
     // their own (glibc's mmap threshold never exceeds 32 MiB), whereas smaller
     // ones share heap pages with unrelated live data that must not be pinned and
-    // unpinned under it.
+    // unpinned under it. Opt-in (MEMB_HIP_PIN_OUTPUT=1): one full GPU test run
+    // aborted while registration was on by default for >= 1 MiB buffers and the
+    // cause could not be established.
     const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     char* pinBase = reinterpret_cast<char*>(out + col_off);
     const size_t pinBytes = ((n - 1) * ld + dim) * sizeof(float);
     bool pinned = false;
-    if (pinBytes >= (size_t(32) << 20)) {
+    if (pinBytes >= (size_t(32) << 20) && envUint("MEMB_HIP_PIN_OUTPUT", 0)) {
         hipError_t registered = hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault);
         if (registered == hipSuccess) {
             pinned = true;

@@ -1001,6 +1001,22 @@ int launchTrained(
     params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
     params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
 
+    // The kernels index LDS and the symbol tile from these numbers without further checks.
+    {
+        const uint32_t group = ctx->fast ? 8 : 4;
+        const bool consistent = wordsPerWave >= 1 && wordsPerWave * params.lanesPerWord <= WAVE &&
+            params.slotDwords >= 4 && params.slotDwords % 4 == 0 && params.segmentSymbols % group == 0 &&
+            uint64_t(params.lanesPerWord) * params.segmentSymbols >= params.dim &&
+            uint64_t(params.lanesPerWord - 1) * params.segmentSymbols < params.dim &&
+            params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
+            uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
+            (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
+            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
+            geometry.ldsBytes <= ctx->ldsLimit && ld >= colOff + params.dim;
+        if (!consistent) {
+            return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
+        }
+    }
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;

@@ -55,9 +55,9 @@ def cpu_baseline(path, rows_host, dim):
     sample = rows_host
     out = np.empty((len(sample), dim), dtype=np.float32)
     best = float('inf')
-    deadline = time.time() + 20.0
+    deadline = time.time() + 6.0
     passes = 0
-    while passes < 3 and time.time() < deadline:
+    while passes < 3 or time.time() < deadline:
         start = time.time()
         reader.rows_embedding(sample, out=out, num_threads=cores)
         best = min(best, time.time() - start)
@@ -71,7 +71,7 @@ def cpu_baseline(path, rows_host, dim):
         'unit': 'embeddings/s',
         'cores': cores,
         'kind': 'port',
-        'sample': '{} pre-resolved rows of the same batch, decode only, best of {} passes; single thread: {:.0f} embeddings/s on {} rows'.format(
+        'sample': '{} pre-resolved rows of the same batch, decode only, all host threads, best of {} passes (~6 s); single thread: {:.0f} embeddings/s on {} rows'.format(
             len(sample), passes, single_rate, len(single)),
     }, out
 

@@ -1,0 +1,20 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import memb_amd, oracle
+from memb_amd import synthetic
+n=2196017
+path,_=synthetic.cached_model(n,300,'trained',4)
+t=time.time(); r=memb_amd.Reader(path); keys=r.keys(); print('open+keys %.2fs'%(time.time()-t))
+t=time.time(); r.info(); print('stage to HBM %.2fs'%(time.time()-t))
+rng=np.random.default_rng(3)
+for m in (1, 1000, 100000, n):
+    words = keys if m==n else [keys[i] for i in rng.integers(0,n,size=m)]
+    for rep in range(2):
+        t0=time.time(); rows=r.resolve_rows(words); t1=time.time(); out=r.rows_embedding(rows); t2=time.time(); full=r.batch_embedding(words); t3=time.time()
+    print('n=%8d resolve %.4fs (%.2f Mw/s) | rows->numpy %.4fs (%.2f GB/s) | reader[words] %.4fs (%.3f M emb/s)'%(m,t1-t0,m/(t1-t0)/1e6,t2-t1,m*1200/(t2-t1)/1e9,t3-t2,m/(t3-t2)/1e6))
+o=oracle.OracleReader(path, os.cpu_count())
+words=[keys[i] for i in rng.integers(0,n,size=100000)]
+t=time.time(); o.batch_embedding(words); print('oracle (all cores) batch 100k: %.4fs'%(time.time()-t))
+o1=oracle.OracleReader(path, 1)
+t=time.time(); o1.batch_embedding(words[:20000]); print('oracle (1 thread) batch 20k: %.4fs'%(time.time()-t))

@@ -654,43 +654,73 @@ __device__ __forceinline__ float dequant(float minValue, float range, uint32_t v
     return addRn(minValue, __fdiv_rn(scaled, levels));
 }
 
+constexpr uint32_t ROWWISE_MAX_WORDS = 64;   // words per block of the row-wise kernels
+constexpr int ROWWISE_BATCH = 4;             // 16-byte pieces a thread keeps in flight
+
+// Row-wise kernels (uniform, full): a block first stages the row ids (and the
+// per-row constants) of its words in LDS -- one dependent pair of global loads
+// per block instead of per piece -- then every thread keeps ROWWISE_BATCH value
+// loads in flight before it converts and stores.
 template <bool VEC4>
 __global__ void dequant_uniform(UniformParams p)
 {
+    __shared__ uint32_t rowLds[ROWWISE_MAX_WORDS];
+    __shared__ float2 minMaxLds[ROWWISE_MAX_WORDS];
     const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
     const uint32_t blockWords =
         static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
+    if (threadIdx.x < blockWords) {
+        const uint32_t row = p.rows[blockBase + threadIdx.x];
+        rowLds[threadIdx.x] = row;
+        minMaxLds[threadIdx.x] = row < p.nRows ? p.minMax[row] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
 
     if (VEC4) {
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = blockWords * piecesPerWord;
-        for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
-            const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
-            const uint32_t c = q - w * piecesPerWord;
-            const uint32_t row = p.rows[blockBase + w];
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < p.nRows) {
-                const float2 mm = p.minMax[row];
-                const float range = subRn(mm.y, mm.x);
-                const uint32_t v =
-                    *reinterpret_cast<const uint32_t*>(p.values + static_cast<unsigned long long>(row) * p.dim + 4 * c);
-                f.x = dequant(mm.x, range, v & 0xff, p.levels);
-                f.y = dequant(mm.x, range, (v >> 8) & 0xff, p.levels);
-                f.z = dequant(mm.x, range, (v >> 16) & 0xff, p.levels);
-                f.w = dequant(mm.x, range, v >> 24, p.levels);
+        for (uint32_t q0 = threadIdx.x; q0 < pieces; q0 += blockDim.x * ROWWISE_BATCH) {
+            uint32_t word[ROWWISE_BATCH];
+            uint32_t column[ROWWISE_BATCH];
+            uint32_t packed[ROWWISE_BATCH];
+#pragma unroll
+            for (int u = 0; u < ROWWISE_BATCH; ++u) {
+                const uint32_t q = min(q0 + u * blockDim.x, pieces - 1);
+                word[u] = fastDivide(q, p.pieceMagic, piecesPerWord);
+                column[u] = q - word[u] * piecesPerWord;
+                const uint32_t row = rowLds[word[u]];
+                packed[u] = 0;
+                if (row < p.nRows) {
+                    packed[u] = *reinterpret_cast<const uint32_t*>(
+                        p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
+                }
             }
-            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + 4 * c;
-            *reinterpret_cast<float4*>(dst) = f;
+#pragma unroll
+            for (int u = 0; u < ROWWISE_BATCH; ++u) {
+                if (q0 + u * blockDim.x < pieces) {
+                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rowLds[word[u]] < p.nRows) {
+                        const float2 mm = minMaxLds[word[u]];
+                        const float range = subRn(mm.y, mm.x);
+                        f.x = dequant(mm.x, range, packed[u] & 0xff, p.levels);
+                        f.y = dequant(mm.x, range, (packed[u] >> 8) & 0xff, p.levels);
+                        f.z = dequant(mm.x, range, (packed[u] >> 16) & 0xff, p.levels);
+                        f.w = dequant(mm.x, range, packed[u] >> 24, p.levels);
+                    }
+                    float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
+                    *reinterpret_cast<float4*>(dst) = f;
+                }
+            }
         }
     } else {
         const uint32_t total = blockWords * p.dim;
         for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
             const uint32_t w = q / p.dim;
             const uint32_t c = q - w * p.dim;
-            const uint32_t row = p.rows[blockBase + w];
+            const uint32_t row = rowLds[w];
             float f = 0.f;
             if (row < p.nRows) {
-                const float2 mm = p.minMax[row];
+                const float2 mm = minMaxLds[w];
                 const float range = subRn(mm.y, mm.x);
                 f = dequant(mm.x, range, p.values[static_cast<unsigned long long>(row) * p.dim + c], p.levels);
             }
@@ -715,28 +745,46 @@ struct FullParams {
 template <bool VEC4>
 __global__ void gather_full(FullParams p)
 {
+    __shared__ uint32_t rowLds[ROWWISE_MAX_WORDS];
     const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
     const uint32_t blockWords =
         static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
+    if (threadIdx.x < blockWords) {
+        rowLds[threadIdx.x] = p.rows[blockBase + threadIdx.x];
+    }
+    __syncthreads();
     if (VEC4) {
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = blockWords * piecesPerWord;
-        for (uint32_t q = threadIdx.x; q < pieces; q += blockDim.x) {
-            const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
-            const uint32_t c = q - w * piecesPerWord;
-            const uint32_t row = p.rows[blockBase + w];
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < p.nRows) {
-                f = *reinterpret_cast<const float4*>(p.values + static_cast<unsigned long long>(row) * p.dim + 4 * c);
+        for (uint32_t q0 = threadIdx.x; q0 < pieces; q0 += blockDim.x * ROWWISE_BATCH) {
+            uint32_t word[ROWWISE_BATCH];
+            uint32_t column[ROWWISE_BATCH];
+            float4 f[ROWWISE_BATCH];
+#pragma unroll
+            for (int u = 0; u < ROWWISE_BATCH; ++u) {
+                const uint32_t q = min(q0 + u * blockDim.x, pieces - 1);
+                word[u] = fastDivide(q, p.pieceMagic, piecesPerWord);
+                column[u] = q - word[u] * piecesPerWord;
+                const uint32_t row = rowLds[word[u]];
+                f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < p.nRows) {
+                    f[u] = *reinterpret_cast<const float4*>(
+                        p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
+                }
             }
-            *reinterpret_cast<float4*>(p.out + (blockBase + w) * p.ld + p.colOff + 4 * c) = f;
+#pragma unroll
+            for (int u = 0; u < ROWWISE_BATCH; ++u) {
+                if (q0 + u * blockDim.x < pieces) {
+                    *reinterpret_cast<float4*>(p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u]) = f[u];
+                }
+            }
         }
     } else {
         const uint32_t total = blockWords * p.dim;
         for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
             const uint32_t w = q / p.dim;
             const uint32_t c = q - w * p.dim;
-            const uint32_t row = p.rows[blockBase + w];
+            const uint32_t row = rowLds[w];
             p.out[(blockBase + w) * p.ld + p.colOff + c] =
                 row < p.nRows ? p.values[static_cast<unsigned long long>(row) * p.dim + c] : 0.f;
         }
@@ -1091,8 +1139,8 @@ constexpr uint32_t ROWWISE_THREADS = 256;
 
 uint32_t rowwiseWordsPerBlock(uint32_t dim)
 {
-    // about 16 KiB of output per block, at least one word
-    return std::max<uint32_t>(1, std::min<uint32_t>(64, 4096 / std::max<uint32_t>(dim, 1)));
+    // about 16 KiB of output per block (one batch of pieces per thread), at least one word
+    return std::max<uint32_t>(1, std::min<uint32_t>(ROWWISE_MAX_WORDS, 4096 / std::max<uint32_t>(dim, 1)));
 }
 
 int launchUniform(

@@ -143,6 +143,19 @@ int memb_hip_decode_rows(
 int memb_hip_decode_rows_device(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream);
 
+/*
+ * Same with an epilogue, for merging several models into one matrix on the
+ * device (reference python/memb/readers_union.py:18, numpy.mean over the readers):
+ * with MEMB_HIP_ACCUMULATE the decoded rows are added (fp32) to what `out` holds,
+ * and a non-zero `divisor` divides the result. R readers average as: first call
+ * plain, calls 2..R with MEMB_HIP_ACCUMULATE, the last one also with divisor = R --
+ * the same additions in the same order and the same single division as numpy.mean.
+ */
+#define MEMB_HIP_ACCUMULATE 1u
+int memb_hip_decode_rows_device_ex(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream,
+    uint32_t flags, float divisor);
+
 /* Wait for the context's own stream (used by memb_hip_decode_rows). */
 int memb_hip_sync(memb_hip_ctx* ctx);
 

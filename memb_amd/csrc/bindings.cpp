@@ -228,7 +228,9 @@ PYBIND11_MODULE(_memb, m) {
                uintptr_t out,
                size_t ld,
                size_t colOff,
-               uintptr_t stream)
+               uintptr_t stream,
+               bool accumulate,
+               float divisor)
             {
                 reader.rowsToDeviceBuffer(
                     reinterpret_cast<const uint32_t*>(rows),
@@ -236,14 +238,18 @@ PYBIND11_MODULE(_memb, m) {
                     reinterpret_cast<float*>(out),
                     ld,
                     colOff,
-                    reinterpret_cast<void*>(stream));
+                    reinterpret_cast<void*>(stream),
+                    accumulate,
+                    divisor);
             },
             py::arg("rows_ptr"),
             py::arg("n"),
             py::arg("out_ptr"),
             py::arg("ld"),
             py::arg("col_off") = 0,
-            py::arg("stream") = 0);
+            py::arg("stream") = 0,
+            py::arg("accumulate") = false,
+            py::arg("divisor") = 0.0f);
 
     m.def("available_compression_strategies", &memb::availableCompressionStrategies);
 

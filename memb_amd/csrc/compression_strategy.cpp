@@ -78,9 +78,12 @@ void CompressedStorage::decodeRows(const uint32_t* rows, size_t n, float* out, s
 }
 
 void CompressedStorage::decodeRowsDevice(
-    const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream) const
+    const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream, bool accumulate,
+    float divisor) const
 {
-    if (memb_hip_decode_rows_device(deviceContext(), rows, n, out, ld, colOff, stream) != MEMB_HIP_OK) {
+    if (memb_hip_decode_rows_device_ex(
+            deviceContext(), rows, n, out, ld, colOff, stream, accumulate ? MEMB_HIP_ACCUMULATE : 0u, divisor) !=
+        MEMB_HIP_OK) {
         throwDeviceError("HIP batch lookup failed");
     }
 }

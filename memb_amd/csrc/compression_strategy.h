@@ -48,8 +48,10 @@ public:
     // Decode rows[0..n) into out[i * ld + colOff ..], host buffers.
     void decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
     // Same with device buffers, enqueued on `stream` (hipStream_t, may be null).
+    // `accumulate` / `divisor`: see memb_hip_decode_rows_device_ex.
     void decodeRowsDevice(
-        const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream) const;
+        const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream,
+        bool accumulate = false, float divisor = 0.f) const;
 
     void setDevice(int device);
     int device() const { return device_; }

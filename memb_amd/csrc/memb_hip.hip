@@ -94,6 +94,8 @@ struct TrainedParams {
     uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
     uint32_t indexSegmentSymbols;
     uint32_t debugFlags;      // measurement only (MEMB_HIP_DEBUG): 1 = skip decode, 2 = skip output
+    uint32_t accumulate;      // epilogue: add to what the output already holds ...
+    float divisor;            // ... and / or divide by this (0 = no division)
 };
 
 enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3 };
@@ -128,6 +130,64 @@ __device__ __forceinline__ void waveLdsFence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+}
+
+// Single-lane-op IEEE fp32 add / sub / mul. Written as instructions because the
+// optimiser otherwise pairs neighbouring operations into v_pk_add_f32 /
+// v_pk_mul_f32, and the packed forms flush subnormal values on gfx950 (measured:
+// min = 1e-40 came back as 0), which would break bit parity with the CPU.
+__device__ __forceinline__ float addRn(float a, float b)
+{
+    float r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float subRn(float a, float b)
+{
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float mulRn(float a, float b)
+{
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Epilogue of ReadersUnion 'average' (reference python/memb/readers_union.py:18:
+// numpy.mean over the readers = fp32 sums in reader order, then one division
+// by the reader count): later readers add to what earlier ones stored, the last
+// one divides. Same operations and order as numpy, so the result is bit-identical.
+__device__ __forceinline__ float epilogue(float value, const float* destination, uint32_t accumulate, float divisor)
+{
+    if (accumulate) {
+        value = addRn(*destination, value);
+    }
+    if (divisor != 0.f) {
+        value = __fdiv_rn(value, divisor);
+    }
+    return value;
+}
+
+__device__ __forceinline__ float4 epilogue4(float4 value, const float* destination, uint32_t accumulate, float divisor)
+{
+    if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(destination);
+        value.x = addRn(old.x, value.x);
+        value.y = addRn(old.y, value.y);
+        value.z = addRn(old.z, value.z);
+        value.w = addRn(old.w, value.w);
+    }
+    if (divisor != 0.f) {
+        value.x = __fdiv_rn(value.x, divisor);
+        value.y = __fdiv_rn(value.y, divisor);
+        value.z = __fdiv_rn(value.z, divisor);
+        value.w = __fdiv_rn(value.w, divisor);
+    }
+    return value;
 }
 
 // ---- building blocks shared by the one-shot and the persistent kernel ----
@@ -340,6 +400,16 @@ __device__ __forceinline__ void outputTile(
     const float2* pairLds = reinterpret_cast<const float2*>(codebookLds);
     const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
 
+    // Nibble keys have no spare code for "absent" (byte keys use ZERO_KEY): rows of
+    // absent words are zeroed after the tile is written -- or, when an epilogue
+    // reads the destination, their pieces go through it as zeros.
+    const bool hasEpilogue = p.accumulate || p.divisor != 0.f;   // wave-uniform
+    unsigned long long absent = 0;
+    if (FAST) {
+        absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
+    }
+    const bool checkWords = FAST && hasEpilogue && absent != 0;
+
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
         // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
         // (byte keys: rows of dim bytes; nibble keys: rows of dim / 2 bytes).
@@ -375,13 +445,21 @@ __device__ __forceinline__ void outputTile(
             for (int u = 0; u < BURST; ++u) {
                 const uint32_t q = q0 + WAVE * u;
                 if (q < pieces) {
-                    if (MODE == OUT_FLAT) {
-                        reinterpret_cast<float4*>(tileOut)[q] = f[u];
+                    float* destination;
+                    if (MODE == OUT_FLAT && !checkWords) {
+                        destination = tileOut + 4 * static_cast<size_t>(q);
                     } else {
                         const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
                         const uint32_t c = q - w * piecesPerWord;
-                        *reinterpret_cast<float4*>(tileOut + w * p.ld + 4 * c) = f[u];
+                        destination = tileOut + w * p.ld + 4 * c;
+                        if (checkWords && ((absent >> (w * p.lanesPerWord)) & 1)) {
+                            f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
+                    if (hasEpilogue) {   // off the common path
+                        f[u] = epilogue4(f[u], destination, p.accumulate, p.divisor);
+                    }
+                    *reinterpret_cast<float4*>(destination) = f[u];
                 }
             }
         }
@@ -394,17 +472,22 @@ __device__ __forceinline__ void outputTile(
             if (FAST) {
                 const uint32_t k = keyBytes[w * p.keyRowBytes + (c >> 1)];
                 value = pairLds[(k >> (4 * (c & 1))) & 15].x;
+                if (checkWords && ((absent >> (w * p.lanesPerWord)) & 1)) {
+                    value = 0.f;
+                }
             } else {
                 value = centroidLds[keyBytes[w * p.keyRowBytes + c]];
             }
-            p.out[(tileBase + w) * p.ld + p.colOff + c] = value;
+            float* destination = p.out + (tileBase + w) * p.ld + p.colOff + c;
+            if (hasEpilogue) {
+                value = epilogue(value, destination, p.accumulate, p.divisor);
+            }
+            *destination = value;
         }
     }
 
-    if (FAST) {
-        // Nibble keys have no spare code for "absent": zero the rows of absent
-        // words afterwards (same wave, same addresses: program order holds).
-        unsigned long long absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
+    if (FAST && !hasEpilogue) {
+        // zero the rows of absent words (same wave, same addresses: program order holds)
         while (absent) {
             const uint32_t w = fastDivide(__ffsll(static_cast<long long>(absent)) - 1, p.laneMagic, p.lanesPerWord);
             absent &= absent - 1;
@@ -607,6 +690,8 @@ __global__ void repack_streams(
 // ---------------------------------------------------------------------------
 
 struct UniformParams {
+    uint32_t accumulate;
+    float divisor;
     const uint32_t* rows;
     float* out;
     unsigned long long n;
@@ -620,31 +705,6 @@ struct UniformParams {
     uint32_t pieceMagic;     // ceil(2^32 / (dim / 4)), vector path
     float levels;
 };
-
-// Single-lane-op IEEE fp32 add / sub / mul. Written as instructions because the
-// optimiser otherwise pairs neighbouring operations into v_pk_add_f32 /
-// v_pk_mul_f32, and the packed forms flush subnormal values on gfx950 (measured:
-// min = 1e-40 came back as 0), which would break bit parity with the CPU.
-__device__ __forceinline__ float addRn(float a, float b)
-{
-    float r;
-    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float subRn(float a, float b)
-{
-    float r;
-    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float mulRn(float a, float b)
-{
-    float r;
-    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 // reference src/uniform_compression.cpp:70-71, evaluated left to right in fp32:
 // sub, mul, div, add -- each correctly rounded, nothing fused, subnormals kept.
@@ -708,6 +768,9 @@ __global__ void dequant_uniform(UniformParams p)
                         f.w = dequant(mm.x, range, packed[u] >> 24, p.levels);
                     }
                     float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
+                    if (p.accumulate || p.divisor != 0.f) {
+                        f = epilogue4(f, dst, p.accumulate, p.divisor);
+                    }
                     *reinterpret_cast<float4*>(dst) = f;
                 }
             }
@@ -724,12 +787,18 @@ __global__ void dequant_uniform(UniformParams p)
                 const float range = subRn(mm.y, mm.x);
                 f = dequant(mm.x, range, p.values[static_cast<unsigned long long>(row) * p.dim + c], p.levels);
             }
-            p.out[(blockBase + w) * p.ld + p.colOff + c] = f;
+            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + c;
+            if (p.accumulate || p.divisor != 0.f) {
+                f = epilogue(f, dst, p.accumulate, p.divisor);
+            }
+            *dst = f;
         }
     }
 }
 
 struct FullParams {
+    uint32_t accumulate;
+    float divisor;
     const uint32_t* rows;
     float* out;
     unsigned long long n;
@@ -775,7 +844,11 @@ __global__ void gather_full(FullParams p)
 #pragma unroll
             for (int u = 0; u < ROWWISE_BATCH; ++u) {
                 if (q0 + u * blockDim.x < pieces) {
-                    *reinterpret_cast<float4*>(p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u]) = f[u];
+                    float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
+                    if (p.accumulate || p.divisor != 0.f) {
+                        f[u] = epilogue4(f[u], dst, p.accumulate, p.divisor);
+                    }
+                    *reinterpret_cast<float4*>(dst) = f[u];
                 }
             }
         }
@@ -785,8 +858,12 @@ __global__ void gather_full(FullParams p)
             const uint32_t w = q / p.dim;
             const uint32_t c = q - w * p.dim;
             const uint32_t row = rowLds[w];
-            p.out[(blockBase + w) * p.ld + p.colOff + c] =
-                row < p.nRows ? p.values[static_cast<unsigned long long>(row) * p.dim + c] : 0.f;
+            float f = row < p.nRows ? p.values[static_cast<unsigned long long>(row) * p.dim + c] : 0.f;
+            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + c;
+            if (p.accumulate || p.divisor != 0.f) {
+                f = epilogue(f, dst, p.accumulate, p.divisor);
+            }
+            *dst = f;
         }
     }
 }
@@ -1027,8 +1104,14 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     return params;
 }
 
+struct Epilogue {
+    uint32_t accumulate = 0;
+    float divisor = 0.f;
+};
+
 int launchTrained(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
+    const Epilogue& epilogue)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out);
@@ -1041,6 +1124,8 @@ int launchTrained(
     params.n = n;
     params.ld = ld;
     params.colOff = colOff;
+    params.accumulate = epilogue.accumulate;
+    params.divisor = epilogue.divisor;
     params.lanesPerWord = ctx->lanesPerWord;
     params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
     params.wordsPerWave = wordsPerWave;
@@ -1144,9 +1229,12 @@ uint32_t rowwiseWordsPerBlock(uint32_t dim)
 }
 
 int launchUniform(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
+    const Epilogue& epilogue)
 {
     UniformParams params{};
+    params.accumulate = epilogue.accumulate;
+    params.divisor = epilogue.divisor;
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -1175,9 +1263,12 @@ int launchUniform(
 }
 
 int launchFull(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
+    const Epilogue& epilogue)
 {
     FullParams params{};
+    params.accumulate = epilogue.accumulate;
+    params.divisor = epilogue.divisor;
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -1203,7 +1294,9 @@ int launchFull(
     return MEMB_HIP_OK;
 }
 
-int launch(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+int launch(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
+    const Epilogue& epilogue = Epilogue())
 {
     if (n == 0) {
         return MEMB_HIP_OK;
@@ -1213,11 +1306,11 @@ int launch(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t
     }
     switch (ctx->storage) {
         case memb::wire::Storage_Trained:
-            return launchTrained(ctx, rows, n, out, ld, colOff, stream);
+            return launchTrained(ctx, rows, n, out, ld, colOff, stream, epilogue);
         case memb::wire::Storage_Uniform:
-            return launchUniform(ctx, rows, n, out, ld, colOff, stream);
+            return launchUniform(ctx, rows, n, out, ld, colOff, stream, epilogue);
         case memb::wire::Storage_Full:
-            return launchFull(ctx, rows, n, out, ld, colOff, stream);
+            return launchFull(ctx, rows, n, out, ld, colOff, stream, epilogue);
         default:
             return fail(MEMB_HIP_ERR_INVALID, "context has no storage");
     }
@@ -1676,6 +1769,26 @@ int memb_hip_decode_rows_device(
     }
     HIP_TRY(hipSetDevice(ctx->device));
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream));
+}
+
+int memb_hip_decode_rows_device_ex(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream,
+    uint32_t flags, float divisor)
+{
+    if (!ctx || (n && (!rows || !out))) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    if (ld < col_off + ctx->dim) {
+        return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
+    }
+    if ((flags & ~uint32_t(MEMB_HIP_ACCUMULATE)) || !(divisor == divisor)) {
+        return fail(MEMB_HIP_ERR_INVALID, "unknown flags or NaN divisor");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    Epilogue epilogue;
+    epilogue.accumulate = (flags & MEMB_HIP_ACCUMULATE) ? 1u : 0u;
+    epilogue.divisor = divisor;
+    return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream), epilogue);
 }
 
 int memb_hip_decode_rows(

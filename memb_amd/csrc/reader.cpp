@@ -202,9 +202,10 @@ void Reader::rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t 
 }
 
 void Reader::rowsToDeviceBuffer(
-    const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream) const
+    const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream, bool accumulate,
+    float divisor) const
 {
-    compressedStorage_->decodeRowsDevice(rows, n, buffer, ld, colOff, stream);
+    compressedStorage_->decodeRowsDevice(rows, n, buffer, ld, colOff, stream, accumulate, divisor);
 }
 
 std::vector<float> Reader::wordEmbedding(const std::string& word) const

@@ -68,7 +68,8 @@ public:
     // Lookup by row id with host or device buffers (see include/memb_hip.h).
     void rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff) const;
     void rowsToDeviceBuffer(
-        const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream) const;
+        const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream,
+        bool accumulate = false, float divisor = 0.f) const;
 
     memb_hip_ctx* deviceContext() const;
 

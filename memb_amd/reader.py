@@ -148,12 +148,14 @@ class Reader(BaseReader):
         '''Write the batch into columns [col_off, col_off + dim) of a wider float32 matrix'''
         self._impl.batch_embedding_into(words, out, col_off)
 
-    def rows_embedding_device(self, rows, out=None, col_off=0):
+    def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0):
         '''Lookup that never leaves the GPU.
         Parameters
         ----------
         rows : torch.Tensor (int32 view of the uint32 row ids, on this reader's device)
         out : torch.Tensor float32 (n, >= col_off + dim) on the same device, optional
+        accumulate : add the rows to what `out` holds instead of overwriting it
+        divisor : if non-zero, divide the (accumulated) rows by it
         '''
         import torch
         if rows.device.type != 'cuda' or rows.dtype not in (torch.int32, torch.uint32) or not rows.is_contiguous():
@@ -164,8 +166,15 @@ class Reader(BaseReader):
         if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n:
             raise TypeError('out must be a float32 (n, width) tensor with unit column stride')
         stream = torch.cuda.current_stream(rows.device).cuda_stream
-        self._impl.rows_to_device(rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, stream)
+        self._impl.rows_to_device(
+            rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, stream, accumulate, float(divisor))
         return out
+
+    def batch_embedding_device(self, words):
+        '''batch_embedding with the result left on the GPU as a torch.Tensor (DLPack capable)'''
+        import torch
+        rows = torch.from_numpy(self.resolve_rows(words).view('int32')).to('cuda:{}'.format(self.device))
+        return self.rows_embedding_device(rows)
 
     def info(self):
         '''Facts about the device context (stages the model on first call)'''

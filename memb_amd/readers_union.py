@@ -116,6 +116,33 @@ class ReadersUnion(BaseReader):
         '''
         return self._union_maker.batch(self._readers, words)
 
+    def batch_embedding_device(self, words):
+        '''batch_embedding merged on the GPU; returns a torch.Tensor (DLPack capable).
+        concatenate: every reader decodes into its column block of one (n, sum of dims)
+        tensor; average: readers 2..R add to the first one's rows, the last one divides
+        by R -- the additions and the division numpy.mean performs, in the same order.
+        All readers must sit on the same device (not in the reference API).'''
+        import torch
+        readers = self._readers
+        if not all(isinstance(reader, Reader) for reader in readers):
+            raise TypeError('device merge needs memb_amd.Reader instances')
+        device = 'cuda:{}'.format(readers[0].device)
+        if any(reader.device != readers[0].device for reader in readers):
+            raise ValueError('all readers of a union must be on one device')
+        rows = [torch.from_numpy(reader.resolve_rows(words).view('int32')).to(device) for reader in readers]
+        out = torch.empty((len(words), self.dim), dtype=torch.float32, device=device)
+        if self._union_maker is UNION_MAKERS['concatenate']:
+            col_off = 0
+            for reader, reader_rows in zip(readers, rows):
+                reader.rows_embedding_device(reader_rows, out=out, col_off=col_off)
+                col_off += reader.dim
+        else:
+            for position, (reader, reader_rows) in enumerate(zip(readers, rows)):
+                last = position == len(readers) - 1
+                reader.rows_embedding_device(
+                    reader_rows, out=out, accumulate=position > 0, divisor=float(len(readers)) if last else 0.0)
+        return out
+
     def tokenizer_embedding(self, tokenizer):
         '''Merged results of tokenizer_embedding call from all readers
         Parameters

@@ -200,6 +200,46 @@ def test_readers_union_concatenate_and_average(native, make_model):
     assert concat.keys() == sorted(set(words_a) | set(words_b))
 
 
+def test_union_merged_on_the_device(native, make_model):
+    # device-side concatenate / average must equal numpy's merge of the CPU checker's rows, bit for bit
+    import torch
+    specs = [(20000, 'trained', 4, 1234), (9000, 'trained', 4, 77), (700, 'uniform', 8, 300), (20000, 'trained', 8, 1234)]
+    models = [make_model(count, 300, storage, bits, seed=seed) for count, storage, bits, seed in specs]
+    readers = [native.Reader(path) for path, _ in models]
+    checkers = [oracle.OracleReader(path) for path, _ in models]
+    vocabulary = sorted(set(models[0][1]) | set(models[1][1]) | set(models[2][1]))
+    rng = np.random.default_rng(21)
+    batch = [vocabulary[i] for i in rng.integers(0, len(vocabulary), size=3001)] + ['nowhere', '']
+    expected = [checker.batch_embedding(batch) for checker in checkers]
+    for count in (2, 3, 4):
+        union = native.ReadersUnion(readers[:count], 'average')
+        merged = union.batch_embedding_device(batch)
+        assert merged.device.type == 'cuda' and merged.shape == (len(batch), 300)
+        assert bits_equal(merged.cpu().numpy(), np.mean(expected[:count], axis=0)), count
+        assert bits_equal(merged.cpu().numpy(), union[batch])   # the reference's host-side merge
+        concat = native.ReadersUnion(readers[:count], 'concatenate').batch_embedding_device(batch)
+        assert bits_equal(concat.cpu().numpy(), np.concatenate(expected[:count], axis=-1)), count
+    # hand-off without a copy
+    exported = torch.from_dlpack(merged)
+    assert exported.data_ptr() == merged.data_ptr()
+    single = readers[0].batch_embedding_device(batch)
+    assert bits_equal(single.cpu().numpy(), expected[0])
+
+
+def test_epilogue_scalar_paths(native, make_model):
+    # odd dimensions take the scalar output path; accumulate + divide there too
+    import torch
+    for dim, storage, bits in ((5, 'trained', 4), (5, 'trained', 8), (7, 'uniform', 8), (3, 'full', 8)):
+        path_a, words = make_model(700, dim, storage, bits, seed=1)
+        path_b, _ = make_model(700, dim, storage, bits, seed=2)
+        readers = [native.Reader(path_a), native.Reader(path_b)]
+        checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+        batch = sorted(words)[::3] + ['missing']
+        expected = np.mean([c.batch_embedding(batch) for c in checkers], axis=0)
+        merged = native.ReadersUnion(readers, 'average').batch_embedding_device(batch)
+        assert bits_equal(merged.cpu().numpy(), expected), (dim, storage, bits)
+
+
 def test_device_resident_lookup_matches_host_path(native, make_model):
     import torch
     path, words = make_model(20000, 300, 'trained', 6)

@@ -52,10 +52,11 @@ except ImportError as error:  # fail loudly: nothing here works without the nati
 from .builder import Builder
 from .reader import Reader
 from .readers_union import ReadersUnion
+from .sharding import ShardedReader
 
 available_compression_strategies = _memb.available_compression_strategies
 hip_device_count = _memb.hip_device_count
 
 HIP_LIBRARY_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'libmemb_hip.so')
 
-__all__ = ['Builder', 'Reader', 'ReadersUnion', 'available_compression_strategies', 'hip_device_count']
+__all__ = ['Builder', 'Reader', 'ReadersUnion', 'ShardedReader', 'available_compression_strategies', 'hip_device_count']

@@ -8,7 +8,11 @@ holds a full replica of the model (<= 0.4 GB, nothing next to 288 GB of HBM).
 There is no collective on the data path. `gather_rows` is the optional
 host-side gather for callers that want the whole matrix in one place.
 """
+import threading
+
 import numpy as np
+
+from .reader import BaseReader, Reader, tokenizer_word_list
 
 
 def shard_range(count, rank, world_size):
@@ -53,3 +57,71 @@ def gather_rows(local_rows, count, group=None, dst=0):
         start, stop = shard_range(count, r, world_size)
         out[start:stop] = piece[:stop - start].cpu().numpy()
     return out
+
+
+class ShardedReader(BaseReader):
+    '''One model replicated on several GPUs of a node, driven from one process.
+    A batch is resolved to row ids once on the host, split into contiguous slices
+    (shard_range), every device decodes its slice and writes it straight into its
+    rows of the one result array: the "gather" is that the slices are disjoint
+    ranges of one host buffer. No collective, no peer traffic.
+    Parameters
+    ----------
+    filename : str or pathlib.Path
+    devices : list of int, HIP device indices (a device may be listed more than once)
+    num_threads : int, host threads for the word search (0 = all cores)
+    '''
+
+    def __init__(self, filename, devices, num_threads=0):
+        super().__init__()
+        if not devices:
+            raise ValueError('at least one device is needed')
+        self._readers = [Reader(filename, num_threads, device=device) for device in devices]
+
+    @property
+    def dim(self):
+        return self._readers[0].dim
+
+    @property
+    def devices(self):
+        return [reader.device for reader in self._readers]
+
+    def __len__(self):
+        return len(self._readers[0])
+
+    def keys(self):
+        return self._readers[0].keys()
+
+    def word_embedding(self, word):
+        return self._readers[0].word_embedding(word)
+
+    def rows_embedding(self, rows):
+        '''Rows by id, slices decoded concurrently on all devices'''
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.empty((len(rows), self.dim), dtype=np.float32)
+        world = len(self._readers)
+        errors = []
+
+        def work(rank):
+            start, stop = shard_range(len(rows), rank, world)
+            try:
+                if stop > start:
+                    out[start:stop] = self._readers[rank].rows_embedding(rows[start:stop])
+            except Exception as error:  # re-raised on the calling thread
+                errors.append(error)
+
+        threads = [threading.Thread(target=work, args=(rank,)) for rank in range(1, world)]
+        for thread in threads:
+            thread.start()
+        work(0)
+        for thread in threads:
+            thread.join()
+        if errors:
+            raise errors[0]
+        return out
+
+    def batch_embedding(self, words):
+        return self.rows_embedding(self._readers[0].resolve_rows(words))
+
+    def tokenizer_embedding(self, tokenizer):
+        return self.batch_embedding(tokenizer_word_list(tokenizer))

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_LIBRARY = os.path.join(_HERE, 'libmemb_oracle.so')
+ORACLE_LIBRARY = os.environ.get('MEMB_ORACLE_LIBRARY', os.path.join(_HERE, 'libmemb_oracle.so'))  # override: sanitizer build
 REFERENCE_LIBRARY = os.path.join(_HERE, '_ref', 'libmemb_ref.so')
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -268,6 +268,20 @@ def test_batch_split_like_two_ranks(native, make_model):
     assert bits_equal(np.concatenate(pieces), reader.batch_embedding(batch))
 
 
+def test_sharded_reader_in_one_process(native, make_model):
+    # the node-level path of north_star: one replica per device, host-side gather into one buffer
+    # (this box has one GPU: the same device listed three times exercises the split and the threads)
+    path, words = make_model(20000, 300, 'trained', 4)
+    sharded = native.ShardedReader(path, devices=[0, 0, 0])
+    checker = oracle.OracleReader(path)
+    batch = sorted(words)[:7001:3] + ['missing'] * 5
+    assert sharded.devices == [0, 0, 0] and sharded.dim == 300 and len(sharded) == 20000
+    assert bits_equal(sharded[batch], checker.batch_embedding(batch))
+    assert bits_equal(sharded[batch[:2]], checker.batch_embedding(batch[:2]))   # fewer entries than devices
+    assert bits_equal(sharded['missing'], np.zeros(300, dtype=np.float32))
+    assert sharded.batch_embedding([]).shape == (0, 300)
+
+
 def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
     # lanes per word (segments of the side index) and waves per block must not change results
     for bits, distribution in ((4, 'normal'), (8, 'student')):

@@ -229,3 +229,34 @@ def test_readers_union_argument_checks(native):
     assert union.dim == 7
     assert union.keys() == ['a', 'b', 'c']
     assert native.ReadersUnion([Fake(3), Fake(3)], 'average').dim == 3
+
+
+def test_writer_round_trip_properties(native, tmp_path):
+    """Builder -> file -> CPU checker on random small models: every decoded trained value is a
+    centroid and (up to rounding at the mid-point) the nearest one to the original weight; every
+    uniform value is within one quantisation step; keys come back sorted; odd shapes included."""
+    rng = np.random.default_rng(123)
+    for trial in range(24):
+        dim = int(rng.integers(1, 41))
+        count = int(rng.integers(30, 400))
+        bits = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        scale = float(rng.choice([0.01, 0.4, 30.0]))
+        vectors = (rng.standard_t(4, size=(count, dim)) * scale).astype(np.float32)
+        words = ['w{}_{}'.format(trial, i) for i in rng.permutation(count)]
+        for storage in ('trained', 'uniform'):
+            builder = native.Builder(dim, storage, bits)
+            builder.add_words(words, vectors)
+            path = tmp_path / 'm{}_{}.bin'.format(trial, storage)
+            builder.save(path)
+            checker = oracle.OracleReader(str(path))
+            assert checker.keys() == sorted(words)
+            decoded = checker.batch_embedding(words)
+            if storage == 'trained':
+                centroids = np.unique(decoded)
+                assert len(centroids) <= min(2 ** bits, 255)
+                nearest = np.abs(vectors[..., None] - centroids[None, None, :]).min(axis=-1)
+                assert np.all(np.abs(vectors - decoded) <= nearest * (1 + 1e-5) + 1e-6 * scale), (trial, dim, bits)
+            else:
+                span = vectors.max(axis=1, keepdims=True) - vectors.min(axis=1, keepdims=True)
+                step = span / min(2 ** bits, 255)
+                assert np.all(np.abs(vectors - decoded) <= step * 1.0001 + 1e-6 * scale), (trial, dim, bits)

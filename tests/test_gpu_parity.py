@@ -268,6 +268,54 @@ def test_batch_split_like_two_ranks(native, make_model):
     assert bits_equal(np.concatenate(pieces), reader.batch_embedding(batch))
 
 
+def test_boundary_argument_errors(native, make_model):
+    import ctypes
+    import torch
+    path, words = make_model(700, 8, 'trained', 4, seed=8)
+    reader = native.Reader(path)
+    rows = torch.zeros(4, dtype=torch.int32, device='cuda')
+    with pytest.raises(RuntimeError, match='ld must be at least col_off'):
+        reader.rows_embedding_device(rows, out=torch.empty((4, 8), device='cuda'), col_off=4)
+    with pytest.raises(TypeError):
+        reader.rows_embedding_device(rows.cpu())
+    with pytest.raises(TypeError):
+        reader.rows_embedding_device(rows.to(torch.int64))
+    with pytest.raises(TypeError):
+        reader.rows_embedding_device(rows, out=torch.empty((4, 8), dtype=torch.float64, device='cuda'))
+    with pytest.raises(RuntimeError):
+        reader.batch_embedding_into(['a'], np.zeros((1, 4), dtype=np.float32), 0)   # narrower than dim
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+    context = ctypes.c_void_p(reader._impl.context_handle())
+    out = torch.empty((4, 8), device='cuda')
+    call = library.memb_hip_decode_rows_device_ex
+    args = [context, ctypes.c_void_p(rows.data_ptr()), ctypes.c_size_t(4), ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_size_t(8), ctypes.c_size_t(0), ctypes.c_void_p(0)]
+    assert call(*args, ctypes.c_uint32(2), ctypes.c_float(0.0)) == 1 and b'flags' in library.memb_hip_last_error()
+    assert call(*args, ctypes.c_uint32(0), ctypes.c_float(float('nan'))) == 1
+    assert call(*args, ctypes.c_uint32(0), ctypes.c_float(0.0)) == 0
+    torch.cuda.synchronize()
+    assert bits_equal(out.cpu().numpy(), oracle.OracleReader(path).rows_embedding(np.zeros(4, dtype=np.uint32)))
+    total = ctypes.c_uint64(0)
+    ids = np.array([0, 0xFFFFFFFF, 5], dtype=np.uint32)
+    assert library.memb_hip_algorithmic_bytes(context, ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(3), ctypes.byref(total)) == 0
+    checker = oracle.OracleReader(path)
+    assert total.value == 3 * (4 + 32) + 2 * 4 + checker.stream_bytes(0) + checker.stream_bytes(5)   # SURVEY 8d formula
+
+
+def test_empty_models(native, tmp_path):
+    # no words at all: every lookup is a miss (uniform / full can be written empty; trained has nothing to train on)
+    for storage in ('uniform', 'full'):
+        path = tmp_path / ('empty_' + storage + '.bin')
+        native.Builder(6, storage, 8).save(path)
+        reader = native.Reader(path)
+        assert reader.keys() == [] and len(reader) == 0 and reader.dim == 6
+        assert bits_equal(reader[['a', '']], np.zeros((2, 6), dtype=np.float32))
+        assert bits_equal(reader[['a', '']], oracle.OracleReader(str(path)).batch_embedding(['a', '']))
+    with pytest.raises(RuntimeError, match='Nothing to encode'):
+        native.Builder(6, 'trained', 4).save(tmp_path / 'empty_trained.bin')
+
+
 def test_sharded_reader_in_one_process(native, make_model):
     # the node-level path of north_star: one replica per device, host-side gather into one buffer
     # (this box has one GPU: the same device listed three times exercises the split and the threads)

@@ -29,12 +29,14 @@
 #include "wire.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1437,6 +1439,9 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         return fail(MEMB_HIP_ERR_INVALID, "inconsistent trained storage description");
     }
 
+    const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tStart = now();
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ctx->storage = memb::wire::Storage_Trained;
     ctx->dim = desc->dim;
@@ -1457,34 +1462,68 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         return fail(MEMB_HIP_ERR_INVALID, error.what());
     }
 
-    // Per-row stream length: streams are laid out back to back, so a stream
-    // ends where the next one (in storage order) begins.
+    // Per-row stream length: streams are laid out back to back, so a stream ends
+    // where the next one (in storage order) begins. Every start is marked in a
+    // bitmap over the byte positions; each row then scans forward to the next
+    // mark. Both passes run on a few host threads.
     {
-        std::vector<uint64_t> order(desc->n_rows);
         for (uint64_t r = 0; r < desc->n_rows; ++r) {
             if (desc->value_offsets[r] > desc->packed_values_bytes) {
                 delete ctx;
                 return fail(MEMB_HIP_ERR_INVALID, "value offset beyond packed values");
             }
-            order[r] = (static_cast<uint64_t>(desc->value_offsets[r]) << 32) | r;
         }
-        std::sort(order.begin(), order.end());
+        const uint64_t totalBytes = desc->packed_values_bytes;
+        const size_t bitmapWords = static_cast<size_t>(totalBytes / 64 + 2);
+        std::vector<std::atomic<uint64_t>> marks(bitmapWords);
+        for (auto& word : marks) {
+            word.store(0, std::memory_order_relaxed);
+        }
+        marks[totalBytes / 64].fetch_or(uint64_t(1) << (totalBytes % 64), std::memory_order_relaxed);   // end sentinel
+        const uint64_t bound =
+            (static_cast<uint64_t>(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) + 7) / 8;
         ctx->streamBytes.assign(desc->n_rows, 0);
-        uint64_t nextStart = desc->packed_values_bytes;
-        uint64_t previousOffset = desc->packed_values_bytes;
-        for (size_t i = order.size(); i > 0; --i) {
-            uint64_t offset = order[i - 1] >> 32;
-            uint32_t rowIndex = static_cast<uint32_t>(order[i - 1]);
-            if (offset != previousOffset) {
-                nextStart = previousOffset;
-                previousOffset = offset;
+        const size_t threads = std::max<size_t>(1, std::min<size_t>({std::thread::hardware_concurrency(), size_t(16), size_t(desc->n_rows / 65536 + 1)}));
+        const uint64_t perThread = (desc->n_rows + threads - 1) / threads;
+        auto parallel = [&](auto body) {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < threads; ++t) {
+                pool.emplace_back(body, t * perThread, std::min<uint64_t>(desc->n_rows, (t + 1) * perThread));
             }
-            uint64_t bytes = nextStart - offset;
-            // a stream never holds more than dim codes of the longest length
-            uint64_t bound = (static_cast<uint64_t>(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) + 7) / 8;
-            ctx->streamBytes[rowIndex] = static_cast<uint32_t>(std::min(bytes, bound));
-            ctx->maxStreamBytes = std::max(ctx->maxStreamBytes, ctx->streamBytes[rowIndex]);
-        }
+            body(uint64_t(0), std::min<uint64_t>(desc->n_rows, perThread));
+            for (auto& thread : pool) {
+                thread.join();
+            }
+        };
+        parallel([&](uint64_t first, uint64_t last) {
+            for (uint64_t r = first; r < last; ++r) {
+                const uint64_t offset = desc->value_offsets[r];
+                marks[offset / 64].fetch_or(uint64_t(1) << (offset % 64), std::memory_order_relaxed);
+            }
+        });
+        std::vector<uint32_t> threadMax(threads, 0);
+        parallel([&](uint64_t first, uint64_t last) {
+            uint32_t longest = 0;
+            for (uint64_t r = first; r < last; ++r) {
+                const uint64_t offset = desc->value_offsets[r];
+                uint64_t bytes = 0;
+                if (offset < totalBytes) {
+                    // next mark strictly after `offset` (a stream never holds more than dim codes of the longest length)
+                    uint64_t position = offset + 1;
+                    size_t word = position / 64;
+                    uint64_t bits = marks[word].load(std::memory_order_relaxed) & (~uint64_t(0) << (position % 64));
+                    while (!bits && (word + 1) * 64 <= offset + bound + 64) {
+                        bits = marks[++word].load(std::memory_order_relaxed);
+                    }
+                    const uint64_t next = bits ? word * 64 + static_cast<uint64_t>(__builtin_ctzll(bits)) : offset + bound;
+                    bytes = std::min(next - offset, bound);
+                }
+                ctx->streamBytes[r] = static_cast<uint32_t>(bytes);
+                longest = std::max(longest, ctx->streamBytes[r]);
+            }
+            threadMax[first / std::max<uint64_t>(perThread, 1)] = longest;
+        });
+        ctx->maxStreamBytes = *std::max_element(threadMax.begin(), threadMax.end());
     }
     // Slot: stream plus the 12-byte window the decoder reads at its last
     // position; whole 16-byte pieces, an odd number of them so that equal
@@ -1507,6 +1546,7 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
     }
 
+    const double tSorted = now();
     // Re-packed layout: row r's stream occupies ceil(bytes / 16) pieces from streamStarts[r].
     std::vector<uint32_t> streamStarts(desc->n_rows + 1, 0);
     {
@@ -1576,6 +1616,7 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
             (void)hipFree(fileOffsets);
         }
     }
+    const double tRepacked = now();
     if (code == MEMB_HIP_OK) {
         code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);
     }
@@ -1624,6 +1665,10 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
     }
     if (code == MEMB_HIP_OK) {
         code = buildSegmentIndex(ctx);
+    }
+    if (verbose) {
+        std::fprintf(stderr, "memb_hip: stage trained rows=%llu: host lengths %.3fs, device open + copy + repack %.3fs, tables + index %.3fs\n",
+                     static_cast<unsigned long long>(desc->n_rows), tSorted - tStart, tRepacked - tSorted, now() - tRepacked);
     }
     if (code != MEMB_HIP_OK) {
         std::string message = g_lastError;

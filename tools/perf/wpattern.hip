@@ -60,6 +60,58 @@ __global__ void fill_tiles_gather(float4* out, size_t n4, unsigned tileWords, co
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// tiles + ONE contiguous read per tile: the wave reads `tileReadPieces` consecutive 16-byte pieces (coalesced)
+__global__ void fill_tiles_block_read(float4* out, size_t n4, unsigned tileWords, const uint4* src, size_t srcPieces,
+                                      unsigned tileReadPieces, unsigned* sink) {
+    unsigned lane = threadIdx.x & 63;
+    size_t wave = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    size_t waves = (size_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned tilePieces = tileWords * 75;
+    size_t tiles = (n4 + tilePieces - 1) / tilePieces;
+    unsigned acc = 0;
+    for (size_t t = wave; t < tiles; t += waves) {
+        size_t start = (t * tileReadPieces) % (srcPieces - tileReadPieces - 64);
+        for (unsigned q = lane; q < tileReadPieces; q += 64) {
+            uint4 v = src[start + q];
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+        size_t base = t * tilePieces;
+        for (unsigned q = lane; q < tilePieces; q += 64)
+            if (base + q < n4) out[base + q] = make_float4(1, 2, 3, 4);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+// read-only touch of a range (pull it into L2 / Infinity Cache)
+__global__ void touch_range(const uint4* src, size_t first, size_t count, unsigned* sink) {
+    unsigned acc = 0;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint4 v = src[first + i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+// tiles [tileFirst, tileFirst + tileCount) with one contiguous read per tile at src[(tile * tileReadPieces)]
+__global__ void fill_tiles_range(float4* out, size_t n4, unsigned tileWords, const uint4* src, unsigned tileReadPieces,
+                                 size_t tileFirst, size_t tileCount, unsigned* sink) {
+    unsigned lane = threadIdx.x & 63;
+    size_t wave = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    size_t waves = (size_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned tilePieces = tileWords * 75;
+    unsigned acc = 0;
+    for (size_t k = wave; k < tileCount; k += waves) {
+        size_t t = tileFirst + k;
+        size_t start = t * tileReadPieces;
+        for (unsigned q = lane; q < tileReadPieces; q += 64) {
+            uint4 v = src[start + q];
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+        size_t base = t * tilePieces;
+        for (unsigned q = lane; q < tilePieces; q += 64)
+            if (base + q < n4) out[base + q] = make_float4(1, 2, 3, 4);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 template <typename F> float timeIt(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) f();
@@ -90,6 +142,30 @@ int main() {
         for (int randomOrder : {1, 0}) for (unsigned ppw : {11u, 9u, 6u}) for (int wavesPerCu : {16, 32}) {
             char name[160]; snprintf(name, sizeof name, "tiles 8 words + %s gather %u x16B/word from 286 MB, %d waves/CU", randomOrder ? "RANDOM" : "sequential", ppw, wavesPerCu);
             show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles_gather, dim3(cus * wavesPerCu / 8), dim3(512), 0, 0, out, n4, 8u, src, srcBytes / 16, ppw, 130u, randomOrder, sink); }));
+        }
+        for (size_t mb : {8u, 32u, 128u, 286u}) for (unsigned tileRead : {72u, 128u}) {
+            char name[160]; snprintf(name, sizeof name, "tiles 8 words + one contiguous %u-B read per tile, source %zu MB, 32 waves/CU", tileRead * 16, mb);
+            show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles_block_read, dim3(cus * 4), dim3(512), 0, 0, out, n4, 8u, src, (mb << 20) / 16, tileRead, sink); }));
+        }
+        for (size_t mb : {8u, 32u, 128u}) {
+            char name[160]; snprintf(name, sizeof name, "tiles 8 words + RANDOM gather 9 x16B/word from %zu MB, 32 waves/CU", mb);
+            show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles_gather, dim3(cus * 4), dim3(512), 0, 0, out, n4, 8u, src, (mb << 20) / 16, 9u, 130u, 1, sink); }));
+        }
+        {
+            // chunked: per chunk a read-only touch kernel, then the tile kernel; source = 69 pieces (1104 B) per tile, 303 MB in all
+            const unsigned tileRead = 69; const size_t tiles = (n4 + 599) / 600;
+            uint4* big; CHECK(hipMalloc(&big, (tiles + 8) * tileRead * 16)); CHECK(hipMemset(big, 1, (tiles + 8) * tileRead * 16));
+            for (int chunks : {1, 4, 8, 12, 16, 24, 32}) for (int touch : {0, 1}) {
+                char name[160]; snprintf(name, sizeof name, "CHUNKED x%2d %s: tiles + contiguous 1104-B read per tile (303 MB source)", chunks, touch ? "touch-then-decode" : "decode only      ");
+                show(name, timeIt([&] {
+                    size_t per = (tiles + chunks - 1) / chunks;
+                    for (int c = 0; c < chunks; ++c) {
+                        size_t first = size_t(c) * per, count = std::min(per, tiles - first);
+                        if (touch) hipLaunchKernelGGL(touch_range, dim3(cus * 8), dim3(256), 0, 0, big, first * tileRead, count * tileRead, sink);
+                        hipLaunchKernelGGL(fill_tiles_range, dim3(cus * 4), dim3(512), 0, 0, out, n4, 8u, big, tileRead, first, count, sink);
+                    }
+                }));
+            }
         }
         size_t small = 165u << 20;
         show("tiles 8 words + RANDOM gather 7 x16B/word from 165 MB, 32 waves/CU", timeIt([&] { hipLaunchKernelGGL(fill_tiles_gather, dim3(cus * 4), dim3(512), 0, 0, out, n4, 8u, src, small / 16, 7u, 75u, 1, sink); }));

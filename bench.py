@@ -43,6 +43,8 @@ def parse_args():
     parser.add_argument('--workload', default='glove840b-300d-4bit-fullvocab', choices=sorted(WORKLOADS))
     parser.add_argument('--cache-dir', default=os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench'))
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--secondary', action='store_true',
+                        help='also time the 100k-row batch of configs[1] (extra launches of the same kernel)')
     return parser.parse_args()
 
 
@@ -176,7 +178,7 @@ def main():
     # BASELINE.json configs[1] on the same model: a 100 000-row random batch with 1 % misses
     # (rank 0 only, outside the timed region; kernel time from HIP events).
     secondary = None
-    if batch is None:
+    if batch is None and args.secondary:
         rng = np.random.default_rng(11)
         small_host = rng.integers(0, count, size=100000).astype(np.uint32)
         small_host[rng.integers(0, 100000, size=1000)] = 0xFFFFFFFF

@@ -23,6 +23,16 @@ def test_header_declares_the_expected_entry_points():
     ])
 
 
+def test_header_is_plain_c_and_cxx():
+    import subprocess
+    header = os.path.join(REPO, 'include', 'memb_hip.h')
+    for compiler, flags in (('gcc', ['-std=c99', '-pedantic', '-Wall', '-Werror', '-x', 'c']),
+                            ('g++', ['-std=c++14', '-Wall', '-Werror', '-x', 'c++'])):
+        result = subprocess.run([compiler, *flags, '-fsyntax-only', header], stdout=subprocess.PIPE,
+                                stderr=subprocess.STDOUT, text=True)
+        assert result.returncode == 0, result.stdout
+
+
 def test_library_exports_every_declared_symbol(native):
     library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
     for name in declared_functions():
@@ -61,3 +71,27 @@ def test_error_reporting_without_compute(native):
                     size_offsets.ctypes.data, 2, centroids.ctypes.data, 2, 0)
         assert library.memb_hip_ctx_create_trained(ctypes.byref(context), 0, ctypes.byref(desc)) == 2  # ERR_DEVICE
         assert b'no HIP device' in library.memb_hip_last_error()
+
+
+@pytest.mark.gpu
+def test_pure_c_client(native, tmp_path):
+    # a C99 program linked against the shared library: no Python, torch or C++ in the loop
+    import subprocess
+    library_dir = os.path.dirname(native.HIP_LIBRARY_PATH)
+    binary = str(tmp_path / 'client')
+    build = subprocess.run(
+        ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'),
+         os.path.join(REPO, 'tests', 'cabi', 'client.c'), '-L', library_dir, '-lmemb_hip',
+         '-Wl,-rpath,' + library_dir, '-o', binary],
+        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    run = subprocess.run([binary], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout
+    lines = [line for line in run.stdout.splitlines() if line and not line.startswith('/opt/amdgpu')]
+    assert lines[:4] == [
+        '9 2.25 2.25 -1.5 -1.5 9',      # row 1 = 1100b
+        '9 0 0 0 0 9',                  # missing row -> zeros, neighbours untouched
+        '9 -1.5 2.25 -1.5 2.25 9',      # row 0 = 0101b
+        '9 2.25 2.25 -1.5 -1.5 9',
+    ], run.stdout
+    assert lines[4] == 'error: ld must be at least col_off + dim'

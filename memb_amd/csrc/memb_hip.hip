@@ -120,11 +120,6 @@ __device__ __forceinline__ uint32_t fastDivide(uint32_t q, uint32_t magic, uint3
     return magic ? __umulhi(q, magic) : q / d;
 }
 
-__device__ __forceinline__ uint32_t byteSwap(uint32_t v)
-{
-    return __builtin_bswap32(v);
-}
-
 // Orders this wave's LDS writes before its later LDS reads (and vice versa).
 // LDS operations of one wave execute in order; the fence makes the compiler
 // wait for them and keeps it from moving accesses across.
@@ -1348,7 +1343,7 @@ int copyToDevice(void* dst, const void* src, size_t bytes)
     }
     hipError_t status = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     if (registered) {
-        hipHostUnregister(const_cast<void*>(src));
+        (void)hipHostUnregister(const_cast<void*>(src));
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("hipMemcpy to device: ") + hipGetErrorString(status));

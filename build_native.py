@@ -50,7 +50,8 @@ def _hipcc():
 
 
 def build_hip_library(force=False):
-    sources = [os.path.join(CSRC, name) for name in ('memb_hip.hip', 'codec.h', 'wire.h')]
+    sources = [os.path.join(CSRC, name) for name in
+               ('memb_hip.hip', 'hip_device_common.h', 'hip_trained_kernels.h', 'hip_rowwise_kernels.h', 'codec.h', 'wire.h')]
     sources.append(os.path.join(INCLUDE, 'memb_hip.h'))
     if force or _newer(HIP_LIBRARY, sources):
         _run([

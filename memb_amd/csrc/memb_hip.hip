@@ -63,807 +63,10 @@ int fail(int code, const std::string& message)
         }                                                                                        \
     } while (0)
 
-// ---------------------------------------------------------------------------
-// decode_trained
-// ---------------------------------------------------------------------------
-
-struct TrainedParams {
-    const uint32_t* rows;        // batch -> row id; null = identity (row = batch position)
-    float* out;
-    unsigned long long n;
-    unsigned long long ld;
-    unsigned long long colOff;
-    const uint4* streams;           // re-packed bitstreams: big-endian dwords, one 16-byte aligned run per row
-    const uint32_t* streamStarts;   // [nRows + 1] first 16-byte piece of each row's run
-    const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
-    uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
-    const uint32_t* table;          // 8-byte entries, see TableEntry
-    const float* codebook;          // 256 centroids, or 256 centroid pairs (FAST)
-    unsigned long long nRows;
-    uint32_t tableDwords;     // multiple of 4
-    uint32_t codebookDwords;  // 256 or 512
-    uint32_t rootBits;
-    uint32_t dim;
-    uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
-    uint32_t slotMagic;       // fastDivide magic for slotDwords / 4
-    uint32_t lanesPerWord;    // G
-    uint32_t laneMagic;       // fastDivide magic for G
-    uint32_t wordsPerWave;    // 64 / G
-    uint32_t segmentSymbols;  // S, multiple of the decode group (4, or 8 when FAST)
-    uint32_t keyRowBytes;     // bytes per word in the symbol tile
-    uint32_t keyTileDwords;   // dwords of the symbol tile of one wave
-    uint32_t pieceMagic;      // fastDivide magic for dim / 4 (vector output)
-    uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
-    uint32_t indexSegmentSymbols;
-    uint32_t debugFlags;      // measurement only (MEMB_HIP_DEBUG): 1 = skip decode, 2 = skip output
-    uint32_t accumulate;      // epilogue: add to what the output already holds ...
-    float divisor;            // ... and / or divide by this (0 = no division)
-};
-
-enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3 };
-
-// Device form of one lookup-table entry (logical layout: memb::DecodeTable).
-//   x: leaf    -> code length                       (bits 8..31 zero)
-//      pointer -> TABLE_POINTER_FLAG | extra bits | first sub-table entry << 8
-//   y: leaf    -> the symbol replicated into every byte (or every nibble, FAST),
-//                 so that packing symbol s of a group is one AND-OR with a
-//                 constant mask
-struct TableEntry {
-    uint32_t x;
-    uint32_t y;
-};
-
-// q / d with a host-computed magic = ceil(2^32 / d) (exact while q * d < 2^32);
-// magic == 0 means "no magic" (d == 1, or the range is too large): plain division.
-__device__ __forceinline__ uint32_t fastDivide(uint32_t q, uint32_t magic, uint32_t d)
-{
-    return magic ? __umulhi(q, magic) : q / d;
-}
-
-// Orders this wave's LDS writes before its later LDS reads (and vice versa).
-// LDS operations of one wave execute in order; the fence makes the compiler
-// wait for them and keeps it from moving accesses across.
-__device__ __forceinline__ void waveLdsFence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Single-lane-op IEEE fp32 add / sub / mul. Written as instructions because the
-// optimiser otherwise pairs neighbouring operations into v_pk_add_f32 /
-// v_pk_mul_f32, and the packed forms flush subnormal values on gfx950 (measured:
-// min = 1e-40 came back as 0), which would break bit parity with the CPU.
-__device__ __forceinline__ float addRn(float a, float b)
-{
-    float r;
-    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float subRn(float a, float b)
-{
-    float r;
-    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float mulRn(float a, float b)
-{
-    float r;
-    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// Epilogue of ReadersUnion 'average' (reference python/memb/readers_union.py:18:
-// numpy.mean over the readers = fp32 sums in reader order, then one division
-// by the reader count): later readers add to what earlier ones stored, the last
-// one divides. Same operations and order as numpy, so the result is bit-identical.
-__device__ __forceinline__ float epilogue(float value, const float* destination, uint32_t accumulate, float divisor)
-{
-    if (accumulate) {
-        value = addRn(*destination, value);
-    }
-    if (divisor != 0.f) {
-        value = __fdiv_rn(value, divisor);
-    }
-    return value;
-}
-
-__device__ __forceinline__ float4 epilogue4(float4 value, const float* destination, uint32_t accumulate, float divisor)
-{
-    if (accumulate) {
-        const float4 old = *reinterpret_cast<const float4*>(destination);
-        value.x = addRn(old.x, value.x);
-        value.y = addRn(old.y, value.y);
-        value.z = addRn(old.z, value.z);
-        value.w = addRn(old.w, value.w);
-    }
-    if (divisor != 0.f) {
-        value.x = __fdiv_rn(value.x, divisor);
-        value.y = __fdiv_rn(value.y, divisor);
-        value.z = __fdiv_rn(value.z, divisor);
-        value.w = __fdiv_rn(value.w, divisor);
-    }
-    return value;
-}
-
-// ---- building blocks shared by the one-shot and the persistent kernel ----
-
-struct LaneRole {
-    uint32_t word;      // word of the tile this lane works on
-    uint32_t segment;   // segment of that word
-    bool spare;         // 64 % G lanes at the top: decode word 0's slot, store nothing
-};
-
-__device__ __forceinline__ LaneRole laneRole(const TrainedParams& p, uint32_t lane)
-{
-    LaneRole role;
-    const uint32_t laneWord = fastDivide(lane, p.laneMagic, p.lanesPerWord);
-    role.segment = lane - laneWord * p.lanesPerWord;
-    role.spare = laneWord >= p.wordsPerWave;
-    role.word = role.spare ? 0 : laneWord;
-    return role;
-}
-
-// Row id of the lane's word in tile `tile`; MISSING for padding lanes and past the batch end.
-__device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned long long tile, const LaneRole& role)
-{
-    const unsigned long long index = tile * p.wordsPerWave + role.word;
-    if (role.spare || index >= p.n) {
-        return MISSING;
-    }
-    return p.rows ? p.rows[index] : static_cast<uint32_t>(index);
-}
-
-struct WordMeta {
-    uint32_t row;
-    uint32_t start;         // first 16-byte piece of the word's bitstream
-    uint32_t segmentBits;   // bit offset of the lane's segment inside that stream
-};
-
-__device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_t row, const LaneRole& role)
-{
-    WordMeta meta;
-    meta.row = row;
-    meta.start = 0;
-    meta.segmentBits = 0;
-    if (row < p.nRows) {
-        meta.start = p.streamStarts[row];
-        if (role.segment > 0) {
-            meta.segmentBits =
-                p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1];
-        }
-    }
-    return meta;
-}
-
-constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
-
-// Named members, not an array: indexed storage ends up in scratch memory, and a
-// load whose result goes to scratch is waited for at once, which would undo the prefetch.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain SSA value (HIP's uint4 is a class)
-
-struct StreamRegisters {
-    u32x4 r0, r1, r2, r3;
-};
-
-// One round of the tile's bitstream copy: piece q = (word, 16-byte piece) -> one lane.
-// A slot's worth of pieces is read from each row's start (running into the next
-// rows' streams, which is harmless; the array ends with a guard of one slot).
-// Absent words read the start of the array and never emit what they decode;
-// lanes past the tile's last piece re-read its last piece.
-__device__ __forceinline__ void issueStreamLoad(
-    const TrainedParams& p, uint32_t sourceStart, uint32_t lane, uint32_t round, u32x4& destination)
-{
-    const uint32_t piecesPerWord = p.slotDwords / 4;
-    const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-    if (round * WAVE < totalPieces) {   // wave-uniform
-        const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
-        const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
-        const uint32_t piece = q - w * piecesPerWord;
-        const uint32_t wordStart = __shfl(sourceStart, w * p.lanesPerWord);
-        destination = reinterpret_cast<const u32x4*>(p.streams)[static_cast<unsigned long long>(wordStart) + piece];
-    }
-}
-
-__device__ __forceinline__ void issueStreamLoads(
-    const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, StreamRegisters& v)
-{
-    const uint32_t sourceStart = meta.row < p.nRows ? meta.start : 0u;
-    issueStreamLoad(p, sourceStart, lane, firstRound + 0, v.r0);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 1, v.r1);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 2, v.r2);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 3, v.r3);
-}
-
-// Into the LDS slots (already big-endian dwords, so the decoder extracts bits with plain shifts).
-__device__ __forceinline__ void writeStream(
-    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t round, const u32x4& value)
-{
-    const uint32_t piecesPerWord = p.slotDwords / 4;
-    const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-    const uint32_t q = round * WAVE + lane;
-    if (q < totalPieces) {
-        const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
-        const uint32_t piece = q - w * piecesPerWord;
-        *reinterpret_cast<u32x4*>(slots + w * p.slotDwords + 4 * piece) = value;
-    }
-}
-
-__device__ __forceinline__ void writeStreams(
-    const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t firstRound, const StreamRegisters& v)
-{
-    writeStream(p, slots, lane, firstRound + 0, v.r0);
-    writeStream(p, slots, lane, firstRound + 1, v.r1);
-    writeStream(p, slots, lane, firstRound + 2, v.r2);
-    writeStream(p, slots, lane, firstRound + 3, v.r3);
-}
-
-// FAST: codebook of at most 16 centroids and no code longer than 8 bits (2- and
-// 4-bit models). Eight symbols are decoded per 64-bit window (7 * 8 consumed bits
-// + 8 looked-ahead bits fit), symbols are staged as nibbles, and the output phase
-// fetches two centroids per LDS read from a 256-entry table of pairs.
-//
-// Decode the lane's segment from its word's LDS slot into the symbol tile
-// (or, OUT_INDEX, record segment start positions).
-template <bool HAS_SUB, int MODE, bool FAST>
-__device__ __forceinline__ void decodeSegment(
-    const TrainedParams& p, const TableEntry* tableLds, const uint32_t* slots, uint32_t* keyTile,
-    const LaneRole& role, const WordMeta& meta)
-{
-    constexpr int GROUP = FAST ? 8 : 4;
-    constexpr uint32_t KEY_BITS = FAST ? 4 : 8;
-    constexpr uint32_t KEY_MASK = FAST ? 0xFu : 0xFFu;
-
-    const bool present = meta.row < p.nRows;
-    const uint32_t* slot = slots + role.word * p.slotDwords;
-    uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
-    const uint32_t lastWindow = p.slotDwords - 3;
-    const uint32_t rootShift = 32 - p.rootBits;
-    uint32_t bitPos = meta.segmentBits;   // streams start on a slot boundary
-    // byte position of this lane's first group inside the symbol tile
-    uint32_t keyOffset = role.word * p.keyRowBytes + role.segment * (p.segmentSymbols * KEY_BITS / 8);
-    const uint32_t keyRowEnd = role.spare ? 0 : (role.word + 1) * p.keyRowBytes;
-    const uint32_t absentFill = present ? 0u : 0xFFFFFFFFu;   // byte keys: ZERO_KEY everywhere
-    uint32_t nextIndexSymbol = p.indexSegmentSymbols;
-    uint32_t indexSlot = 0;
-
-    for (uint32_t j = 0; j < p.segmentSymbols; j += GROUP) {
-        if (MODE == OUT_INDEX) {
-            // one lane per word here; record where every indexSegmentSymbols-th symbol starts
-            if (j == nextIndexSymbol) {
-                if (present && indexSlot + 1 < p.indexLanes) {
-                    p.segmentIndexOut[static_cast<unsigned long long>(meta.row) * (p.indexLanes - 1) + indexSlot] =
-                        static_cast<uint16_t>(bitPos);
-                }
-                ++indexSlot;
-                nextIndexSymbol += p.indexSegmentSymbols;
-            }
-        }
-        const uint32_t d = min(bitPos >> 5, lastWindow);
-        const uint32_t shift = bitPos & 31;
-        const uint32_t w0 = slot[d];
-        const uint32_t w1 = slot[d + 1];
-        const uint32_t w2 = slot[d + 2];
-        // 64 valid bits starting at the current bit position, MSB first.
-        unsigned long long window = ((static_cast<unsigned long long>(w0) << 32) | w1) << shift;
-        window |= static_cast<uint32_t>(static_cast<unsigned long long>(w2) >> (32 - shift));
-        uint32_t keys = 0;
-        uint32_t lengths = 0;
-#pragma unroll
-        for (int s = 0; s < GROUP; ++s) {
-            TableEntry entry = tableLds[static_cast<uint32_t>(window >> 32) >> rootShift];
-            if (HAS_SUB) {
-                if (entry.x & memb::TABLE_POINTER_FLAG) {
-                    const uint32_t subBits = entry.x & 0xff;
-                    const uint32_t base = (entry.x & ~memb::TABLE_POINTER_FLAG) >> 8;
-                    const uint32_t subIndex =
-                        static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
-                    entry = tableLds[base + subIndex];
-                }
-            }
-            window <<= (entry.x & 63);
-            lengths += entry.x;
-            keys |= entry.y & (KEY_MASK << (KEY_BITS * s));
-        }
-        bitPos += lengths;
-        if (MODE != OUT_INDEX) {
-            keys |= absentFill;
-            if (FAST) {
-                // rows are dim / 2 bytes: 2-byte aligned only
-                if (keyOffset + 2 <= keyRowEnd) {
-                    *reinterpret_cast<uint16_t*>(keyBytes + keyOffset) = static_cast<uint16_t>(keys);
-                }
-                if (keyOffset + 4 <= keyRowEnd) {
-                    *reinterpret_cast<uint16_t*>(keyBytes + keyOffset + 2) = static_cast<uint16_t>(keys >> 16);
-                }
-            } else {
-                if (keyOffset + 4 <= keyRowEnd) {
-                    *reinterpret_cast<uint32_t*>(keyBytes + keyOffset) = keys;
-                }
-            }
-            keyOffset += 4;
-        }
-    }
-}
-
-// Symbol tile -> fp32 rows: codebook gather and row-contiguous stores.
-template <int MODE, bool FAST>
-__device__ __forceinline__ void outputTile(
-    const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
-    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
-{
-    const float* centroidLds = reinterpret_cast<const float*>(codebookLds);
-    const float2* pairLds = reinterpret_cast<const float2*>(codebookLds);
-    const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
-
-    // Nibble keys have no spare code for "absent" (byte keys use ZERO_KEY): rows of
-    // absent words are zeroed after the tile is written -- or, when an epilogue
-    // reads the destination, their pieces go through it as zeros.
-    const bool hasEpilogue = p.accumulate || p.divisor != 0.f;   // wave-uniform
-    unsigned long long absent = 0;
-    if (FAST) {
-        absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
-    }
-    const bool checkWords = FAST && hasEpilogue && absent != 0;
-
-    if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
-        // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
-        // (byte keys: rows of dim bytes; nibble keys: rows of dim / 2 bytes).
-        // BURST pieces per lane are gathered first and then stored back to back, so a
-        // tile reaches memory as one burst of consecutive KiBs rather than one KiB per
-        // LDS round trip.
-        constexpr int BURST = 5;
-        const uint32_t piecesPerWord = p.dim / 4;
-        const uint32_t pieces = tileWords * piecesPerWord;
-        float* tileOut = p.out + tileBase * p.ld + p.colOff;
-        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
-            uint32_t k[BURST];
-            float4 f[BURST];
-#pragma unroll
-            for (int u = 0; u < BURST; ++u) {
-                const uint32_t q = min(q0 + WAVE * u, pieces - 1);
-                k[u] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[q] : keyTile[q];
-            }
-#pragma unroll
-            for (int u = 0; u < BURST; ++u) {
-                if (FAST) {
-                    const float2 a = pairLds[k[u] & 0xff];
-                    const float2 b = pairLds[k[u] >> 8];
-                    f[u] = make_float4(a.x, a.y, b.x, b.y);
-                } else {
-                    f[u].x = centroidLds[k[u] & 0xff];
-                    f[u].y = centroidLds[(k[u] >> 8) & 0xff];
-                    f[u].z = centroidLds[(k[u] >> 16) & 0xff];
-                    f[u].w = centroidLds[k[u] >> 24];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BURST; ++u) {
-                const uint32_t q = q0 + WAVE * u;
-                if (q < pieces) {
-                    float* destination;
-                    if (MODE == OUT_FLAT && !checkWords) {
-                        destination = tileOut + 4 * static_cast<size_t>(q);
-                    } else {
-                        const uint32_t w = fastDivide(q, p.pieceMagic, piecesPerWord);
-                        const uint32_t c = q - w * piecesPerWord;
-                        destination = tileOut + w * p.ld + 4 * c;
-                        if (checkWords && ((absent >> (w * p.lanesPerWord)) & 1)) {
-                            f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-                    if (hasEpilogue) {   // off the common path
-                        f[u] = epilogue4(f[u], destination, p.accumulate, p.divisor);
-                    }
-                    *reinterpret_cast<float4*>(destination) = f[u];
-                }
-            }
-        }
-    } else {
-        const uint32_t total = tileWords * p.dim;
-        for (uint32_t q = lane; q < total; q += WAVE) {
-            const uint32_t w = q / p.dim;
-            const uint32_t c = q - w * p.dim;
-            float value;
-            if (FAST) {
-                const uint32_t k = keyBytes[w * p.keyRowBytes + (c >> 1)];
-                value = pairLds[(k >> (4 * (c & 1))) & 15].x;
-                if (checkWords && ((absent >> (w * p.lanesPerWord)) & 1)) {
-                    value = 0.f;
-                }
-            } else {
-                value = centroidLds[keyBytes[w * p.keyRowBytes + c]];
-            }
-            float* destination = p.out + (tileBase + w) * p.ld + p.colOff + c;
-            if (hasEpilogue) {
-                value = epilogue(value, destination, p.accumulate, p.divisor);
-            }
-            *destination = value;
-        }
-    }
-
-    if (FAST && !hasEpilogue) {
-        // zero the rows of absent words (same wave, same addresses: program order holds)
-        while (absent) {
-            const uint32_t w = fastDivide(__ffsll(static_cast<long long>(absent)) - 1, p.laneMagic, p.lanesPerWord);
-            absent &= absent - 1;
-            float* rowOut = p.out + (tileBase + w) * p.ld + p.colOff;
-            if (MODE == OUT_SCALAR) {
-                for (uint32_t c = lane; c < p.dim; c += WAVE) {
-                    rowOut[c] = 0.f;
-                }
-            } else {
-                for (uint32_t c = lane; c < p.dim / 4; c += WAVE) {
-                    reinterpret_cast<float4*>(rowOut)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-    }
-}
-
-struct WaveLds {
-    const TableEntry* table;
-    const uint32_t* codebook;
-    uint32_t* slots;
-    uint32_t* keyTile;
-};
-
-// LDS layout: lookup table | codebook | per wave { bitstream slots | symbol tile }.
-// Loads table and codebook; ends with a block barrier.
-template <int MODE>
-__device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* lds)
-{
-    const uint32_t wave = threadIdx.x / WAVE;
-    uint32_t* codebookLds = lds + p.tableDwords;
-    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
-    WaveLds result;
-    result.table = reinterpret_cast<const TableEntry*>(lds);
-    result.codebook = codebookLds;
-    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
-    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
-
-    for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
-        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
-    }
-    if (MODE != OUT_INDEX) {
-        for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
-            codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
-        }
-    }
-    __syncthreads();
-    return result;
-}
-
-// One-shot kernel: one tile per wavefront. Used to build the segment index
-// (OUT_INDEX) and for tiles too wide for the persistent kernel's registers.
-template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained(TrainedParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const WaveLds mem = setUpLds<MODE>(p, lds);
-
-    const unsigned long long tile =
-        static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    const unsigned long long tileBase = tile * p.wordsPerWave;
-    if (tileBase >= p.n) {
-        return;
-    }
-    const uint32_t tileWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-
-    const LaneRole role = laneRole(p, lane);
-    const WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
-
-    const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
-    for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
-        StreamRegisters v;
-        issueStreamLoads(p, meta, lane, round, v);
-        writeStreams(p, mem.slots, lane, round, v);
-    }
-    waveLdsFence();
-
-    decodeSegment<HAS_SUB, MODE, FAST>(p, mem.table, mem.slots, mem.keyTile, role, meta);
-    if (MODE == OUT_INDEX) {
-        return;
-    }
-    waveLdsFence();
-    outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
-}
-
-// Persistent kernel: every wavefront walks tiles wave, wave + W, wave + 2W, ...
-// and keeps three tiles' worth of loads in flight, so that no decode waits for
-// global memory: while tile t is decoded, the bitstream bytes of tile t + 1 sit
-// in registers, the offsets / segment positions of tile t + 2 and the row ids
-// of tile t + 3 are on their way. Each of those hops depends on the previous
-// one (row id -> offset -> stream bytes); issued back to back they are what a
-// one-tile wavefront spends most of its life waiting for.
-template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained_persistent(TrainedParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const WaveLds mem = setUpLds<MODE>(p, lds);
-
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
-    if (tile >= tiles) {
-        return;
-    }
-    const LaneRole role = laneRole(p, lane);
-
-    // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
-    uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
-    WordMeta meta0 = loadWordMeta(p, loadTileRow(p, tile, role), role);
-    WordMeta meta1 = loadWordMeta(p, loadTileRow(p, tile + stride, role), role);
-    WordMeta metaLoading = loadWordMeta(p, loadTileRow(p, tile + 2 * stride, role), role);
-    StreamRegisters streams;
-    issueStreamLoads(p, meta0, lane, 0, streams);
-    writeStreams(p, mem.slots, lane, 0, streams);
-    issueStreamLoads(p, meta1, lane, 0, streams);
-    waveLdsFence();
-
-    // Invariant at the top, for the current tile t:
-    //   LDS slots hold the bitstreams of t;
-    //   in flight since the end of the previous round: `streams` = stream bytes of t + 1,
-    //   `metaLoading` = offsets of t + 2, `rowLoading` = row ids of t + 3.
-    // In-flight registers are touched at ONE point per round, right after the
-    // decode (which gave them a whole decode to land) and before this round's
-    // stores are issued, so that the wait there is only for loads; the new
-    // loads are the last memory instructions of the round.
-    for (; tile < tiles; tile += stride) {
-        const unsigned long long tileBase = tile * p.wordsPerWave;
-        const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-
-        if (!(p.debugFlags & 1)) {
-            decodeSegment<HAS_SUB, MODE, FAST>(p, mem.table, mem.slots, mem.keyTile, role, meta0);
-        }
-        waveLdsFence();
-
-        // consume point
-        writeStreams(p, mem.slots, lane, 0, streams);   // bitstreams of t + 1 replace those of t
-        // (copies pinned here: left to the register allocator they move to the loop
-        // header, and the wait for the loads moves with them)
-        WordMeta meta2;
-        uint32_t row3;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
-        __builtin_amdgcn_sched_barrier(0);
-
-        if (!(p.debugFlags & 2)) {
-            outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta0.row < p.nRows);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // next round of loads; each uses what the previous round fetched
-        issueStreamLoads(p, meta2, lane, 0, streams);          // stream bytes of t + 2
-        metaLoading = loadWordMeta(p, row3, role);              // offsets of t + 3
-        rowLoading = loadTileRow(p, tile + 4 * stride, role);   // row ids of t + 4
-        meta0 = meta1;
-        meta1 = meta2;
-        waveLdsFence();
-    }
-}
-
-// Staging-time re-pack of the file's bitstreams (byte aligned, insertion order,
-// reference src/trained_compression.cpp:65-71) into the layout the decoder
-// reads: row r's stream starts at piece streamStarts[r], 16-byte aligned, in
-// row (= sorted key) order, stored as big-endian dwords. One wavefront per row.
-__global__ void repack_streams(
-    const uint8_t* packed, unsigned long long packedBytes, const uint32_t* valueOffsets, const uint32_t* streamStarts,
-    unsigned long long nRows, uint4* streams)
-{
-    const unsigned long long row = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) / WAVE;
-    if (row >= nRows) {
-        return;
-    }
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t first = streamStarts[row];
-    const uint32_t pieces = streamStarts[row + 1] - first;
-    const unsigned long long source = valueOffsets[row];
-    for (uint32_t piece = lane; piece < pieces; piece += WAVE) {
-        uint32_t dwords[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t value = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const unsigned long long at = source + 16ull * piece + 4 * k + b;
-                value = (value << 8) | (at < packedBytes ? packed[at] : 0u);
-            }
-            dwords[k] = value;
-        }
-        streams[static_cast<unsigned long long>(first) + piece] = make_uint4(dwords[0], dwords[1], dwords[2], dwords[3]);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// dequant_uniform / gather_full
-// ---------------------------------------------------------------------------
-
-struct UniformParams {
-    uint32_t accumulate;
-    float divisor;
-    const uint32_t* rows;
-    float* out;
-    unsigned long long n;
-    unsigned long long ld;
-    unsigned long long colOff;
-    const uint8_t* values;   // dense [nRows][dim]
-    const float2* minMax;    // [nRows]
-    unsigned long long nRows;
-    uint32_t dim;
-    uint32_t wordsPerBlock;
-    uint32_t pieceMagic;     // ceil(2^32 / (dim / 4)), vector path
-    float levels;
-};
-
-// reference src/uniform_compression.cpp:70-71, evaluated left to right in fp32:
-// sub, mul, div, add -- each correctly rounded, nothing fused, subnormals kept.
-__device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels)
-{
-    const float scaled = mulRn(range, static_cast<float>(v));
-    return addRn(minValue, __fdiv_rn(scaled, levels));
-}
-
-constexpr uint32_t ROWWISE_MAX_WORDS = 64;   // words per block of the row-wise kernels
-constexpr int ROWWISE_BATCH = 4;             // 16-byte pieces a thread keeps in flight
-
-// Row-wise kernels (uniform, full): a block first stages the row ids (and the
-// per-row constants) of its words in LDS -- one dependent pair of global loads
-// per block instead of per piece -- then every thread keeps ROWWISE_BATCH value
-// loads in flight before it converts and stores.
-template <bool VEC4>
-__global__ void dequant_uniform(UniformParams p)
-{
-    __shared__ uint32_t rowLds[ROWWISE_MAX_WORDS];
-    __shared__ float2 minMaxLds[ROWWISE_MAX_WORDS];
-    const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
-    const uint32_t blockWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
-    if (threadIdx.x < blockWords) {
-        const uint32_t row = p.rows[blockBase + threadIdx.x];
-        rowLds[threadIdx.x] = row;
-        minMaxLds[threadIdx.x] = row < p.nRows ? p.minMax[row] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-
-    if (VEC4) {
-        const uint32_t piecesPerWord = p.dim / 4;
-        const uint32_t pieces = blockWords * piecesPerWord;
-        for (uint32_t q0 = threadIdx.x; q0 < pieces; q0 += blockDim.x * ROWWISE_BATCH) {
-            uint32_t word[ROWWISE_BATCH];
-            uint32_t column[ROWWISE_BATCH];
-            uint32_t packed[ROWWISE_BATCH];
-#pragma unroll
-            for (int u = 0; u < ROWWISE_BATCH; ++u) {
-                const uint32_t q = min(q0 + u * blockDim.x, pieces - 1);
-                word[u] = fastDivide(q, p.pieceMagic, piecesPerWord);
-                column[u] = q - word[u] * piecesPerWord;
-                const uint32_t row = rowLds[word[u]];
-                packed[u] = 0;
-                if (row < p.nRows) {
-                    packed[u] = *reinterpret_cast<const uint32_t*>(
-                        p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ROWWISE_BATCH; ++u) {
-                if (q0 + u * blockDim.x < pieces) {
-                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rowLds[word[u]] < p.nRows) {
-                        const float2 mm = minMaxLds[word[u]];
-                        const float range = subRn(mm.y, mm.x);
-                        f.x = dequant(mm.x, range, packed[u] & 0xff, p.levels);
-                        f.y = dequant(mm.x, range, (packed[u] >> 8) & 0xff, p.levels);
-                        f.z = dequant(mm.x, range, (packed[u] >> 16) & 0xff, p.levels);
-                        f.w = dequant(mm.x, range, packed[u] >> 24, p.levels);
-                    }
-                    float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
-                    if (p.accumulate || p.divisor != 0.f) {
-                        f = epilogue4(f, dst, p.accumulate, p.divisor);
-                    }
-                    *reinterpret_cast<float4*>(dst) = f;
-                }
-            }
-        }
-    } else {
-        const uint32_t total = blockWords * p.dim;
-        for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
-            const uint32_t w = q / p.dim;
-            const uint32_t c = q - w * p.dim;
-            const uint32_t row = rowLds[w];
-            float f = 0.f;
-            if (row < p.nRows) {
-                const float2 mm = minMaxLds[w];
-                const float range = subRn(mm.y, mm.x);
-                f = dequant(mm.x, range, p.values[static_cast<unsigned long long>(row) * p.dim + c], p.levels);
-            }
-            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + c;
-            if (p.accumulate || p.divisor != 0.f) {
-                f = epilogue(f, dst, p.accumulate, p.divisor);
-            }
-            *dst = f;
-        }
-    }
-}
-
-struct FullParams {
-    uint32_t accumulate;
-    float divisor;
-    const uint32_t* rows;
-    float* out;
-    unsigned long long n;
-    unsigned long long ld;
-    unsigned long long colOff;
-    const float* values;     // dense [nRows][dim]
-    unsigned long long nRows;
-    uint32_t dim;
-    uint32_t wordsPerBlock;
-    uint32_t pieceMagic;
-};
-
-template <bool VEC4>
-__global__ void gather_full(FullParams p)
-{
-    __shared__ uint32_t rowLds[ROWWISE_MAX_WORDS];
-    const unsigned long long blockBase = static_cast<unsigned long long>(blockIdx.x) * p.wordsPerBlock;
-    const uint32_t blockWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerBlock), p.n - blockBase));
-    if (threadIdx.x < blockWords) {
-        rowLds[threadIdx.x] = p.rows[blockBase + threadIdx.x];
-    }
-    __syncthreads();
-    if (VEC4) {
-        const uint32_t piecesPerWord = p.dim / 4;
-        const uint32_t pieces = blockWords * piecesPerWord;
-        for (uint32_t q0 = threadIdx.x; q0 < pieces; q0 += blockDim.x * ROWWISE_BATCH) {
-            uint32_t word[ROWWISE_BATCH];
-            uint32_t column[ROWWISE_BATCH];
-            float4 f[ROWWISE_BATCH];
-#pragma unroll
-            for (int u = 0; u < ROWWISE_BATCH; ++u) {
-                const uint32_t q = min(q0 + u * blockDim.x, pieces - 1);
-                word[u] = fastDivide(q, p.pieceMagic, piecesPerWord);
-                column[u] = q - word[u] * piecesPerWord;
-                const uint32_t row = rowLds[word[u]];
-                f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < p.nRows) {
-                    f[u] = *reinterpret_cast<const float4*>(
-                        p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ROWWISE_BATCH; ++u) {
-                if (q0 + u * blockDim.x < pieces) {
-                    float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
-                    if (p.accumulate || p.divisor != 0.f) {
-                        f[u] = epilogue4(f[u], dst, p.accumulate, p.divisor);
-                    }
-                    *reinterpret_cast<float4*>(dst) = f[u];
-                }
-            }
-        }
-    } else {
-        const uint32_t total = blockWords * p.dim;
-        for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
-            const uint32_t w = q / p.dim;
-            const uint32_t c = q - w * p.dim;
-            const uint32_t row = rowLds[w];
-            float f = row < p.nRows ? p.values[static_cast<unsigned long long>(row) * p.dim + c] : 0.f;
-            float* dst = p.out + (blockBase + w) * p.ld + p.colOff + c;
-            if (p.accumulate || p.divisor != 0.f) {
-                f = epilogue(f, dst, p.accumulate, p.divisor);
-            }
-            *dst = f;
-        }
-    }
-}
+// Device code (all inside this anonymous namespace).
+#include "hip_device_common.h"
+#include "hip_trained_kernels.h"
+#include "hip_rowwise_kernels.h"
 
 // ceil(2^32 / d) for fastDivide: exact for every q <= maxQ when maxQ * d < 2^32.
 // Returns 0 (plain division) for d == 1, where the magic does not fit 32 bits,

@@ -364,3 +364,44 @@ def test_generic_path_on_a_small_codebook(native, make_model, monkeypatch):
     assert bits_equal(native.Reader(path).rows_embedding(rows), expected)
     monkeypatch.delenv('MEMB_HIP_NO_FAST')
     assert bits_equal(native.Reader(path).rows_embedding(rows), expected)
+
+
+def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
+    """Seeded sweep: random dimension, vocabulary, storage, bit width, lanes per word, batch make-up,
+    output stride / column offset -- HIP path vs CPU checker, bit for bit."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        dim = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 20, 31, 32, 48, 63, 64, 96, 100, 128, 200, 257, 300, 512]))
+        count = int(rng.integers(1, 2500))
+        storage = str(rng.choice(['trained', 'trained', 'trained', 'uniform', 'full']))
+        bits = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))
+        scale = float(rng.choice([1e-3, 0.4, 50.0]))
+        if rng.random() < 0.5:
+            vectors = (rng.standard_normal((count, dim)) * scale).astype(np.float32)
+        else:
+            vectors = (rng.standard_t(3, size=(count, dim)) * scale).astype(np.float32)
+        words = ['t{}w{}'.format(trial, i) for i in rng.permutation(count)]
+        builder = native.Builder(dim, storage, bits)
+        builder.add_words(words, vectors)
+        path = tmp_path / 'r{}.bin'.format(trial)
+        builder.save(path)
+
+        monkeypatch.setenv('MEMB_HIP_LANES', str(int(rng.choice([1, 2, 3, 4, 8, 8, 16, 32]))))
+        monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(int(rng.random() < 0.7)))
+        monkeypatch.setenv('MEMB_HIP_ROOT_BITS', str(int(rng.choice([1, 2, 4, 8, 11, 12]))))
+        reader = native.Reader(path)
+        checker = oracle.OracleReader(str(path))
+
+        n = int(rng.choice([1, 2, 5, 64, 65, 300, 1500]))
+        batch = [words[i] for i in rng.integers(0, count, size=n)]
+        miss_rate = float(rng.choice([0.0, 0.1, 0.9]))
+        batch = [w if rng.random() >= miss_rate else w + '?' for w in batch]
+        expected = checker.batch_embedding(batch)
+        assert nan_aware_equal(reader.batch_embedding(batch), expected), (trial, dim, count, storage, bits)
+
+        pad = int(rng.choice([0, 1, 4, 5, 64]))
+        col_off = int(rng.choice([0, 1, 4, 8]))
+        wide = np.full((n, col_off + dim + pad), 3.25, dtype=np.float32)
+        reader.batch_embedding_into(batch, wide, col_off)
+        assert nan_aware_equal(wide[:, col_off:col_off + dim], expected), (trial, 'strided', dim, col_off, pad)
+        assert (np.delete(wide, np.s_[col_off:col_off + dim], axis=1) == 3.25).all()

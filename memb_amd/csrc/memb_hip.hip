@@ -1067,20 +1067,42 @@ int memb_hip_decode_rows(
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedOut), sliceWords * dim * sizeof(float)));
         ctx->stagedCapacity = sliceWords;
     }
-    // Pin the caller's output range for the duration of the call: a fresh host
-    // buffer is otherwise faulted in page by page behind the DMA engine (measured
-    // 10-17 GB/s against 53-57 GB/s pinned; registering 2.6 GB of untouched pages
-    // takes 0.11 s). Only for buffers of 32 MiB and more: those are mappings of
-    // their own (glibc's mmap threshold never exceeds 32 MiB), whereas smaller
-    // ones share heap pages with unrelated live data that must not be pinned and
-    // unpinned under it. Opt-in (MEMB_HIP_PIN_OUTPUT=1): one full GPU test run
-    // aborted while registration was on by default for >= 1 MiB buffers and the
-    // cause could not be established.
     const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    // A freshly allocated host buffer is faulted in page by page behind the DMA
+    // engine (measured 10-17 GB/s for 2.6 GB against ~55 GB/s once the pages
+    // exist). Touch the caller's output range first, on a few threads: every page
+    // gets one byte read and written back unchanged (the caller owns the buffer
+    // for the duration of the call, and with ld > dim the columns between rows
+    // must keep their contents).
     char* pinBase = reinterpret_cast<char*>(out + col_off);
     const size_t pinBytes = ((n - 1) * ld + dim) * sizeof(float);
+    if (pinBytes >= (size_t(8) << 20) && envUint("MEMB_HIP_PREFAULT", 1)) {
+        const size_t page = 4096;
+        const size_t threads = std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+        const size_t perThread = (pinBytes / threads + page) / page * page;
+        auto touch = [pinBase, pinBytes, page](size_t first, size_t last) {
+            for (size_t at = first; at < std::min(last, pinBytes); at += page) {
+                volatile char* byte = pinBase + at;
+                *byte = *byte;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads; ++t) {
+            pool.emplace_back(touch, t * perThread, (t + 1) * perThread);
+        }
+        touch(0, perThread);
+        for (auto& thread : pool) {
+            thread.join();
+        }
+        volatile char* lastByte = pinBase + pinBytes - 1;
+        *lastByte = *lastByte;
+    }
+    // Optionally also pin the range (MEMB_HIP_PIN_OUTPUT=1, buffers of 32 MiB and
+    // more, which are mappings of their own). Off by default: one full GPU test run
+    // aborted while registration was on for >= 1 MiB buffers (heap pages shared
+    // with unrelated live data) and the cause could not be established.
     bool pinned = false;
     if (pinBytes >= (size_t(32) << 20) && envUint("MEMB_HIP_PIN_OUTPUT", 0)) {
         hipError_t registered = hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault);
@@ -1131,7 +1153,7 @@ int memb_hip_decode_rows(
         (void)hipHostUnregister(pinBase);
     }
     if (verbose) {
-        std::fprintf(stderr, "memb_hip: decode_rows n=%zu pinned=%d register %.4fs copy+kernel %.4fs unregister %.4fs\n",
+        std::fprintf(stderr, "memb_hip: decode_rows n=%zu pinned=%d prefault/register %.4fs copy+kernel %.4fs unregister %.4fs\n",
                      n, int(pinned), t1 - t0, t2 - t1, now() - t2);
     }
     return result;

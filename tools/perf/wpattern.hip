@@ -112,6 +112,40 @@ __global__ void fill_tiles_range(float4* out, size_t n4, unsigned tileWords, con
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// persistent tiles + contiguous read per tile, plus a "touch ahead": every `ahead` tiles a wave touches, with ONE load
+// instruction per 64 lines, every 128-B line its next `ahead` tiles will read (bringing them into L2 / Infinity Cache)
+__global__ void fill_tiles_touch_ahead(float4* out, size_t n4, unsigned tileWords, const uint4* src, unsigned tileReadPieces,
+                                       unsigned ahead, unsigned* sink) {
+    unsigned lane = threadIdx.x & 63;
+    size_t wave = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    size_t waves = (size_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned tilePieces = tileWords * 75;
+    size_t tiles = (n4 + tilePieces - 1) / tilePieces;
+    unsigned linesPerTile = (tileReadPieces * 16 + 127) / 128 + 1;
+    unsigned acc = 0;
+    size_t iteration = 0;
+    for (size_t t = wave; t < tiles; t += waves, ++iteration) {
+        if (ahead && iteration % ahead == 0) {
+            // lines of tiles t + ahead*waves .. t + (2*ahead-1)*waves
+            for (unsigned l = lane; l < ahead * linesPerTile; l += 64) {
+                size_t tt = t + size_t(ahead + l / linesPerTile) * waves;
+                if (tt < tiles) {
+                    const unsigned* line = reinterpret_cast<const unsigned*>(src + tt * tileReadPieces) + 32 * (l % linesPerTile);
+                    acc += *line;
+                }
+            }
+        }
+        size_t start = t * tileReadPieces;
+        for (unsigned q = lane; q < tileReadPieces; q += 64) {
+            uint4 v = src[start + q];
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+        size_t base = t * tilePieces;
+        for (unsigned q = lane; q < tilePieces; q += 64)
+            if (base + q < n4) out[base + q] = make_float4(1, 2, 3, 4);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 template <typename F> float timeIt(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) f();
@@ -155,7 +189,11 @@ int main() {
             // chunked: per chunk a read-only touch kernel, then the tile kernel; source = 69 pieces (1104 B) per tile, 303 MB in all
             const unsigned tileRead = 69; const size_t tiles = (n4 + 599) / 600;
             uint4* big; CHECK(hipMalloc(&big, (tiles + 8) * tileRead * 16)); CHECK(hipMemset(big, 1, (tiles + 8) * tileRead * 16));
-            for (int chunks : {1, 4, 8, 12, 16, 24, 32}) for (int touch : {0, 1}) {
+            for (unsigned ahead : {0u, 1u, 2u, 4u, 6u, 8u, 12u}) for (int wavesPerCu : {16, 32}) {
+                char name[160]; snprintf(name, sizeof name, "TOUCH-AHEAD %2u tiles, %d waves/CU: tiles + contiguous 1104-B read per tile (303 MB source)", ahead, wavesPerCu);
+                show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles_touch_ahead, dim3(cus * wavesPerCu / 8), dim3(512), 0, 0, out, n4, 8u, big, tileRead, ahead, sink); }));
+            }
+            for (int chunks : {1, 12}) for (int touch : {0, 1}) {
                 char name[160]; snprintf(name, sizeof name, "CHUNKED x%2d %s: tiles + contiguous 1104-B read per tile (303 MB source)", chunks, touch ? "touch-then-decode" : "decode only      ");
                 show(name, timeIt([&] {
                     size_t per = (tiles + chunks - 1) / chunks;

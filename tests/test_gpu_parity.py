@@ -405,3 +405,35 @@ def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
         reader.batch_embedding_into(batch, wide, col_off)
         assert nan_aware_equal(wide[:, col_off:col_off + dim], expected), (trial, 'strided', dim, col_off, pad)
         assert (np.delete(wide, np.s_[col_off:col_off + dim], axis=1) == 3.25).all()
+
+
+def test_concurrent_callers(native, make_model):
+    # reference: all read methods are const and re-entrant (src/reader.h:19-27); here the word search is
+    # lock-free, the host-buffer entry point serialises per context, the device entry point is per stream
+    import threading
+    path_a, words_a = make_model(20000, 300, 'trained', 4)
+    path_b, words_b = make_model(20000, 300, 'trained', 8, distribution='student')
+    readers = [native.Reader(path_a, num_threads=2), native.Reader(path_b, num_threads=2)]
+    checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+    vocab = [sorted(words_a), sorted(words_b)]
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(12):
+        which = k % 2
+        size = int(rng.choice([1, 70, 1500, 6000]))
+        batch = [vocab[which][i] for i in rng.integers(0, 20000, size=size)] + ['?']
+        jobs.append((which, batch, checkers[which].batch_embedding(batch)))
+    failures = []
+
+    def run(which, batch, expected):
+        for _ in range(3):
+            got = readers[which].batch_embedding(batch)
+            if not bits_equal(got, expected):
+                failures.append((which, len(batch)))
+
+    threads = [threading.Thread(target=run, args=job) for job in jobs]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    assert not failures

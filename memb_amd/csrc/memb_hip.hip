@@ -130,6 +130,10 @@ struct memb_hip_ctx {
     uint32_t* stagedRows = nullptr;
     float* stagedOut = nullptr;
     size_t stagedCapacity = 0;   // words
+    // small batches: pinned host memory the kernel reads row ids from and writes rows to directly
+    void* smallHost = nullptr;
+    void* smallDevice = nullptr;
+    bool smallUnavailable = false;
     size_t stagedLd = 0;
     std::mutex mutex;
 };
@@ -590,6 +594,9 @@ void destroy(memb_hip_ctx* ctx)
     for (void* allocation : ctx->allocations) {
         (void)hipFree(allocation);
     }
+    if (ctx->smallHost) {
+        (void)hipHostFree(ctx->smallHost);
+    }
     if (ctx->stagedRows) {
         (void)hipFree(ctx->stagedRows);
     }
@@ -1048,6 +1055,45 @@ int memb_hip_decode_rows(
     }
     std::lock_guard<std::mutex> lock(ctx->mutex);
     HIP_TRY(hipSetDevice(ctx->device));
+
+    // Small batches (single words above all): two tiny copies cost more than the
+    // decode. Row ids and results go through one pinned, device-mapped host
+    // buffer instead: the kernel reads the ids from it and writes the rows into it
+    // over PCIe, the host then copies them to the caller's (possibly strided) rows.
+    constexpr size_t SMALL_WORDS = 512;
+    if (n <= SMALL_WORDS && !ctx->smallUnavailable) {
+        const size_t rowBytes = size_t(ctx->dim) * sizeof(float);
+        const size_t outOffset = 256;   // row ids first, rows from a 256-byte boundary
+        if (!ctx->smallHost) {
+            void* host = nullptr;
+            void* device = nullptr;
+            if (hipHostMalloc(&host, outOffset + SMALL_WORDS * rowBytes, hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer(&device, host, 0) == hipSuccess) {
+                ctx->smallHost = host;
+                ctx->smallDevice = device;
+            } else {
+                (void)hipGetLastError();
+                if (host) {
+                    (void)hipHostFree(host);
+                }
+                ctx->smallUnavailable = true;
+            }
+        }
+        if (ctx->smallHost) {
+            std::memcpy(ctx->smallHost, rows, n * sizeof(uint32_t));
+            float* deviceOut = reinterpret_cast<float*>(static_cast<char*>(ctx->smallDevice) + outOffset);
+            int code = launch(ctx, static_cast<const uint32_t*>(ctx->smallDevice), n, deviceOut, ctx->dim, 0, ctx->stream);
+            if (code != MEMB_HIP_OK) {
+                return code;
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const char* hostOut = static_cast<const char*>(ctx->smallHost) + outOffset;
+            for (size_t i = 0; i < n; ++i) {
+                std::memcpy(out + i * ld + col_off, hostOut + i * rowBytes, rowBytes);
+            }
+            return MEMB_HIP_OK;
+        }
+    }
 
     // Device staging holds dense [words][dim] rows; batches larger than the
     // staging area are processed in slices.

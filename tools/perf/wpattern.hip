@@ -146,6 +146,16 @@ __global__ void fill_tiles_touch_ahead(float4* out, size_t n4, unsigned tileWord
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// non-persistent: every wave writes `storesPerWave` consecutive KiB and exits
+__global__ void fill_short_waves(float4* out, size_t n4, unsigned storesPerWave) {
+    unsigned lane = threadIdx.x & 63;
+    size_t wave = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    size_t base = wave * storesPerWave * 64;
+    for (unsigned s = 0; s < storesPerWave; ++s) {
+        size_t i = base + s * 64 + lane;
+        if (i < n4) out[i] = make_float4(1, 2, 3, 4);
+    }
+}
 template <typename F> float timeIt(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) f();
@@ -207,6 +217,12 @@ int main() {
         }
         size_t small = 165u << 20;
         show("tiles 8 words + RANDOM gather 7 x16B/word from 165 MB, 32 waves/CU", timeIt([&] { hipLaunchKernelGGL(fill_tiles_gather, dim3(cus * 4), dim3(512), 0, 0, out, n4, 8u, src, small / 16, 7u, 75u, 1, sink); }));
+    }
+    for (unsigned storesPerWave : {1u, 2u, 3u, 5u, 10u, 20u, 40u}) for (unsigned threads : {256u, 512u}) {
+        char name[128]; snprintf(name, sizeof name, "short-lived waves: %2u x 1 KiB per wave, %u-thread blocks", storesPerWave, threads);
+        size_t waves = (n4 + size_t(storesPerWave) * 64 - 1) / (size_t(storesPerWave) * 64);
+        size_t blocks = (waves * 64 + threads - 1) / threads;
+        show(name, timeIt([&] { hipLaunchKernelGGL(fill_short_waves, dim3((unsigned)blocks), dim3(threads), 0, 0, out, n4, storesPerWave); }));
     }
     // one tile per wave, non-persistent
     {

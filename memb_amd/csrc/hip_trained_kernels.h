@@ -264,15 +264,18 @@ __device__ __forceinline__ void outputTile(
     const float2* pairLds = reinterpret_cast<const float2*>(codebookLds);
     const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
 
-    // Nibble keys have no spare code for "absent" (byte keys use ZERO_KEY): rows of
-    // absent words are zeroed after the tile is written -- or, when an epilogue
-    // reads the destination, their pieces go through it as zeros.
+    // Nibble keys have no spare code for "absent" (byte keys use ZERO_KEY): in a
+    // tile that contains absent words every piece looks up its word in the ballot
+    // and absent ones become zeros. (Writing the tile first and zeroing those rows
+    // afterwards relies on two stores of one wave to one address landing in
+    // order; that held in HBM but not for rows written over PCIe into pinned
+    // host memory.)
     const bool hasEpilogue = p.accumulate || p.divisor != 0.f;   // wave-uniform
     unsigned long long absent = 0;
     if (FAST) {
         absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
     }
-    const bool checkWords = FAST && hasEpilogue && absent != 0;
+    const bool checkWords = FAST && absent != 0;
 
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
         // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
@@ -350,23 +353,6 @@ __device__ __forceinline__ void outputTile(
         }
     }
 
-    if (FAST && !hasEpilogue) {
-        // zero the rows of absent words (same wave, same addresses: program order holds)
-        while (absent) {
-            const uint32_t w = fastDivide(__ffsll(static_cast<long long>(absent)) - 1, p.laneMagic, p.lanesPerWord);
-            absent &= absent - 1;
-            float* rowOut = p.out + (tileBase + w) * p.ld + p.colOff;
-            if (MODE == OUT_SCALAR) {
-                for (uint32_t c = lane; c < p.dim; c += WAVE) {
-                    rowOut[c] = 0.f;
-                }
-            } else {
-                for (uint32_t c = lane; c < p.dim / 4; c += WAVE) {
-                    reinterpret_cast<float4*>(rowOut)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-    }
 }
 
 struct WaveLds {

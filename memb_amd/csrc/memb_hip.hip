@@ -1063,7 +1063,8 @@ int memb_hip_decode_rows(
     constexpr size_t SMALL_WORDS = 512;
     if (n <= SMALL_WORDS && !ctx->smallUnavailable) {
         const size_t rowBytes = size_t(ctx->dim) * sizeof(float);
-        const size_t outOffset = 256;   // row ids first, rows from a 256-byte boundary
+        // row ids first, rows from the next 256-byte boundary
+        constexpr size_t outOffset = (SMALL_WORDS * sizeof(uint32_t) + 255) / 256 * 256;
         if (!ctx->smallHost) {
             void* host = nullptr;
             void* device = nullptr;

@@ -87,7 +87,7 @@ def test_trained_full_dump_and_random_batches(native, make_model, bits, distribu
     assert not result[[i for i, w in enumerate(batch) if w.startswith('absent')]].any()
 
 
-@pytest.mark.parametrize('count', [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000])
+@pytest.mark.parametrize('count', [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000])
 def test_ragged_batch_sizes(native, make_model, count):
     path, words = make_model(20000, 300, 'trained', 4)
     reader = native.Reader(path)
@@ -99,6 +99,27 @@ def test_ragged_batch_sizes(native, make_model, count):
     assert result.shape == (count, 300)
     assert bits_equal(result, checker.rows_embedding(rows))
     assert reader.batch_embedding([]).shape == (0, 300)
+
+
+@pytest.mark.parametrize('storage,bits', [('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)])
+def test_small_batches_through_the_pinned_buffer(native, make_model, storage, bits):
+    # batches of <= 512 words skip the staging copies (memb_hip_decode_rows): row
+    # ids and rows share one pinned buffer and must not overlap, first call
+    # included, into plain and strided outputs
+    path, words = make_model(3000, 300, storage, bits)
+    checker = oracle.OracleReader(path)
+    for count in (512, 65, 1, 300, 512):
+        reader = native.Reader(path)
+        rows = np.random.default_rng(count).integers(0, len(words), size=count).astype(np.uint32)
+        rows[count // 3] = 0xFFFFFFFF
+        expected = checker.rows_embedding(rows)
+        for _ in range(3):
+            assert bits_equal(reader.rows_embedding(rows), expected), count
+        keys = reader.keys()
+        wide = np.full((count, 307), 7.0, dtype=np.float32)
+        reader.batch_embedding_into([keys[r] if r < len(keys) else '?' for r in rows], wide, 5)
+        assert bits_equal(wide[:, 5:305], expected), count
+        assert (wide[:, :5] == 7.0).all() and (wide[:, 305:] == 7.0).all()
 
 
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])

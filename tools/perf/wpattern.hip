@@ -1,6 +1,7 @@
 // Write-pattern microbenchmark: how fast can 2.635 GB be written under the tile patterns the decoder uses?
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -156,6 +157,26 @@ __global__ void fill_short_waves(float4* out, size_t n4, unsigned storesPerWave)
         if (i < n4) out[i] = make_float4(1, 2, 3, 4);
     }
 }
+
+// persistent tiles with at most N stores outstanding per wave (s_waitcnt vmcnt(N) after every store)
+template <int N>
+__global__ void fill_tiles_throttled(float4* out, size_t n4, unsigned tilePieces) {
+    unsigned lane = threadIdx.x & 63;
+    size_t wave = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    size_t waves = (size_t(gridDim.x) * blockDim.x) >> 6;
+    size_t tiles = (n4 + tilePieces - 1) / tilePieces;
+    for (size_t t = wave; t < tiles; t += waves) {
+        size_t base = t * tilePieces;
+        for (unsigned q = lane; q < tilePieces; q += 64) {
+            if (base + q < n4) out[base + q] = make_float4(1, 2, 3, 4);
+            if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+    }
+}
 template <typename F> float timeIt(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) f();
@@ -172,6 +193,13 @@ int main() {
     auto show = [&](const char* name, float ms) { printf("%-64s %.3f ms  %.2f TB/s\n", name, ms, gb / ms); fflush(stdout); };
     show("linear grid-stride, 256 thr, 8 blocks/CU", timeIt([&] { hipLaunchKernelGGL(fill_linear, dim3(cus * 8), dim3(256), 0, 0, out, n4); }));
     show("linear, one float4 per thread (n4/256 blocks)", timeIt([&] { hipLaunchKernelGGL(fill_linear, dim3((n4 + 255) / 256), dim3(256), 0, 0, out, n4); }));
+    for (int wavesPerCu : {8, 16, 32, 64}) {
+        char name[128];
+        #define THR(N) snprintf(name, sizeof name, "THROTTLED tiles 9600 B, <= %d stores in flight per wave, %2d waves/CU", N, wavesPerCu); \
+            show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles_throttled<N>, dim3(cus * wavesPerCu / 8), dim3(512), 0, 0, out, n4, 600u); }));
+        THR(0) THR(1) THR(2) THR(4) THR(8) THR(99)
+    }
+    if (getenv("WP_ONLY_THROTTLE")) return 0;
     for (unsigned words_per_tile : {8u, 16u, 64u}) for (int wavesPerCu : {8, 16, 32}) for (int gap : {0, 4}) {
         char name[128]; snprintf(name, sizeof name, "persistent waves: tile %2u words (%u B), %2d waves/CU, gap %d", words_per_tile, words_per_tile * 1200, wavesPerCu, gap);
         show(name, timeIt([&] { hipLaunchKernelGGL(fill_tiles, dim3(cus * wavesPerCu / 8), dim3(512), 0, 0, out, n4, words_per_tile * 75, gap); }));

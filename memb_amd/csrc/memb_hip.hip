@@ -27,6 +27,7 @@
 #include "../../include/memb_hip.h"
 #include "codec.h"
 #include "wire.h"
+#include "worker_pool.h"
 
 #include <algorithm>
 #include <atomic>
@@ -34,6 +35,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -135,6 +138,12 @@ struct memb_hip_ctx {
     void* smallDevice = nullptr;
     bool smallUnavailable = false;
     size_t stagedLd = 0;
+    // pinned ring the DMA engine fills while host threads copy earlier chunks to the caller's rows
+    static constexpr int RING = 4;
+    void* ring[RING] = {};
+    hipEvent_t ringEvents[RING] = {};
+    bool ringUnavailable = false;
+    std::unique_ptr<memb::WorkerPool> copyPool;   // the host threads that empty the ring
     std::mutex mutex;
 };
 
@@ -597,6 +606,14 @@ void destroy(memb_hip_ctx* ctx)
     if (ctx->smallHost) {
         (void)hipHostFree(ctx->smallHost);
     }
+    for (int i = 0; i < memb_hip_ctx::RING; ++i) {
+        if (ctx->ring[i]) {
+            (void)hipHostFree(ctx->ring[i]);
+        }
+        if (ctx->ringEvents[i]) {
+            (void)hipEventDestroy(ctx->ringEvents[i]);
+        }
+    }
     if (ctx->stagedRows) {
         (void)hipFree(ctx->stagedRows);
     }
@@ -609,16 +626,200 @@ void destroy(memb_hip_ctx* ctx)
     delete ctx;
 }
 
-}  // namespace
+struct ContextGuard {
+    explicit ContextGuard(memb_hip_ctx* ctx): ctx_(ctx) {}
+    ~ContextGuard() { destroy(ctx_); }
+    ContextGuard(const ContextGuard&) = delete;
+    ContextGuard& operator=(const ContextGuard&) = delete;
+    memb_hip_ctx* release()
+    {
+        memb_hip_ctx* ctx = ctx_;
+        ctx_ = nullptr;
+        return ctx;
+    }
 
-extern "C" {
+private:
+    memb_hip_ctx* ctx_;
+};
 
-const char* memb_hip_last_error(void)
+constexpr size_t RING_CHUNK_BYTES = size_t(32) << 20;
+
+bool ensureRing(memb_hip_ctx* ctx)
 {
-    return g_lastError.c_str();
+    if (ctx->ringUnavailable) {
+        return false;
+    }
+    if (ctx->ring[0]) {
+        return true;
+    }
+    for (int i = 0; i < memb_hip_ctx::RING; ++i) {
+        if (hipHostMalloc(&ctx->ring[i], RING_CHUNK_BYTES, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ringEvents[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int k = 0; k < memb_hip_ctx::RING; ++k) {
+                if (ctx->ring[k]) {
+                    (void)hipHostFree(ctx->ring[k]);
+                    ctx->ring[k] = nullptr;
+                }
+                if (ctx->ringEvents[k]) {
+                    (void)hipEventDestroy(ctx->ringEvents[k]);
+                    ctx->ringEvents[k] = nullptr;
+                }
+            }
+            ctx->ringUnavailable = true;
+            return false;
+        }
+    }
+    return true;
 }
 
-int memb_hip_device_count(int* count)
+void copyRows(float* destination, size_t ld, const float* source, size_t dim, size_t first, size_t last)
+{
+    if (ld == dim) {
+        std::memcpy(destination + first * ld, source + first * dim, (last - first) * dim * sizeof(float));
+        return;
+    }
+    for (size_t i = first; i < last; ++i) {
+        std::memcpy(destination + i * ld, source + i * dim, dim * sizeof(float));
+    }
+}
+
+// Dense device rows [words][dim] -> destination[i * ld .. + dim), i < words, host memory.
+// The copy engine writes 32-MiB chunks into the pinned ring (enqueued on the
+// context's stream, behind the decode); as a chunk lands, `threads` host threads
+// copy its rows to the caller's buffer -- which is where fresh pages are first
+// touched, in parallel -- while the engine fills the next chunks. A pageable
+// hipMemcpy of the same buffer ran at 14-37 GB/s depending on the host (pages
+// faulted in one by one behind the engine), and 2-D copies for ld > dim slower still.
+int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, float* destination, size_t ld)
+{
+    const size_t dim = ctx->dim;
+    const size_t rowBytes = dim * sizeof(float);
+    if (rowBytes > RING_CHUNK_BYTES || !ensureRing(ctx)) {
+        // no pinned memory to be had: plain (2-D) copy
+        hipError_t status = hipMemcpy2DAsync(
+            destination, ld * sizeof(float), deviceRows, rowBytes, rowBytes, words, hipMemcpyDeviceToHost, ctx->stream);
+        if (status == hipSuccess) {
+            status = hipStreamSynchronize(ctx->stream);
+        }
+        return status == hipSuccess ? MEMB_HIP_OK
+                                    : fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+    }
+    constexpr size_t RING = memb_hip_ctx::RING;
+    // (tests shrink the chunk and force the threads to run every branch on small batches)
+    const size_t chunkRows =
+        std::max<size_t>(1, std::min<size_t>(RING_CHUNK_BYTES / rowBytes, envUint("MEMB_HIP_COPY_CHUNK_ROWS", ~0u)));
+    const size_t chunks = (words + chunkRows - 1) / chunkRows;
+    const size_t wanted = std::min<size_t>(envUint("MEMB_HIP_COPY_THREADS", 8), 64);
+    const bool parallel = words * rowBytes >= (size_t(8) << 20) || envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0) != 0;
+    const size_t threads = parallel ? wanted : 0;   // 0: this thread copies
+
+    std::mutex mutex;
+    std::condition_variable changed;
+    size_t ready = 0;      // chunks that have landed in the ring
+    size_t finished = 0;   // chunks copied out of it by every thread
+    size_t pending[RING] = {};
+    bool failed = false;
+
+    auto chunkWords = [&](size_t chunk) { return std::min(chunkRows, words - chunk * chunkRows); };
+    auto worker = [&](size_t index) {
+        for (size_t chunk = 0; chunk < chunks; ++chunk) {
+            {
+                std::unique_lock<std::mutex> lock(mutex);
+                changed.wait(lock, [&] { return ready > chunk || failed; });
+                if (failed) {
+                    return;
+                }
+            }
+            const size_t count = chunkWords(chunk);
+            const size_t share = (count + threads - 1) / threads;
+            const size_t first = std::min(count, index * share), last = std::min(count, first + share);
+            copyRows(destination + chunk * chunkRows * ld, ld, static_cast<const float*>(ctx->ring[chunk % RING]), dim, first, last);
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+                if (++pending[chunk % RING] == threads) {
+                    pending[chunk % RING] = 0;
+                    ++finished;
+                    changed.notify_all();
+                }
+            }
+        }
+    };
+    // every job runs until the last chunk, so each needs a thread of its own
+    if (threads && (!ctx->copyPool || ctx->copyPool->size() != threads)) {
+        ctx->copyPool.reset(new memb::WorkerPool(threads));
+    }
+    if (threads) {
+        ctx->copyPool->start(threads, worker);
+    }
+
+    hipError_t status = hipSuccess;
+    size_t issued = 0;
+    for (;;) {
+        // keep the engine busy: a chunk may be issued once its ring slot has been copied out
+        size_t issuable;
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            if (finished >= chunks) {
+                break;
+            }
+            issuable = std::min(chunks, finished + RING);
+        }
+        for (; issued < issuable && status == hipSuccess; ++issued) {
+            status = hipMemcpyAsync(
+                ctx->ring[issued % RING], deviceRows + issued * chunkRows * dim, chunkWords(issued) * rowBytes,
+                hipMemcpyDeviceToHost, ctx->stream);
+            if (status == hipSuccess) {
+                status = hipEventRecord(ctx->ringEvents[issued % RING], ctx->stream);
+            }
+        }
+        if (status != hipSuccess) {
+            break;
+        }
+        if (ready < issued) {   // `ready` is written by this thread only
+            status = hipEventSynchronize(ctx->ringEvents[ready % RING]);
+            if (status != hipSuccess) {
+                break;
+            }
+            if (threads == 0) {
+                copyRows(destination + ready * chunkRows * ld, ld, static_cast<const float*>(ctx->ring[ready % RING]), dim, 0, chunkWords(ready));
+            }
+            std::lock_guard<std::mutex> lock(mutex);
+            ++ready;
+            if (threads == 0) {
+                ++finished;
+            }
+            changed.notify_all();
+        } else {
+            // every issued chunk has landed: wait until the copy threads free a slot (or are done)
+            std::unique_lock<std::mutex> lock(mutex);
+            changed.wait(lock, [&] { return finished >= chunks || (issued < chunks && finished + RING > issued); });
+        }
+    }
+    if (status != hipSuccess) {
+        std::lock_guard<std::mutex> lock(mutex);
+        failed = true;
+        changed.notify_all();
+    }
+    if (threads) {
+        ctx->copyPool->wait();
+    }
+    if (status != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+}  // namespace
+
+// Implementations of the entry points; the extern "C" functions at the end of the
+// file call them behind an exception barrier.
+namespace {
+
+
+
+int device_count_checked(int* count)
 {
     if (!count) {
         return fail(MEMB_HIP_ERR_INVALID, "count is null");
@@ -633,7 +834,7 @@ int memb_hip_device_count(int* count)
     return MEMB_HIP_OK;
 }
 
-int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
+int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
 {
     if (!out || !desc) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -648,6 +849,7 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tStart = now();
     memb_hip_ctx* ctx = new memb_hip_ctx();
+    ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->storage = memb::wire::Storage_Trained;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -663,7 +865,6 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
         uint32_t limit = desc->max_direct_bits ? desc->max_direct_bits : envUint("MEMB_HIP_ROOT_BITS", 11);
         ctx->hostTable = memb::buildDecodeTable(lengths, std::min<uint32_t>(limit, 12));
     } catch (const std::exception& error) {
-        delete ctx;
         return fail(MEMB_HIP_ERR_INVALID, error.what());
     }
 
@@ -674,8 +875,7 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
     {
         for (uint64_t r = 0; r < desc->n_rows; ++r) {
             if (desc->value_offsets[r] > desc->packed_values_bytes) {
-                delete ctx;
-                return fail(MEMB_HIP_ERR_INVALID, "value offset beyond packed values");
+                        return fail(MEMB_HIP_ERR_INVALID, "value offset beyond packed values");
             }
         }
         const uint64_t totalBytes = desc->packed_values_bytes;
@@ -761,8 +961,7 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
             next += (ctx->streamBytes[r] + 15) / 16;
         }
         if (next + ctx->slotDwords / 4 + 1 >= (1ull << 32)) {
-            delete ctx;
-            return fail(MEMB_HIP_ERR_INVALID, "bitstreams too large");
+                return fail(MEMB_HIP_ERR_INVALID, "bitstreams too large");
         }
         streamStarts[desc->n_rows] = static_cast<uint32_t>(next);
     }
@@ -876,16 +1075,13 @@ int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_t
                      static_cast<unsigned long long>(desc->n_rows), tSorted - tStart, tRepacked - tSorted, now() - tRepacked);
     }
     if (code != MEMB_HIP_OK) {
-        std::string message = g_lastError;
-        destroy(ctx);
-        g_lastError = message;
         return code;
     }
-    *out = ctx;
+    *out = guard.release();
     return MEMB_HIP_OK;
 }
 
-int memb_hip_ctx_create_uniform(memb_hip_ctx** out, int device, const memb_hip_uniform_desc* desc)
+int ctx_create_uniform_checked(memb_hip_ctx** out, int device, const memb_hip_uniform_desc* desc)
 {
     if (!out || !desc) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -895,6 +1091,7 @@ int memb_hip_ctx_create_uniform(memb_hip_ctx** out, int device, const memb_hip_u
         return fail(MEMB_HIP_ERR_INVALID, "inconsistent uniform storage description");
     }
     memb_hip_ctx* ctx = new memb_hip_ctx();
+    ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->storage = memb::wire::Storage_Uniform;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -928,16 +1125,13 @@ int memb_hip_ctx_create_uniform(memb_hip_ctx** out, int device, const memb_hip_u
         code = copyToDevice(ctx->minMax, minMax.data(), minMax.size() * sizeof(float2));
     }
     if (code != MEMB_HIP_OK) {
-        std::string message = g_lastError;
-        destroy(ctx);
-        g_lastError = message;
         return code;
     }
-    *out = ctx;
+    *out = guard.release();
     return MEMB_HIP_OK;
 }
 
-int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full_desc* desc)
+int ctx_create_full_checked(memb_hip_ctx** out, int device, const memb_hip_full_desc* desc)
 {
     if (!out || !desc) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -947,6 +1141,7 @@ int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full
         return fail(MEMB_HIP_ERR_INVALID, "inconsistent full storage description");
     }
     memb_hip_ctx* ctx = new memb_hip_ctx();
+    ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->storage = memb::wire::Storage_Full;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -967,21 +1162,14 @@ int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full
         code = copyToDevice(ctx->fullValues, values.data(), values.size() * sizeof(float));
     }
     if (code != MEMB_HIP_OK) {
-        std::string message = g_lastError;
-        destroy(ctx);
-        g_lastError = message;
         return code;
     }
-    *out = ctx;
+    *out = guard.release();
     return MEMB_HIP_OK;
 }
 
-void memb_hip_ctx_destroy(memb_hip_ctx* ctx)
-{
-    destroy(ctx);
-}
 
-int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
+int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
 {
     if (!ctx || !info) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -1008,7 +1196,7 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
     return MEMB_HIP_OK;
 }
 
-int memb_hip_decode_rows_device(
+int decode_rows_device_checked(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream)
 {
     if (!ctx || (n && (!rows || !out))) {
@@ -1021,7 +1209,7 @@ int memb_hip_decode_rows_device(
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream));
 }
 
-int memb_hip_decode_rows_device_ex(
+int decode_rows_device_ex_checked(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream,
     uint32_t flags, float divisor)
 {
@@ -1041,7 +1229,7 @@ int memb_hip_decode_rows_device_ex(
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream), epilogue);
 }
 
-int memb_hip_decode_rows(
+int decode_rows_checked(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
 {
     if (!ctx || (n && (!rows || !out))) {
@@ -1097,9 +1285,10 @@ int memb_hip_decode_rows(
     }
 
     // Device staging holds dense [words][dim] rows; batches larger than the
-    // staging area are processed in slices.
+    // staging area (4 GiB of rows) are processed in slices.
     const size_t dim = ctx->dim;
-    const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, (size_t(512) << 20) / (dim * sizeof(float))));
+    const size_t sliceLimit = std::min<size_t>((size_t(4) << 30) / (dim * sizeof(float)), envUint("MEMB_HIP_SLICE_WORDS", ~0u));
+    const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, sliceLimit));
     if (ctx->stagedCapacity < sliceWords) {
         if (ctx->stagedRows) {
             (void)hipFree(ctx->stagedRows);
@@ -1117,96 +1306,38 @@ int memb_hip_decode_rows(
     const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    // A freshly allocated host buffer is faulted in page by page behind the DMA
-    // engine (measured 10-17 GB/s for 2.6 GB against ~55 GB/s once the pages
-    // exist). Touch the caller's output range first, on a few threads: every page
-    // gets one byte read and written back unchanged (the caller owns the buffer
-    // for the duration of the call, and with ld > dim the columns between rows
-    // must keep their contents).
-    char* pinBase = reinterpret_cast<char*>(out + col_off);
-    const size_t pinBytes = ((n - 1) * ld + dim) * sizeof(float);
-    if (pinBytes >= (size_t(8) << 20) && envUint("MEMB_HIP_PREFAULT", 1)) {
-        const size_t page = 4096;
-        const size_t threads = std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
-        const size_t perThread = (pinBytes / threads + page) / page * page;
-        auto touch = [pinBase, pinBytes, page](size_t first, size_t last) {
-            for (size_t at = first; at < std::min(last, pinBytes); at += page) {
-                volatile char* byte = pinBase + at;
-                *byte = *byte;
-            }
-        };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < threads; ++t) {
-            pool.emplace_back(touch, t * perThread, (t + 1) * perThread);
-        }
-        touch(0, perThread);
-        for (auto& thread : pool) {
-            thread.join();
-        }
-        volatile char* lastByte = pinBase + pinBytes - 1;
-        *lastByte = *lastByte;
-    }
-    // Optionally also pin the range (MEMB_HIP_PIN_OUTPUT=1, buffers of 32 MiB and
-    // more, which are mappings of their own). Off by default: one full GPU test run
-    // aborted while registration was on for >= 1 MiB buffers (heap pages shared
-    // with unrelated live data) and the cause could not be established.
-    bool pinned = false;
-    if (pinBytes >= (size_t(32) << 20) && envUint("MEMB_HIP_PIN_OUTPUT", 0)) {
-        hipError_t registered = hipHostRegister(pinBase, pinBytes, hipHostRegisterDefault);
-        if (registered == hipSuccess) {
-            pinned = true;
-        } else {
-            (void)hipGetLastError();
-            if (envUint("MEMB_HIP_VERBOSE", 0)) {
-                std::fprintf(stderr, "memb_hip: hipHostRegister(%zu bytes): %s\n", pinBytes, hipGetErrorString(registered));
-            }
-        }
-    }
-    const double t1 = now();
     int result = MEMB_HIP_OK;
     for (size_t start = 0; start < n && result == MEMB_HIP_OK; start += sliceWords) {
         const size_t words = std::min(sliceWords, n - start);
         hipError_t status = hipMemcpyAsync(
             ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (status == hipSuccess) {
-            result = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
-            if (result != MEMB_HIP_OK) {
-                break;
-            }
-            if (ld == dim) {
-                status = hipMemcpyAsync(
-                    out + start * ld, ctx->stagedOut, words * dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-            } else {
-                status = hipMemcpy2DAsync(
-                    out + start * ld + col_off,
-                    ld * sizeof(float),
-                    ctx->stagedOut,
-                    dim * sizeof(float),
-                    dim * sizeof(float),
-                    words,
-                    hipMemcpyDeviceToHost,
-                    ctx->stream);
-            }
-        }
-        if (status == hipSuccess) {
-            status = hipStreamSynchronize(ctx->stream);
-        }
         if (status != hipSuccess) {
-            result = fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+            result = fail(MEMB_HIP_ERR_DEVICE, std::string("row id copy: ") + hipGetErrorString(status));
+            break;
+        }
+        result = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
+        if (result == MEMB_HIP_OK) {
+            result = copyRowsToHost(ctx, ctx->stagedOut, words, out + start * ld + col_off, ld);
         }
     }
-    const double t2 = now();
-    if (pinned) {
-        (void)hipHostUnregister(pinBase);
+    if (result != MEMB_HIP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);   // nothing of this call may still be running when the caller's buffers go away
+    }
+    // a full-vocabulary dump should not keep gigabytes of HBM for the next small batch
+    if (ctx->stagedCapacity * dim * sizeof(float) > (size_t(1) << 30)) {
+        (void)hipFree(ctx->stagedRows);
+        (void)hipFree(ctx->stagedOut);
+        ctx->stagedRows = nullptr;
+        ctx->stagedOut = nullptr;
+        ctx->stagedCapacity = 0;
     }
     if (verbose) {
-        std::fprintf(stderr, "memb_hip: decode_rows n=%zu pinned=%d prefault/register %.4fs copy+kernel %.4fs unregister %.4fs\n",
-                     n, int(pinned), t1 - t0, t2 - t1, now() - t2);
+        std::fprintf(stderr, "memb_hip: decode_rows n=%zu rows + kernel + copy %.4fs\n", n, now() - t0);
     }
     return result;
 }
 
-int memb_hip_sync(memb_hip_ctx* ctx)
+int sync_checked(memb_hip_ctx* ctx)
 {
     if (!ctx) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -1216,7 +1347,7 @@ int memb_hip_sync(memb_hip_ctx* ctx)
     return MEMB_HIP_OK;
 }
 
-int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes)
+int algorithmic_bytes_checked(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes)
 {
     if (!ctx || !bytes || (n && !rows)) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
@@ -1244,6 +1375,85 @@ int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, si
     }
     *bytes = total;
     return MEMB_HIP_OK;
+}
+
+// No C++ exception leaves the library: allocation failures and the like become error codes.
+template <typename Call>
+int guarded(Call call)
+{
+    try {
+        return call();
+    } catch (const std::bad_alloc&) {
+        return fail(MEMB_HIP_ERR_DEVICE, "out of host memory");
+    } catch (const std::exception& error) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("internal error: ") + error.what());
+    } catch (...) {
+        return fail(MEMB_HIP_ERR_DEVICE, "internal error");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* memb_hip_last_error(void)
+{
+    return g_lastError.c_str();
+}
+
+void memb_hip_ctx_destroy(memb_hip_ctx* ctx)
+{
+    destroy(ctx);
+}
+
+int memb_hip_device_count(int* count)
+{
+    return guarded([&] { return device_count_checked(count); });
+}
+
+int memb_hip_ctx_create_trained(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
+{
+    return guarded([&] { return ctx_create_trained_checked(out, device, desc); });
+}
+
+int memb_hip_ctx_create_uniform(memb_hip_ctx** out, int device, const memb_hip_uniform_desc* desc)
+{
+    return guarded([&] { return ctx_create_uniform_checked(out, device, desc); });
+}
+
+int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full_desc* desc)
+{
+    return guarded([&] { return ctx_create_full_checked(out, device, desc); });
+}
+
+int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
+{
+    return guarded([&] { return ctx_get_info_checked(ctx, info); });
+}
+
+int memb_hip_decode_rows_device(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream)
+{
+    return guarded([&] { return decode_rows_device_checked(ctx, rows, n, out, ld, col_off, stream); });
+}
+
+int memb_hip_decode_rows_device_ex(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream, uint32_t flags, float divisor)
+{
+    return guarded([&] { return decode_rows_device_ex_checked(ctx, rows, n, out, ld, col_off, stream, flags, divisor); });
+}
+
+int memb_hip_decode_rows(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
+{
+    return guarded([&] { return decode_rows_checked(ctx, rows, n, out, ld, col_off); });
+}
+
+int memb_hip_sync(memb_hip_ctx* ctx)
+{
+    return guarded([&] { return sync_checked(ctx); });
+}
+
+int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes)
+{
+    return guarded([&] { return algorithmic_bytes_checked(ctx, rows, n, bytes); });
 }
 
 }  // extern "C"

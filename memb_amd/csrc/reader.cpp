@@ -130,15 +130,34 @@ void Reader::wordEmbeddingToBuffer(const std::string& word, float* buffer) const
     }
 }
 
-// Host half of the batch driver. The reference splits a batch of >= 1024
-// words over numThreads_ std::async jobs that search and decode
-// (src/reader.cpp:59-86); here the jobs only search, the decode of the whole
-// batch is one kernel launch. Jobs are not made smaller than 2048 words:
-// starting a thread costs more than searching a few hundred words.
+// The search half of the reference's batch driver (src/reader.cpp:59-86): the
+// batch is split over host threads as there, but only to find row ids -- the
+// decode of the whole batch is one kernel launch. The threads come from a pool
+// that lives as long as the Reader (at most 64: the search is a few cache
+// misses per word and stops scaling long before the 256 threads of a GPU
+// host); jobs are not made smaller than 1024 words.
+namespace {
+
+const size_t MIN_JOB_SIZE = 1024;
+const size_t INDEX_THRESHOLD = 4096;      // smaller batches do not pay for building the hash index
+const size_t MAX_POOL_THREADS = 64;
+const size_t OVERLAP_THRESHOLD = 262144;  // batches from here on search and decode at the same time
+
+}  // namespace
+
+void Reader::startSearch(const char* const* words, size_t count, uint32_t* rows, bool useIndex) const
+{
+    const CompressedStorage* storage = compressedStorage_.get();
+    const size_t jobs = std::max<size_t>(1, std::min((pool_->size() + 1) * 4, count / MIN_JOB_SIZE));
+    const size_t jobSize = (count + jobs - 1) / jobs;
+    pool_->start(jobs, [=](size_t job) {
+        const size_t first = std::min(count, job * jobSize);
+        storage->resolveMany(words + first, std::min(jobSize, count - first), rows + first, useIndex);
+    });
+}
+
 void Reader::resolveRows(const char* const* words, size_t count, uint32_t* rows) const
 {
-    static const size_t MIN_JOB_SIZE = 2048;
-    static const size_t INDEX_THRESHOLD = 4096;   // smaller batches do not pay for building the hash index
     const CompressedStorage* storage = compressedStorage_.get();
     const bool useIndex = count >= INDEX_THRESHOLD || storage->hasWordIndex();
 
@@ -146,7 +165,18 @@ void Reader::resolveRows(const char* const* words, size_t count, uint32_t* rows)
         storage->resolveMany(words, count, rows, useIndex);
         return;
     }
-    const size_t jobs = std::max<size_t>(1, std::min(numThreads_, count / MIN_JOB_SIZE));
+    std::unique_lock<std::mutex> poolLock(poolMutex_, std::try_to_lock);
+    if (poolLock.owns_lock()) {
+        if (!pool_) {
+            pool_.reset(new WorkerPool(std::min(numThreads_, MAX_POOL_THREADS) - 1));
+        }
+        startSearch(words, count, rows, useIndex);
+        pool_->help();
+        pool_->wait();
+        return;
+    }
+    // the pool is busy with another caller's batch: threads of this call's own, as the reference does
+    const size_t jobs = std::max<size_t>(1, std::min(std::min(numThreads_, MAX_POOL_THREADS), count / (2 * MIN_JOB_SIZE)));
     const size_t jobSize = (count + jobs - 1) / jobs;
     std::vector<std::future<void>> results;
     for (size_t startIndex = jobSize; startIndex < count; startIndex += jobSize) {
@@ -177,6 +207,35 @@ void Reader::batchEmbeddingToStridedBuffer(
         return;
     }
     std::vector<uint32_t> rows(count);
+    if (count >= OVERLAP_THRESHOLD && numThreads_ > 2) {
+        // Large batch: the first quarter is searched, then decoded and copied
+        // back while the pool searches the rest.
+        std::unique_lock<std::mutex> poolLock(poolMutex_, std::try_to_lock);
+        if (poolLock.owns_lock()) {
+            if (!pool_) {
+                pool_.reset(new WorkerPool(std::min(numThreads_, MAX_POOL_THREADS) - 1));
+            }
+            const CompressedStorage* storage = compressedStorage_.get();
+            const size_t head = count / 4;
+            startSearch(words, head, rows.data(), true);
+            pool_->help();
+            pool_->wait();
+            startSearch(words + head, count - head, rows.data() + head, true);
+            try {
+                storage->decodeRows(rows.data(), head, buffer, ld, colOff);
+            } catch (...) {
+                try {
+                    pool_->wait();   // the jobs write into `rows`
+                } catch (...) {
+                }
+                throw;
+            }
+            pool_->wait();
+            poolLock.unlock();
+            storage->decodeRows(rows.data() + head, count - head, buffer + head * ld, ld, colOff);
+            return;
+        }
+    }
     resolveRows(words, count, rows.data());
     compressedStorage_->decodeRows(rows.data(), rows.size(), buffer, ld, colOff);
 }

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "compression_strategy.h"
+#include "worker_pool.h"
 
 #include <memory>
 #include <string>
@@ -78,7 +79,15 @@ private:
     size_t adjustedNumThreads(size_t numThreads) const;
     void init(std::shared_ptr<CompressionStrategy> compressionStrategy, int device);
 
+    // Word search of rows[begin, end) as one batch on the pool (which the caller
+    // has locked): start only, the caller waits.
+    void startSearch(const char* const* words, size_t count, uint32_t* rows, bool useIndex) const;
+
     size_t numThreads_;
+    // threads for the word search: created with the first large batch, used by one batch at
+    // a time (a second concurrent caller falls back to threads of its own)
+    mutable std::mutex poolMutex_;
+    mutable std::unique_ptr<WorkerPool> pool_;
     MappedFile mappedFile_;
     wire::TableView flatIndex_;
     size_t dim_ = 0;

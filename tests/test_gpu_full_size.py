@@ -59,3 +59,29 @@ def test_full_vocabulary_dump(native, full_model):
     valid = perm >= 0
     assert torch.equal(shuffled[valid].view(torch.int32), out[perm[valid].long()].view(torch.int32))
     assert not bool(shuffled[~valid].any())
+
+
+def test_full_vocabulary_through_the_word_api(native, full_model):
+    # reader[keys()] -- the reference's to_keyed_vectors call (python/memb/reader.py:27-28):
+    # word search overlapped with decode and the pinned-ring copy, against the device-resident result
+    import torch
+    path, count = full_model
+    reader = native.Reader(path)
+    keys = reader.keys()
+    assert len(keys) == count and keys == sorted(keys)
+
+    device_rows = reader.rows_embedding_device(torch.arange(count, dtype=torch.int32, device='cuda'))
+    host_rows = reader[keys]
+    assert host_rows.shape == (count, 300) and host_rows.dtype == np.float32
+    assert bits_equal(host_rows, device_rows.cpu().numpy())
+    del host_rows
+
+    # reversed order with unknown words mixed in, into a wider matrix (ReadersUnion's concatenation)
+    sample = keys[::-7]
+    sample[::100] = ['\x7fnot a word'] * len(sample[::100])
+    wide = np.full((len(sample), 310), 3.0, dtype=np.float32)
+    reader.batch_embedding_into(sample, wide, 10)
+    expected = device_rows[torch.arange(count - 1, -1, -7, device='cuda')].cpu().numpy()
+    expected[::100] = 0
+    assert bits_equal(wide[:, 10:], expected)
+    assert (wide[:, :10] == 3.0).all()

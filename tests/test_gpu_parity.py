@@ -122,6 +122,34 @@ def test_small_batches_through_the_pinned_buffer(native, make_model, storage, bi
         assert (wide[:, :5] == 7.0).all() and (wide[:, 305:] == 7.0).all()
 
 
+def test_host_copy_ring_chunks_threads_and_slices(native, make_model, monkeypatch):
+    # memb_hip_decode_rows streams results through a ring of pinned chunks that
+    # host threads copy out; shrink chunks and slices so that a small batch runs
+    # many of them, with and without copy threads, into dense and strided outputs
+    path, words = make_model(20000, 300, 'trained', 4)
+    checker = oracle.OracleReader(path)
+    rows = np.random.default_rng(5).integers(0, len(words), size=9001).astype(np.uint32)
+    rows[::50] = 0xFFFFFFFF
+    expected = checker.rows_embedding(rows)
+    for chunk_rows, threads, slice_words in ((0, 8, 0), (7, 3, 0), (64, 1, 0), (100, 8, 2500), (1, 2, 1000), (513, 0, 0), (9001, 64, 0)):
+        if chunk_rows:
+            monkeypatch.setenv('MEMB_HIP_COPY_CHUNK_ROWS', str(chunk_rows))
+        else:
+            monkeypatch.delenv('MEMB_HIP_COPY_CHUNK_ROWS', raising=False)
+        monkeypatch.setenv('MEMB_HIP_COPY_THREADS', str(threads))
+        if slice_words:
+            monkeypatch.setenv('MEMB_HIP_SLICE_WORDS', str(slice_words))
+        else:
+            monkeypatch.delenv('MEMB_HIP_SLICE_WORDS', raising=False)
+        reader = native.Reader(path)
+        assert bits_equal(reader.rows_embedding(rows), expected), (chunk_rows, threads, slice_words)
+        keys = reader.keys()
+        wide = np.full((len(rows), 303), -1.0, dtype=np.float32)
+        reader.batch_embedding_into([keys[r] if r < len(keys) else '?' for r in rows], wide, 2)
+        assert bits_equal(wide[:, 2:302], expected), (chunk_rows, threads, slice_words)
+        assert (wide[:, :2] == -1.0).all() and (wide[:, 302:] == -1.0).all()
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

@@ -49,11 +49,24 @@ def parse_args():
 
 
 def cpu_baseline(path, rows_host, dim):
-    """The CPU restatement (oracle/memb_oracle.c), decode only, on this box's host cores."""
+    """CPU decode of the same batch on this box's host cores, pre-resolved rows, decode only.
+
+    kind "reference": the reference's own HuffmanTableDecoder + centroid gather (oracle/_ref, compiled
+    from /root/reference/src in the build container with the reference's -O3; the prebuilt library
+    travels with the tree), split over threads as Reader::batchEmbeddingToBuffer splits a batch.
+    kind "port": oracle/memb_oracle.c, when oracle/_ref is not there. Either way the output is also
+    the parity check of the timed GPU result.
+    """
     import numpy as np
     import oracle
     cores = os.cpu_count() or 1
     reader = oracle.OracleReader(path, cores)
+    kind = 'port'
+    decode = lambda rows, out, threads: reader.rows_embedding(rows, out=out, num_threads=threads)
+    if oracle.reference_available() and reader.trained_view() is not None:
+        reference = oracle.ReferenceDecoder(reader)
+        kind = 'reference'
+        decode = lambda rows, out, threads: reference.rows_embedding(rows, out=out, num_threads=threads)
     sample = rows_host
     out = np.empty((len(sample), dim), dtype=np.float32)
     best = float('inf')
@@ -61,20 +74,27 @@ def cpu_baseline(path, rows_host, dim):
     passes = 0
     while passes < 3 or time.time() < deadline:
         start = time.time()
-        reader.rows_embedding(sample, out=out, num_threads=cores)
+        decode(sample, out, cores)
         best = min(best, time.time() - start)
         passes += 1
     single = sample[:min(len(sample), 100000)]
     start = time.time()
-    reader.rows_embedding(single, out=out[:len(single)], num_threads=1)
+    decode(single, out[:len(single)], 1)
     single_rate = len(single) / (time.time() - start)
+    if kind == 'reference':
+        # the restatement must agree with the reference on this batch too
+        port = reader.rows_embedding(single, num_threads=cores)
+        if not np.array_equal(port.view(np.uint32), out[:len(single)].view(np.uint32)):
+            raise SystemExit('oracle/memb_oracle.c and oracle/_ref disagree')
     return {
         'value': len(sample) / best,
         'unit': 'embeddings/s',
         'cores': cores,
-        'kind': 'port',
-        'sample': '{} pre-resolved rows of the same batch, decode only, all host threads, best of {} passes (~6 s); single thread: {:.0f} embeddings/s on {} rows'.format(
-            len(sample), passes, single_rate, len(single)),
+        'kind': kind,
+        'sample': '{} pre-resolved rows of the same batch, decode only ({}), all host threads, best of {} passes (~6 s); single thread: {:.0f} embeddings/s on {} rows'.format(
+            len(sample),
+            "reference's HuffmanTableDecoder, oracle/_ref" if kind == 'reference' else 'oracle/memb_oracle.c',
+            passes, single_rate, len(single)),
     }, out
 
 

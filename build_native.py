@@ -112,7 +112,7 @@ def build_reference_oracle(force=False):
     if force or _newer(REFERENCE_LIBRARY, sources):
         os.makedirs(os.path.dirname(REFERENCE_LIBRARY), exist_ok=True)
         _run([
-            'g++', '-O2', '-std=c++14', '-fPIC', '-shared', '-I' + REFERENCE_SRC,
+            'g++', '-O3', '-std=c++14', '-fPIC', '-shared', '-pthread', '-I' + REFERENCE_SRC,   # -O3: reference CMakeLists.txt:15
             driver, os.path.join(REFERENCE_SRC, 'prefix_code.cpp'),
             '-o', REFERENCE_LIBRARY,
         ])

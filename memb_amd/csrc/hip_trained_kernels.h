@@ -41,7 +41,11 @@ struct TrainedParams {
     float divisor;            // ... and / or divide by this (0 = no division)
 };
 
-enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3 };
+// OUT_KEYS: no codebook gather -- `out` receives the symbol tile itself, dense rows of
+// keyRowBytes (one centroid index per byte, or per nibble when FAST), for the host-buffer
+// entry point: PCIe then carries 1/4 or 1/8 of the bytes and the host threads that copy rows
+// out of pinned memory anyway expand them (memb_hip.hip: expandKeyRows).
+enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3, OUT_KEYS = 4 };
 
 // Device form of one lookup-table entry (logical layout: memb::DecodeTable).
 //   x: leaf    -> code length                       (bits 8..31 zero)
@@ -260,6 +264,26 @@ __device__ __forceinline__ void outputTile(
     const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
     uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
 {
+    if (MODE == OUT_KEYS) {
+        // rows of a tile are dense in LDS and in the output; absent words carry whatever was
+        // decoded for them (the host knows them by their row ids)
+        const unsigned long long firstByte = tileBase * p.keyRowBytes;
+        uint8_t* keysOut = reinterpret_cast<uint8_t*>(p.out) + firstByte;
+        const uint32_t bytes = tileWords * p.keyRowBytes;   // even
+        if ((firstByte & 3) == 0) {
+            for (uint32_t q = lane; q < bytes / 4; q += WAVE) {
+                reinterpret_cast<uint32_t*>(keysOut)[q] = keyTile[q];
+            }
+            if ((bytes & 2) && lane == 0) {   // the next tile owns the bytes after these two
+                reinterpret_cast<uint16_t*>(keysOut)[bytes / 2 - 1] = reinterpret_cast<const uint16_t*>(keyTile)[bytes / 2 - 1];
+            }
+        } else {
+            for (uint32_t q = lane; q < bytes / 2; q += WAVE) {
+                reinterpret_cast<uint16_t*>(keysOut)[q] = reinterpret_cast<const uint16_t*>(keyTile)[q];
+            }
+        }
+        return;
+    }
     const float* centroidLds = reinterpret_cast<const float*>(codebookLds);
     const float2* pairLds = reinterpret_cast<const float2*>(codebookLds);
     const uint8_t* keyBytes = reinterpret_cast<const uint8_t*>(keyTile);
@@ -379,7 +403,7 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
     for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
     }
-    if (MODE != OUT_INDEX) {
+    if (MODE != OUT_INDEX && MODE != OUT_KEYS) {
         for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
             codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
         }

@@ -131,8 +131,10 @@ struct memb_hip_ctx {
 
     // staging for the host-buffer entry point
     uint32_t* stagedRows = nullptr;
-    float* stagedOut = nullptr;
-    size_t stagedCapacity = 0;   // words
+    float* stagedOut = nullptr;   // fp32 rows, or rows of centroid indices (trained: see decodeRowsAsKeys)
+    size_t stagedCapacity = 0;    // words
+    size_t stagedRowBytes = 0;
+    std::vector<float> hostCodebook;   // the device codebook's host copy (256 centroids or 256 pairs)
     // small batches: pinned host memory the kernel reads row ids from and writes rows to directly
     void* smallHost = nullptr;
     void* smallDevice = nullptr;
@@ -322,12 +324,16 @@ struct Epilogue {
     float divisor = 0.f;
 };
 
+// keysOut: `out` receives rows of centroid indices (OUT_KEYS) instead of fp32 rows; ld = dim, colOff = 0.
 int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
-    const Epilogue& epilogue)
+    const Epilogue& epilogue, bool keysOut = false)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out);
+    if (keysOut) {
+        geometry.mode = OUT_KEYS;
+    }
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
@@ -379,6 +385,10 @@ int launchTrained(
         case OUT_VEC4:
             status = persistent ? launchPersistentMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
                                 : launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+            break;
+        case OUT_KEYS:
+            status = persistent ? launchPersistentMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
+                                : launchTrainedMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
             break;
         default:
             status = persistent ? launchPersistentMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
@@ -684,40 +694,65 @@ void copyRows(float* destination, size_t ld, const float* source, size_t dim, si
     }
 }
 
-// Dense device rows [words][dim] -> destination[i * ld .. + dim), i < words, host memory.
-// The copy engine writes 32-MiB chunks into the pinned ring (enqueued on the
-// context's stream, behind the decode); as a chunk lands, `threads` host threads
-// copy its rows to the caller's buffer -- which is where fresh pages are first
-// touched, in parallel -- while the engine fills the next chunks. A pageable
-// hipMemcpy of the same buffer ran at 14-37 GB/s depending on the host (pages
-// faulted in one by one behind the engine), and 2-D copies for ld > dim slower still.
-int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, float* destination, size_t ld)
+// Rows of centroid indices (what OUT_KEYS wrote: keyRowBytes per row, one index per byte or,
+// `fast`, per nibble, low nibble first) -> fp32 rows. The values are copies of the file's
+// centroids, exactly what the device-side gather stores; rows whose id is not in the file
+// become zeros (reference src/reader.cpp:41-47).
+void expandKeyRows(
+    const memb_hip_ctx* ctx, const uint8_t* keys, size_t keyRowBytes, const uint32_t* rows, float* destination, size_t ld,
+    size_t first, size_t last)
 {
     const size_t dim = ctx->dim;
-    const size_t rowBytes = dim * sizeof(float);
-    if (rowBytes > RING_CHUNK_BYTES || !ensureRing(ctx)) {
-        // no pinned memory to be had: plain (2-D) copy
-        hipError_t status = hipMemcpy2DAsync(
-            destination, ld * sizeof(float), deviceRows, rowBytes, rowBytes, words, hipMemcpyDeviceToHost, ctx->stream);
-        if (status == hipSuccess) {
-            status = hipStreamSynchronize(ctx->stream);
+    const float* codebook = ctx->hostCodebook.data();
+    for (size_t i = first; i < last; ++i) {
+        float* out = destination + i * ld;
+        if (rows[i] >= ctx->nRows) {
+            std::memset(out, 0, dim * sizeof(float));
+            continue;
         }
-        return status == hipSuccess ? MEMB_HIP_OK
-                                    : fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+        const uint8_t* source = keys + i * keyRowBytes;
+        if (ctx->fast) {
+            const size_t pairs = dim / 2;
+            for (size_t k = 0; k < pairs; ++k) {
+                std::memcpy(out + 2 * k, codebook + 2 * size_t(source[k]), 2 * sizeof(float));
+            }
+            if (dim & 1) {
+                out[dim - 1] = codebook[2 * size_t(source[pairs] & 15)];
+            }
+        } else {
+            for (size_t k = 0; k < dim; ++k) {
+                out[k] = codebook[source[k]];
+            }
+        }
     }
+}
+
+// Device rows of `rowBytes` each -> the caller's host rows, through the pinned ring.
+// The copy engine writes chunks of the device buffer into the ring (enqueued on the
+// context's stream, behind the decode); as a chunk lands, `threads` pooled host
+// threads turn their shares of its rows into the caller's rows with
+// emit(chunk data, first row of the chunk, first, last) -- a copy or an expansion,
+// and in either case where fresh pages of the result are first touched, in
+// parallel -- while the engine fills the next chunks. (A pageable hipMemcpy of a
+// 2.6 GB result ran at 14-37 GB/s depending on the host, pages being faulted in
+// one by one behind the engine, and 2-D copies for ld > dim slower still.)
+template <typename Emit>
+int streamRowsToHost(memb_hip_ctx* ctx, const void* deviceRows, size_t rowBytes, size_t words, size_t resultRowBytes, Emit emit)
+{
     constexpr size_t RING = memb_hip_ctx::RING;
+    // chunks of at most 32 MiB of device rows and at most 32 MiB worth of result rows
     // (tests shrink the chunk and force the threads to run every branch on small batches)
-    const size_t chunkRows =
-        std::max<size_t>(1, std::min<size_t>(RING_CHUNK_BYTES / rowBytes, envUint("MEMB_HIP_COPY_CHUNK_ROWS", ~0u)));
+    size_t chunkRows = std::min(RING_CHUNK_BYTES / rowBytes, std::max<size_t>(1, RING_CHUNK_BYTES / resultRowBytes));
+    chunkRows = std::max<size_t>(1, std::min<size_t>(chunkRows, envUint("MEMB_HIP_COPY_CHUNK_ROWS", ~0u)));
     const size_t chunks = (words + chunkRows - 1) / chunkRows;
-    const size_t wanted = std::min<size_t>(envUint("MEMB_HIP_COPY_THREADS", 8), 64);
-    const bool parallel = words * rowBytes >= (size_t(8) << 20) || envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0) != 0;
-    const size_t threads = parallel ? wanted : 0;   // 0: this thread copies
+    const size_t wanted = std::min<size_t>(envUint("MEMB_HIP_COPY_THREADS", 16), 64);
+    const bool parallel = words * resultRowBytes >= (size_t(8) << 20) || envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0) != 0;
+    const size_t threads = parallel ? wanted : 0;   // 0: this thread does the rows
 
     std::mutex mutex;
     std::condition_variable changed;
     size_t ready = 0;      // chunks that have landed in the ring
-    size_t finished = 0;   // chunks copied out of it by every thread
+    size_t finished = 0;   // chunks emitted by every thread
     size_t pending[RING] = {};
     bool failed = false;
 
@@ -734,7 +769,7 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
             const size_t count = chunkWords(chunk);
             const size_t share = (count + threads - 1) / threads;
             const size_t first = std::min(count, index * share), last = std::min(count, first + share);
-            copyRows(destination + chunk * chunkRows * ld, ld, static_cast<const float*>(ctx->ring[chunk % RING]), dim, first, last);
+            emit(ctx->ring[chunk % RING], chunk * chunkRows, first, last);
             {
                 std::lock_guard<std::mutex> lock(mutex);
                 if (++pending[chunk % RING] == threads) {
@@ -756,7 +791,7 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
     hipError_t status = hipSuccess;
     size_t issued = 0;
     for (;;) {
-        // keep the engine busy: a chunk may be issued once its ring slot has been copied out
+        // keep the engine busy: a chunk may be issued once its ring slot has been emptied
         size_t issuable;
         {
             std::lock_guard<std::mutex> lock(mutex);
@@ -767,8 +802,8 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
         }
         for (; issued < issuable && status == hipSuccess; ++issued) {
             status = hipMemcpyAsync(
-                ctx->ring[issued % RING], deviceRows + issued * chunkRows * dim, chunkWords(issued) * rowBytes,
-                hipMemcpyDeviceToHost, ctx->stream);
+                ctx->ring[issued % RING], static_cast<const char*>(deviceRows) + issued * chunkRows * rowBytes,
+                chunkWords(issued) * rowBytes, hipMemcpyDeviceToHost, ctx->stream);
             if (status == hipSuccess) {
                 status = hipEventRecord(ctx->ringEvents[issued % RING], ctx->stream);
             }
@@ -782,7 +817,7 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
                 break;
             }
             if (threads == 0) {
-                copyRows(destination + ready * chunkRows * ld, ld, static_cast<const float*>(ctx->ring[ready % RING]), dim, 0, chunkWords(ready));
+                emit(ctx->ring[ready % RING], ready * chunkRows, 0, chunkWords(ready));
             }
             std::lock_guard<std::mutex> lock(mutex);
             ++ready;
@@ -791,7 +826,7 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
             }
             changed.notify_all();
         } else {
-            // every issued chunk has landed: wait until the copy threads free a slot (or are done)
+            // every issued chunk has landed: wait until the threads free a slot (or are done)
             std::unique_lock<std::mutex> lock(mutex);
             changed.wait(lock, [&] { return finished >= chunks || (issued < chunks && finished + RING > issued); });
         }
@@ -809,6 +844,53 @@ int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, flo
         return fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
     }
     return MEMB_HIP_OK;
+}
+
+// Dense device rows [words][dim] -> destination[i * ld .. + dim), i < words, host memory.
+int copyRowsToHost(memb_hip_ctx* ctx, const float* deviceRows, size_t words, float* destination, size_t ld)
+{
+    const size_t dim = ctx->dim;
+    const size_t rowBytes = dim * sizeof(float);
+    if (rowBytes > RING_CHUNK_BYTES || !ensureRing(ctx)) {
+        // no pinned memory to be had: plain (2-D) copy
+        hipError_t status = hipMemcpy2DAsync(
+            destination, ld * sizeof(float), deviceRows, rowBytes, rowBytes, words, hipMemcpyDeviceToHost, ctx->stream);
+        if (status == hipSuccess) {
+            status = hipStreamSynchronize(ctx->stream);
+        }
+        return status == hipSuccess ? MEMB_HIP_OK
+                                    : fail(MEMB_HIP_ERR_DEVICE, std::string("batch copy: ") + hipGetErrorString(status));
+    }
+    return streamRowsToHost(
+        ctx, deviceRows, rowBytes, words, rowBytes,
+        [=](const void* chunk, size_t chunkFirst, size_t first, size_t last) {
+            copyRows(destination + chunkFirst * ld, ld, static_cast<const float*>(chunk), dim, first, last);
+        });
+}
+
+// Trained storage, host buffers: the kernel decodes the bitstreams into rows of
+// centroid indices (1 or 1/2 byte per weight), those cross PCIe, and the ring's
+// host threads expand them -- they write every output byte anyway, and read 4-8x
+// less than a copy of fp32 rows would. The Huffman decode, the part that costs a
+// CPU 3-4 ns per weight, stays on the GPU; the result is bit-identical (the
+// values are the file's centroids either way).
+int decodeRowsAsKeys(
+    memb_hip_ctx* ctx, const uint32_t* deviceRowIds, const uint32_t* hostRowIds, size_t words, uint8_t* deviceKeys,
+    float* destination, size_t ld)
+{
+    const size_t rowBytes = keyRowBytes(ctx);
+    int code = launchTrained(
+        ctx, deviceRowIds, words, reinterpret_cast<float*>(deviceKeys), ctx->dim, 0, ctx->stream, Epilogue(), true);
+    if (code != MEMB_HIP_OK) {
+        return code;
+    }
+    return streamRowsToHost(
+        ctx, deviceKeys, rowBytes, words, ctx->dim * sizeof(float),
+        [=](const void* chunk, size_t chunkFirst, size_t first, size_t last) {
+            expandKeyRows(
+                ctx, static_cast<const uint8_t*>(chunk), rowBytes, hostRowIds + chunkFirst, destination + chunkFirst * ld,
+                ld, first, last);
+        });
 }
 
 }  // namespace
@@ -1057,6 +1139,7 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
             std::copy(centroids.begin(), centroids.end(), codebook.begin());
         }
         code = copyToDevice(ctx->codebook, codebook.data(), 512 * 4);
+        ctx->hostCodebook = codebook;
     }
     if (code == MEMB_HIP_OK) {
         TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
@@ -1284,12 +1367,16 @@ int decode_rows_checked(
         }
     }
 
-    // Device staging holds dense [words][dim] rows; batches larger than the
-    // staging area (4 GiB of rows) are processed in slices.
+    // Device staging holds one row per word -- fp32, or centroid indices for trained
+    // storages (decodeRowsAsKeys) -- ; batches larger than the staging area (4 GiB of
+    // fp32 rows) are processed in slices.
     const size_t dim = ctx->dim;
+    const bool asKeys = ctx->storage == memb::wire::Storage_Trained && !ctx->hostCodebook.empty() &&
+        keyRowBytes(ctx) <= RING_CHUNK_BYTES && envUint("MEMB_HIP_HOST_EXPAND", 1) != 0 && ensureRing(ctx);
+    const size_t stagedRowBytes = asKeys ? keyRowBytes(ctx) : dim * sizeof(float);
     const size_t sliceLimit = std::min<size_t>((size_t(4) << 30) / (dim * sizeof(float)), envUint("MEMB_HIP_SLICE_WORDS", ~0u));
     const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, sliceLimit));
-    if (ctx->stagedCapacity < sliceWords) {
+    if (ctx->stagedCapacity < sliceWords || ctx->stagedRowBytes < stagedRowBytes) {
         if (ctx->stagedRows) {
             (void)hipFree(ctx->stagedRows);
             ctx->stagedRows = nullptr;
@@ -1300,8 +1387,9 @@ int decode_rows_checked(
         }
         ctx->stagedCapacity = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedRows), sliceWords * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedOut), sliceWords * dim * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stagedOut), sliceWords * stagedRowBytes + 16));
         ctx->stagedCapacity = sliceWords;
+        ctx->stagedRowBytes = stagedRowBytes;
     }
     const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1315,24 +1403,32 @@ int decode_rows_checked(
             result = fail(MEMB_HIP_ERR_DEVICE, std::string("row id copy: ") + hipGetErrorString(status));
             break;
         }
-        result = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
-        if (result == MEMB_HIP_OK) {
-            result = copyRowsToHost(ctx, ctx->stagedOut, words, out + start * ld + col_off, ld);
+        float* destination = out + start * ld + col_off;
+        if (asKeys) {
+            result = decodeRowsAsKeys(
+                ctx, ctx->stagedRows, rows + start, words, reinterpret_cast<uint8_t*>(ctx->stagedOut), destination, ld);
+        } else {
+            result = launch(ctx, ctx->stagedRows, words, ctx->stagedOut, dim, 0, ctx->stream);
+            if (result == MEMB_HIP_OK) {
+                result = copyRowsToHost(ctx, ctx->stagedOut, words, destination, ld);
+            }
         }
     }
     if (result != MEMB_HIP_OK) {
         (void)hipStreamSynchronize(ctx->stream);   // nothing of this call may still be running when the caller's buffers go away
     }
     // a full-vocabulary dump should not keep gigabytes of HBM for the next small batch
-    if (ctx->stagedCapacity * dim * sizeof(float) > (size_t(1) << 30)) {
+    if (ctx->stagedCapacity * ctx->stagedRowBytes > (size_t(1) << 30)) {
         (void)hipFree(ctx->stagedRows);
         (void)hipFree(ctx->stagedOut);
         ctx->stagedRows = nullptr;
         ctx->stagedOut = nullptr;
         ctx->stagedCapacity = 0;
+        ctx->stagedRowBytes = 0;
     }
     if (verbose) {
-        std::fprintf(stderr, "memb_hip: decode_rows n=%zu rows + kernel + copy %.4fs\n", n, now() - t0);
+        std::fprintf(stderr, "memb_hip: decode_rows n=%zu (%s over PCIe) rows + kernel + copy %.4fs\n",
+                     n, asKeys ? "centroid indices" : "fp32 rows", now() - t0);
     }
     return result;
 }

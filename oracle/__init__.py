@@ -210,6 +210,65 @@ class OracleReader:
     def stream_bytes(self, row):
         return self.lib.memb_oracle_stream_bytes(self.handle, int(row))
 
+    def trained_view(self):
+        """Pointers to the trained storage's arrays inside the mapped file (None for other storages)."""
+        view = TrainedArrays()
+        self.lib.memb_oracle_trained_view.argtypes = [ctypes.c_void_p, ctypes.POINTER(TrainedArrays)]
+        self.lib.memb_oracle_trained_view.restype = ctypes.c_int
+        return view if self.lib.memb_oracle_trained_view(self.handle, ctypes.byref(view)) else None
+
+
+class TrainedArrays(ctypes.Structure):
+    _fields_ = [('packed_values', ctypes.c_void_p), ('packed_values_size', ctypes.c_uint64),
+                ('value_offsets', ctypes.c_void_p), ('word_count', ctypes.c_uint64),
+                ('keys', ctypes.c_void_p), ('key_count', ctypes.c_uint64),
+                ('size_offsets', ctypes.c_void_p), ('size_offset_count', ctypes.c_uint64),
+                ('centroids', ctypes.c_void_p), ('centroid_count', ctypes.c_uint64)]
+
+
+class ReferenceDecoder:
+    """Rows -> fp32 with the REFERENCE's HuffmanTableDecoder (oracle/_ref) over the
+    arrays of a file opened by OracleReader: the decode loop of
+    TrainedCompressedStorage::extract (reference src/trained_compression.cpp:129-137)."""
+
+    DEFAULT_DECODE_TABLE_BIT_LENGTH = 10   # reference src/trained_compression.h:11
+
+    def __init__(self, reader, max_direct_bits=DEFAULT_DECODE_TABLE_BIT_LENGTH):
+        self.lib = reference_library()
+        if self.lib is None:
+            raise RuntimeError('oracle/_ref is not built')
+        self.reader = reader   # keeps the mapping alive
+        self.view = reader.trained_view()
+        if self.view is None:
+            raise RuntimeError('not a trained storage')
+        self.dim = reader.dim
+        self.lib.memb_ref_rows_embedding.restype = None
+        self.lib.memb_ref_rows_embedding.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]
+        self.decoder = self.lib.memb_ref_decoder_create(
+            ctypes.cast(self.view.keys, _u8p), self.view.key_count,
+            ctypes.cast(self.view.size_offsets, _u32p), self.view.size_offset_count, max_direct_bits)
+
+    def close(self):
+        if self.decoder:
+            self.lib.memb_ref_decoder_destroy(self.decoder)
+            self.decoder = None
+
+    def __del__(self):
+        self.close()
+
+    def rows_embedding(self, rows, out=None, num_threads=1):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        if out is None:
+            out = np.empty((len(rows), self.dim), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape[0] == len(rows)
+        view = self.view
+        self.lib.memb_ref_rows_embedding(
+            self.decoder, view.packed_values, view.packed_values_size, view.value_offsets, view.word_count,
+            view.centroids, rows.ctypes.data, len(rows), self.dim, out.ctypes.data, out.shape[1], num_threads)
+        return out
+
 
 def uniform_value(min_value, max_value, value, levels):
     return oracle_library().memb_oracle_uniform_value(min_value, max_value, value, levels)

@@ -395,6 +395,10 @@ typedef struct oracle_reader {
     const uint8_t* packed_values;
     size_t packed_values_size;
     oracle_decoder* decoder;
+    const uint8_t* decoder_keys;
+    size_t decoder_key_count;
+    const uint32_t* decoder_size_offsets;
+    size_t decoder_size_offset_count;
     float* centroids;
     size_t centroid_count;
 
@@ -485,6 +489,10 @@ EXPORT oracle_reader* memb_oracle_open(
         size_t size_offset_count = 0;
         const uint8_t* keys = b->data + fb_vector(b, decoder, 0, &key_count);
         const uint32_t* size_offsets = (const uint32_t*)(b->data + fb_vector(b, decoder, 1, &size_offset_count));
+        r->decoder_keys = keys;
+        r->decoder_key_count = key_count;
+        r->decoder_size_offsets = size_offsets;
+        r->decoder_size_offset_count = size_offset_count;
         r->decoder = memb_oracle_decoder_create(
             keys, key_count, size_offsets, size_offset_count,
             max_direct_bits ? max_direct_bits : DEFAULT_DECODE_TABLE_BIT_LENGTH);
@@ -724,6 +732,40 @@ EXPORT void memb_oracle_rows_embedding(
 }
 
 /* bytes of the trained bitstream one row's decode consumes (for the roofline byte count) */
+/* The arrays of a trained storage as the file holds them (pointers into the
+ * mapping, valid while the reader is open), for checkers that run another
+ * decoder over the same file (oracle/ref_driver.cpp). Returns 0 for other storages. */
+typedef struct {
+    const uint8_t* packed_values;
+    uint64_t packed_values_size;
+    const uint32_t* value_offsets;
+    uint64_t word_count;
+    const uint8_t* keys;
+    uint64_t key_count;
+    const uint32_t* size_offsets;
+    uint64_t size_offset_count;
+    const float* centroids;
+    uint64_t centroid_count;
+} memb_oracle_trained_arrays;
+
+EXPORT int memb_oracle_trained_view(const oracle_reader* r, memb_oracle_trained_arrays* view)
+{
+    if (r->storage_type != STORAGE_TRAINED) {
+        return 0;
+    }
+    view->packed_values = r->packed_values;
+    view->packed_values_size = r->packed_values_size;
+    view->value_offsets = r->value_offsets;
+    view->word_count = r->word_count;
+    view->keys = r->decoder_keys;
+    view->key_count = r->decoder_key_count;
+    view->size_offsets = r->decoder_size_offsets;
+    view->size_offset_count = r->decoder_size_offset_count;
+    view->centroids = r->centroids;
+    view->centroid_count = r->centroid_count;
+    return 1;
+}
+
 EXPORT uint32_t memb_oracle_stream_bytes(const oracle_reader* r, uint32_t row)
 {
     if (r->storage_type != STORAGE_TRAINED || row >= r->word_count) {

@@ -150,6 +150,34 @@ def test_host_copy_ring_chunks_threads_and_slices(native, make_model, monkeypatc
         assert (wide[:, :2] == -1.0).all() and (wide[:, 302:] == -1.0).all()
 
 
+def test_host_batches_cross_pcie_as_centroid_indices(native, make_model, monkeypatch):
+    # trained storage + host buffers: the kernel writes rows of centroid indices, the host threads
+    # that empty the pinned ring expand them (memb_hip.hip: decodeRowsAsKeys). Same bits as the
+    # fp32 path (MEMB_HIP_HOST_EXPAND=0) and as the checker, for nibble and byte keys, odd
+    # dimensions, tile geometries whose key tiles are not dword multiples, absent rows.
+    for dim, bits, lanes in ((300, 4, 8), (300, 8, 8), (7, 2, 1), (301, 4, 5), (33, 6, 3), (150, 4, 64), (2, 4, 1)):
+        path, words = make_model(2500, dim, 'trained', bits, seed=dim + bits)
+        checker = oracle.OracleReader(path)
+        rows = np.random.default_rng(dim).integers(0, len(words), size=1777).astype(np.uint32)
+        rows[::13] = 0xFFFFFFFF
+        rows[5] = len(words)
+        expected = checker.rows_embedding(rows)
+        monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
+        for expand, chunk_rows in ((1, 0), (1, 5), (0, 0)):
+            monkeypatch.setenv('MEMB_HIP_HOST_EXPAND', str(expand))
+            if chunk_rows:
+                monkeypatch.setenv('MEMB_HIP_COPY_CHUNK_ROWS', str(chunk_rows))
+            else:
+                monkeypatch.delenv('MEMB_HIP_COPY_CHUNK_ROWS', raising=False)
+            reader = native.Reader(path)
+            assert bits_equal(reader.rows_embedding(rows), expected), (dim, bits, lanes, expand, chunk_rows)
+            wide = np.full((len(rows), dim + 5), 9.0, dtype=np.float32)
+            keys = reader.keys()
+            reader.batch_embedding_into([keys[r] if r < len(keys) else '?' for r in rows], wide, 3)
+            assert bits_equal(wide[:, 3:3 + dim], expected), (dim, bits, lanes, expand, chunk_rows)
+            assert (wide[:, :3] == 9.0).all() and (wide[:, 3 + dim:] == 9.0).all()
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

@@ -51,3 +51,36 @@ def test_decoders_agree_on_random_codes():
             want = reference.decode_symbols(keys, size_offsets, bits, stream_a, count)
             assert np.array_equal(got, want), (trial, bits)
             assert np.array_equal(got[:len(message)], message)
+
+
+@pytest.mark.parametrize('bits,distribution', [(2, 'normal'), (4, 'normal'), (6, 'student'), (8, 'student')])
+def test_reference_decoder_rows_equal_restatement_on_whole_files(make_model, bits, distribution):
+    # whole-file check: the reference's HuffmanTableDecoder + centroid gather over every row of a
+    # synthetic model (written by memb_amd.Builder) against the C restatement's Reader
+    path, words = make_model(3000, 300, 'trained', bits, distribution=distribution)
+    reader = oracle.OracleReader(path)
+    rows = np.concatenate([np.arange(len(words), dtype=np.uint32)[::-1],
+                           np.array([0xFFFFFFFF, len(words), 0], dtype=np.uint32)])
+    expected = reader.rows_embedding(rows)
+    assert not expected[-3:-1].any()
+    for max_direct_bits in (10, 1, 3):   # 10 = reference default (src/trained_compression.h:11), 1 = src/tests.cpp:76-88
+        decoder = oracle.ReferenceDecoder(reader, max_direct_bits)
+        for threads in (1, 3):
+            got = decoder.rows_embedding(rows, num_threads=threads)
+            assert np.array_equal(got.view(np.uint32), expected.view(np.uint32)), (max_direct_bits, threads)
+        decoder.close()
+
+
+def test_reference_decoder_on_the_golden_models():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, 'models.json')) as handle:
+        entries = json.load(handle)
+    for entry in entries:
+        if entry['storage'] != 'trained':
+            continue
+        reader = oracle.OracleReader(os.path.join(GOLDEN, entry['file']))
+        rows = np.arange(len(entry['keys']), dtype=np.uint32)
+        got = oracle.ReferenceDecoder(reader).rows_embedding(rows)
+        assert np.array_equal(got.view(np.uint32), np.load(os.path.join(GOLDEN, entry['rows'])).view(np.uint32))

@@ -20,6 +20,18 @@ for m in (1, 1000, 100000, n):
     t0,t1,t2,t3=0,best[0],best[0]+best[1],best[0]+best[1]+best[2]
     print('n=%8d resolve %.4fs (%.2f Mw/s) | rows->numpy %.4fs (%.2f GB/s) | reader[words] %.4fs (%.3f M emb/s)'%(m,t1-t0,m/(t1-t0)/1e6,t2-t1,m*1200/(t2-t1)/1e9,t3-t2,m/(t3-t2)/1e6))
 o=oracle.OracleReader(path, os.cpu_count())
+if oracle.reference_available():
+    ref=oracle.ReferenceDecoder(o)
+    for m in (100000, n):
+        rows=rng.integers(0,n,size=m).astype(np.uint32) if m<n else np.arange(n,dtype=np.uint32)
+        out=np.empty((m,300),dtype=np.float32)
+        for threads in (os.cpu_count(), 64, 16, 1):
+            if threads==1 and m==n: continue
+            best=1e9
+            for rep in range(3):
+                t=time.perf_counter(); ref.rows_embedding(rows,out=out,num_threads=threads); best=min(best,time.perf_counter()-t)
+            print('reference decoder (oracle/_ref), decode only, n=%d threads=%d: %.4fs (%.1f M emb/s)'%(m,threads,best,m/best/1e6), flush=True)
+        del out
 words=[keys[i] for i in rng.integers(0,n,size=100000)]
 t=time.time(); o.batch_embedding(words); print('oracle (all cores) batch 100k: %.4fs'%(time.time()-t))
 o1=oracle.OracleReader(path, 1)

@@ -13,10 +13,10 @@ lib.memb_hip_decode_rows.argtypes=[ctypes.c_void_p,ctypes.c_void_p,ctypes.c_size
 handle=r._impl.context_handle()
 rng=np.random.default_rng(1)
 print(open('/sys/kernel/mm/transparent_hugepage/enabled').read().strip(), '| cpus', os.cpu_count())
-for m in (2000, 10000, 100000, 400000):
-    rows=rng.integers(0,n,size=m).astype(np.uint32)
+for m in (10000, 100000, 400000, n):
+    rows=rng.integers(0,n,size=m).astype(np.uint32) if m<n else np.arange(n,dtype=np.uint32)
     r.rows_embedding(rows)
-    for threads in (0, 1, 4, 8, 16):
+    for threads in (0, 4, 8, 16, 32, 64):
         os.environ['MEMB_HIP_COPY_THREADS']=str(threads)
         best=1e9; reuse=1e9
         out=np.empty((m,300),dtype=np.float32)

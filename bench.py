@@ -116,10 +116,18 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     distributed = world_size > 1
+    # Rehearsal of the multi-rank plumbing on a one-GPU box: MEMB_BENCH_REHEARSAL=1 puts every rank on
+    # cuda:0 and uses gloo (RCCL refuses two ranks on one device). Never set by the driver.
+    rehearsal = distributed and os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         dist.barrier()
     import memb_amd
 

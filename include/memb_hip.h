@@ -130,7 +130,19 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
 /*
  * Batch lookup, host buffers (the reference's calling convention: caller-owned
  * output, fully overwritten, reference src/reader.cpp:41-57). Writes row i of
- * the batch to out[i * ld + col_off .. + dim); ld >= col_off + dim. Synchronous.
+ * the batch to out[i * ld + col_off .. + dim); ld >= col_off + dim. Synchronous;
+ * calls on one context are serialised.
+ *
+ * How the rows reach host memory (results do not depend on it):
+ *   n <= 512        the kernel reads the ids from and writes the rows to one pinned,
+ *                   device-mapped buffer; the rows are then copied to `out`;
+ *   larger batches  results stream through a ring of pinned buffers that the copy
+ *                   engine fills while a few pooled host threads (kept by the
+ *                   context) move landed chunks to `out`. For trained storages
+ *                   the rows cross PCIe as centroid indices (1 or 1/2 byte per
+ *                   weight, written by the same decode kernel) and those threads
+ *                   expand them with the file's centroids -- bit-identical values,
+ *                   1/4 to 1/8 of the transfer.
  */
 int memb_hip_decode_rows(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off);

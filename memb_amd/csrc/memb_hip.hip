@@ -139,7 +139,6 @@ struct memb_hip_ctx {
     void* smallHost = nullptr;
     void* smallDevice = nullptr;
     bool smallUnavailable = false;
-    size_t stagedLd = 0;
     // pinned ring the DMA engine fills while host threads copy earlier chunks to the caller's rows
     static constexpr int RING = 4;
     void* ring[RING] = {};

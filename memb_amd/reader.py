@@ -176,6 +176,12 @@ class Reader(BaseReader):
         rows = torch.from_numpy(self.resolve_rows(words).view('int32')).to('cuda:{}'.format(self.device))
         return self.rows_embedding_device(rows)
 
+    def tokenizer_embedding_device(self, tokenizer):
+        '''tokenizer_embedding with the weights left on the GPU: a torch.Tensor that
+        torch.nn.Embedding.from_pretrained (or any DLPack consumer) takes as is, so the
+        embedding matrix of a model never crosses PCIe'''
+        return self.batch_embedding_device(tokenizer_word_list(tokenizer))
+
     def info(self):
         '''Facts about the device context (stages the model on first call)'''
         return self._impl.info()

@@ -150,3 +150,7 @@ class ReadersUnion(BaseReader):
         tokenizer : keras.preprocessing.text.Tokenizer
         '''
         return self.batch_embedding(tokenizer_word_list(tokenizer))
+
+    def tokenizer_embedding_device(self, tokenizer):
+        '''tokenizer_embedding merged on the GPU (see batch_embedding_device)'''
+        return self.batch_embedding_device(tokenizer_word_list(tokenizer))

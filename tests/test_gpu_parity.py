@@ -178,6 +178,35 @@ def test_host_batches_cross_pcie_as_centroid_indices(native, make_model, monkeyp
             assert (wide[:, :3] == 9.0).all() and (wide[:, 3 + dim:] == 9.0).all()
 
 
+def test_tokenizer_embedding_host_and_device(native, make_model):
+    # reference python/memb/reader.py:89-111: row idx of the matrix belongs to word_index[word] == idx,
+    # row 0 and unknown words are zeros, num_words cuts the table (idx < num_words)
+    import torch
+    path, words = make_model(3000, 300, 'trained', 4)
+    path2, words2 = make_model(2000, 300, 'trained', 6, seed=5)
+    reader, other = native.Reader(path), native.Reader(path2)
+    checker = oracle.OracleReader(path)
+
+    class Tokenizer:
+        word_index = {words[10]: 1, 'not in the model': 2, words[7]: 3, words[2999]: 5}
+        num_words = None
+
+    for num_words, expected_words in ((None, ['', words[10], 'not in the model', words[7], '', words[2999]]),
+                                      (4, ['', words[10], 'not in the model', words[7]])):
+        Tokenizer.num_words = num_words
+        expected = checker.batch_embedding(expected_words)
+        host = reader.tokenizer_embedding(Tokenizer)
+        assert bits_equal(host, expected) and not host[0].any() and not host[2].any()
+        device = reader.tokenizer_embedding_device(Tokenizer)
+        assert device.is_cuda and bits_equal(device.cpu().numpy(), expected)
+        layer = torch.nn.Embedding.from_pretrained(device)   # takes the device tensor as is
+        assert layer.weight.data_ptr() == device.data_ptr()
+        union = native.ReadersUnion([reader, other], 'concatenate')
+        merged = union.tokenizer_embedding_device(Tokenizer)
+        assert bits_equal(merged.cpu().numpy(), union.tokenizer_embedding(Tokenizer))
+        assert bits_equal(merged[:, :300].cpu().numpy(), expected)
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

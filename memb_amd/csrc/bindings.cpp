@@ -12,6 +12,8 @@
 #include <pybind11/stl.h>
 #include <pybind11/numpy.h>
 
+#include <sys/mman.h>
+
 namespace py = pybind11;
 
 namespace {
@@ -32,6 +34,23 @@ std::shared_ptr<memb::Reader> makeReader(
 // vector<string> caster copies every one). The pointers stay valid while the
 // sequence is alive; a word with an embedded NUL ends there, as it does for the
 // reference's strcmp.
+// A large result array is filled once, right after numpy allocated it: ask for
+// transparent huge pages on it (hosts run THP in "madvise" mode), so that filling
+// 2.6 GB takes ~1300 page faults instead of ~640,000. Advice only; ignored where
+// THP is off.
+void adviseHugePages(void* data, size_t bytes)
+{
+    const size_t huge = size_t(2) << 20;
+    if (bytes < 16 * huge) {
+        return;
+    }
+    const uintptr_t first = (reinterpret_cast<uintptr_t>(data) + huge - 1) / huge * huge;
+    const uintptr_t last = (reinterpret_cast<uintptr_t>(data) + bytes) / huge * huge;
+    if (last > first) {
+        (void)::madvise(reinterpret_cast<void*>(first), last - first, MADV_HUGEPAGE);
+    }
+}
+
 struct WordPointers {
     py::object fast;   // keeps the items alive
     std::vector<const char*> pointers;
@@ -154,6 +173,7 @@ PYBIND11_MODULE(_memb, m) {
                 py::array_t<float> result({words.size(), reader.dim()});
                 auto buffer = result.request();
                 float* destination = reinterpret_cast<float*>(buffer.ptr);
+                adviseHugePages(destination, words.size() * reader.dim() * sizeof(float));
                 {
                     py::gil_scoped_release release;
                     reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, reader.dim(), 0);
@@ -213,6 +233,7 @@ PYBIND11_MODULE(_memb, m) {
                 py::array_t<float> result({n, reader.dim()});
                 auto buffer = result.request();
                 float* destination = reinterpret_cast<float*>(buffer.ptr);
+                adviseHugePages(destination, n * reader.dim() * sizeof(float));
                 const uint32_t* source = reinterpret_cast<const uint32_t*>(rowsBuffer.ptr);
                 {
                     py::gil_scoped_release release;

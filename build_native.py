@@ -51,7 +51,8 @@ def _hipcc():
 
 def build_hip_library(force=False):
     sources = [os.path.join(CSRC, name) for name in
-               ('memb_hip.hip', 'hip_device_common.h', 'hip_trained_kernels.h', 'hip_rowwise_kernels.h', 'codec.h', 'wire.h')]
+               ('memb_hip.hip', 'hip_device_common.h', 'hip_trained_kernels.h', 'hip_rowwise_kernels.h',
+                'hip_host_path.h', 'worker_pool.h', 'codec.h', 'wire.h')]
     sources.append(os.path.join(INCLUDE, 'memb_hip.h'))
     if force or _newer(HIP_LIBRARY, sources):
         _run([
@@ -69,7 +70,7 @@ def build_extension(force=False):
     names = ('bindings.cpp', 'reader.cpp', 'builder.cpp', 'compression_strategy.cpp')
     sources = [os.path.join(CSRC, name) for name in names]
     headers = [os.path.join(CSRC, name) for name in
-               ('reader.h', 'builder.h', 'compression_strategy.h', 'codec.h', 'wire.h')]
+               ('reader.h', 'builder.h', 'compression_strategy.h', 'worker_pool.h', 'codec.h', 'wire.h')]
     headers.append(os.path.join(INCLUDE, 'memb_hip.h'))
     build_hip_library(force)
     if force or _newer(EXTENSION, sources + headers + [HIP_LIBRARY]):

@@ -242,6 +242,29 @@ PYBIND11_MODULE(_memb, m) {
                 return result;
             })
         .def(
+            "rows_embedding_into",
+            [](memb::Reader& reader,
+               py::array_t<uint32_t, py::array::c_style | py::array::forcecast> rows,
+               py::array_t<float, py::array::c_style> out,
+               size_t colOff)
+            {
+                auto rowsBuffer = rows.request();
+                auto buffer = out.request(true);
+                if (rowsBuffer.ndim != 1 || buffer.ndim != 2 || buffer.shape[0] != rowsBuffer.shape[0] ||
+                    static_cast<size_t>(buffer.shape[1]) < colOff + reader.dim()) {
+                    throw std::runtime_error("Output must be a (len(rows), >= col_off + dim) float32 matrix");
+                }
+                const uint32_t* source = reinterpret_cast<const uint32_t*>(rowsBuffer.ptr);
+                float* destination = reinterpret_cast<float*>(buffer.ptr);
+                const size_t n = static_cast<size_t>(rowsBuffer.shape[0]);
+                const size_t ld = static_cast<size_t>(buffer.shape[1]);
+                py::gil_scoped_release release;
+                reader.rowsToBuffer(source, n, destination, ld, colOff);
+            },
+            py::arg("rows"),
+            py::arg("out"),
+            py::arg("col_off") = 0)
+        .def(
             "rows_to_device",
             [](memb::Reader& reader,
                uintptr_t rows,

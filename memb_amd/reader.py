@@ -144,6 +144,11 @@ class Reader(BaseReader):
         '''batch_embedding for already resolved row ids'''
         return self._impl.rows_embedding(np.ascontiguousarray(rows, dtype=np.uint32))
 
+    def rows_embedding_into(self, rows, out, col_off=0):
+        '''rows_embedding into columns [col_off, col_off + dim) of a C-contiguous float32 matrix
+        (or a row range of one: slices of a shared result can be filled from several threads)'''
+        self._impl.rows_embedding_into(np.ascontiguousarray(rows, dtype=np.uint32), out, col_off)
+
     def batch_embedding_into(self, words, out, col_off=0):
         '''Write the batch into columns [col_off, col_off + dim) of a wider float32 matrix'''
         self._impl.batch_embedding_into(words, out, col_off)

@@ -106,7 +106,7 @@ class ShardedReader(BaseReader):
             start, stop = shard_range(len(rows), rank, world)
             try:
                 if stop > start:
-                    out[start:stop] = self._readers[rank].rows_embedding(rows[start:stop])
+                    self._readers[rank].rows_embedding_into(rows[start:stop], out[start:stop])
             except Exception as error:  # re-raised on the calling thread
                 errors.append(error)
 

@@ -148,6 +148,9 @@ def test_host_copy_ring_chunks_threads_and_slices(native, make_model, monkeypatc
         reader.batch_embedding_into([keys[r] if r < len(keys) else '?' for r in rows], wide, 2)
         assert bits_equal(wide[:, 2:302], expected), (chunk_rows, threads, slice_words)
         assert (wide[:, :2] == -1.0).all() and (wide[:, 302:] == -1.0).all()
+        again = np.full((len(rows), 301), -2.0, dtype=np.float32)
+        reader.rows_embedding_into(rows[100:], again[100:], 1)   # a row range of a larger matrix
+        assert bits_equal(again[100:, 1:], expected[100:]) and (again[:100] == -2.0).all() and (again[:, 0] == -2.0).all()
 
 
 def test_host_batches_cross_pcie_as_centroid_indices(native, make_model, monkeypatch):

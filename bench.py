@@ -98,6 +98,42 @@ def cpu_baseline(path, rows_host, dim):
     }, out
 
 
+def host_api_timings(reader, path, rows_host):
+    """reader[words] -> numpy for the whole batch and for 100 000 of its words, best of 3; and the CPU
+    restatement's Reader.batch_embedding (word search + decode, all host threads) on the 100 000."""
+    import numpy as np
+    import oracle
+    keys = reader.keys()
+    words = [keys[r] if r < len(keys) else 'not a word' for r in rows_host]
+    rng = np.random.default_rng(3)
+    sample = [words[i] for i in rng.integers(0, len(words), size=min(100000, len(words)))]
+
+    def best_of(call, repeats=3):
+        best = float('inf')
+        for _ in range(repeats):
+            start = time.perf_counter()
+            result = call()
+            best = min(best, time.perf_counter() - start)
+            del result
+        return best
+
+    whole = best_of(lambda: reader.batch_embedding(words))
+    part = best_of(lambda: reader.batch_embedding(sample))
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    cpu_part = best_of(lambda: checker.batch_embedding(sample))
+    return {
+        'note': 'words in, numpy float32 out (word search, PCIe, host memory, result allocation included); never part of value',
+        'batch_words': len(words),
+        'batch_seconds': whole,
+        'batch_embeddings_per_s': len(words) / whole,
+        'sample_words': len(sample),
+        'sample_seconds': part,
+        'sample_embeddings_per_s': len(sample) / part,
+        'cpu_port_sample_seconds': cpu_part,
+        'cpu_port_sample_embeddings_per_s': len(sample) / cpu_part,
+    }
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
@@ -242,6 +278,12 @@ def main():
         got = out.cpu().numpy()
         parity = 'bit-exact' if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
 
+    # Not part of `value`: what a caller of the reference's API sees (words in, numpy out; word search,
+    # PCIe and host memory included), next to the restated CPU Reader on the same words and host cores.
+    host_api = None
+    if not args.no_cpu_baseline:
+        host_api = host_api_timings(reader, path, rows_host)
+
     achieved_gbps = algorithmic_bytes / (kernel_avg_ms * 1e-3) / 1e9
     traffic = None
     traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
@@ -289,6 +331,7 @@ def main():
         },
         'cpu_baseline': baseline,
         'parity_vs_cpu_checker': parity,
+        'host_api': host_api,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
         'secondary': secondary,
         'geometry': {k: info[k] for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',

@@ -260,3 +260,27 @@ def test_writer_round_trip_properties(native, tmp_path):
                 span = vectors.max(axis=1, keepdims=True) - vectors.min(axis=1, keepdims=True)
                 step = span / min(2 ** bits, 255)
                 assert np.all(np.abs(vectors - decoded) <= step * 1.0001 + 1e-6 * scale), (trial, dim, bits)
+
+
+def test_product_never_touches_the_checker():
+    # oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's
+    # cpu_baseline leg may use it; the shipped package and its libraries must not import,
+    # link or load it, and there is no CPU decode in them to fall back on
+    import re
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    package = os.path.join(repo, 'memb_amd')
+    for root, _, files in os.walk(package):
+        for name in files:
+            if name.endswith(('.py', '.h', '.cpp', '.hip')):
+                with open(os.path.join(root, name), encoding='utf-8') as handle:
+                    text = handle.read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', text, re.M), name
+                assert 'memb_oracle' not in text and 'libmemb_ref' not in text, name
+    for library in ('libmemb_hip.so',):
+        needed = subprocess.run(['readelf', '-d', os.path.join(package, library)], stdout=subprocess.PIPE, text=True).stdout
+        assert 'oracle' not in needed and 'memb_ref' not in needed
+    with open(os.path.join(repo, '__graft_entry__.py')) as handle:
+        entry = handle.read()
+    build_body = entry[entry.index('def build('):entry.index('def smoke(')]
+    assert not re.search(r'^\s*(import|from)\s+oracle\b', build_body, re.M)   # building the checker is not using it

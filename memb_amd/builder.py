@@ -1,49 +1,38 @@
+"""Write side: collect (word, vector) pairs and write one memb file.
+
+Same constructor and methods as the reference's `memb.Builder`
+(python/memb/builder.py:4-39). Here the writer exists to produce the files the
+lookup path reads -- test fixtures and benchmark models -- and follows the
+reference's encoders step by step (memb_amd/csrc/compression_strategy.cpp).
+"""
+import os
+
 from . import _memb
 
 
 class Builder:
-    '''Builder object quantizes embeddings with given precision, creates index
-    and saves it to file on request (reference python/memb/builder.py:4-39)
-    Parameters
-    ----------
-    dim : int
-        Dimension of word vectors
-    storage_type : str
-        Type of storage for embeddings. Supported values are 'full', 'uniform' and
-        'trained'
-    bits_per_weight : int
-        Number of bits used to represent single weight. If this value is beyond
-        range accepted by quantization strategy, closest supported value will be
-        used instead
-    '''
+    """Accumulates vectors and writes them, compressed, on `save`.
+
+    dim              length every vector must have
+    storage_type     'trained' (k-means codebook + Huffman), 'uniform'
+                     (per-word min/max, one byte per weight) or 'full' (fp32)
+    bits_per_weight  precision asked of the storage; values a storage cannot
+                     honour are clamped by it
+    """
 
     def __init__(self, dim, storage_type='trained', bits_per_weight=4):
-        self._impl = _memb.Builder(dim, storage_type, bits_per_weight)
+        self._native = _memb.Builder(dim, storage_type, bits_per_weight)
 
     def add_word(self, word, vector):
-        '''Add word to builder
-        Parameters
-        ----------
-        word : str
-
-        vector : numpy.float32
-        '''
-        self._impl.add_word(word, vector)
+        """One word; `vector` is a float32 sequence of length dim. Raises on a
+        wrong length or a word added before."""
+        self._native.add_word(word, vector)
 
     def add_words(self, words, matrix):
-        '''Add many words at once (not in the reference API)
-        Parameters
-        ----------
-        words : list of str
-
-        matrix : numpy.float32 of shape (len(words), dim)
-        '''
-        self._impl.add_words(words, matrix)
+        """Many words in one call: `matrix` is float32 of shape (len(words), dim).
+        Not part of the reference API; same checks as add_word, row by row."""
+        self._native.add_words(words, matrix)
 
     def save(self, filename):
-        '''Compress builder content and save it to file
-        Parameters
-        ----------
-        filename : str or pathlib.Path
-        '''
-        self._impl.save(str(filename))
+        """Compress what was added and write the file (str or path-like)."""
+        self._native.save(os.fspath(filename))

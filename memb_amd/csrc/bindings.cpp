@@ -129,11 +129,8 @@ PYBIND11_MODULE(_memb, m) {
                 if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size()) {
                     throw std::runtime_error("Expected a matrix with one row per word");
                 }
-                const float* values = reinterpret_cast<const float*>(buffer.ptr);
-                size_t dim = static_cast<size_t>(buffer.shape[1]);
-                for (size_t i = 0; i < words.size(); ++i) {
-                    builder.addWord(words[i], values + i * dim, dim);
-                }
+                builder.addWords(
+                    words, reinterpret_cast<const float*>(buffer.ptr), static_cast<size_t>(buffer.shape[1]));
             })
         .def(
             "save",

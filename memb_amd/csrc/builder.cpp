@@ -1,23 +1,42 @@
 #include "builder.h"
 
 #include <fstream>
+#include <ostream>
+#include <sstream>
 #include <stdexcept>
 
 namespace memb {
 
-// reference src/builder.cpp:20-32
-Builder::Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight):
-    dim_(dim),
-    storageType_(storageType),
-    compressor_(createCompressionStrategy(storageType)->createCompressor(builder_, bitsPerWeight))
-{}
-
-Builder::Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight):
-    dim_(dim)
+void Builder::attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight)
 {
-    auto compressionStrategy = createCompressionStrategy(storageName);
-    storageType_ = compressionStrategy->storageType();
-    compressor_ = compressionStrategy->createCompressor(builder_, bitsPerWeight);
+    storageType_ = strategy->storageType();
+    compressor_ = strategy->createCompressor(buffer_, bitsPerWeight);
+}
+
+Builder::Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight): dim_(dim)
+{
+    attach(createCompressionStrategy(storageType), bitsPerWeight);
+}
+
+Builder::Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight): dim_(dim)
+{
+    attach(createCompressionStrategy(storageName), bitsPerWeight);
+}
+
+// The two refusals and their messages are the reference's (src/builder.cpp:12-16, 34-48);
+// its tests match on them (src/tests.cpp:115-136).
+void Builder::addWord(const std::string& word, const float* embedding, size_t size)
+{
+    if (size != dim_) {
+        std::ostringstream message;
+        message << "Vector dimension (" << size << ") for word " << word << " doesn't match builder dimension ("
+                << dim_ << ")";
+        throw std::runtime_error(message.str());
+    }
+    if (!seen_.insert(word).second) {
+        throw std::runtime_error("Attempt to add duplicate word " + word + " to index");
+    }
+    compressor_->add(word, embedding, dim_);
 }
 
 void Builder::addWord(const std::string& word, const std::vector<float>& embedding)
@@ -25,42 +44,38 @@ void Builder::addWord(const std::string& word, const std::vector<float>& embeddi
     addWord(word, embedding.data(), embedding.size());
 }
 
-// reference src/builder.cpp:34-48 (messages: :12-16)
-void Builder::addWord(const std::string& word, const float* embedding, size_t size)
+void Builder::addWords(const std::vector<std::string>& words, const float* matrix, size_t rowLength)
 {
-    if (size != dim_) {
-        throw std::runtime_error(
-            "Vector dimension (" + std::to_string(size) + ") for word " + word +
-            " doesn't match builder dimension (" + std::to_string(dim_) + ")");
+    seen_.reserve(seen_.size() + words.size());
+    for (size_t row = 0; row < words.size(); ++row) {
+        addWord(words[row], matrix + row * rowLength, rowLength);
     }
-    auto insertionResult = addedWords_.insert(word);
-    if (!insertionResult.second) {
-        throw std::runtime_error("Attempt to add duplicate word " + word + " to index");
-    }
-    compressor_->add(word, embedding, dim_);
 }
 
-// reference src/builder.cpp:50-61
+// Root table Index{storage_type, storage, dim} behind the "memb" identifier
+// (reference src/flatbuffers/embeddings.fbs:7-19, src/builder.cpp:50-61).
 void Builder::dump(std::ostream& sink)
 {
-    auto storage = compressor_->finalize();
-    builder_.startTable();
-    builder_.addScalar<uint32_t>(wire::field::Index_dim, static_cast<uint32_t>(dim_));
-    builder_.addScalar<uint8_t>(wire::field::Index_storage_type, static_cast<uint8_t>(storageType_));
-    builder_.addOffset(wire::field::Index_storage, storage);
-    auto root = builder_.endTable();
-    builder_.finish(root, wire::FILE_IDENTIFIER);
-
-    sink.write(reinterpret_cast<const char*>(builder_.data()), static_cast<std::streamsize>(builder_.size()));
+    const wire::BufferBuilder::Ref storage = compressor_->finalize();
+    buffer_.startTable();
+    buffer_.addScalar<uint32_t>(wire::field::Index_dim, static_cast<uint32_t>(dim_));
+    buffer_.addScalar<uint8_t>(wire::field::Index_storage_type, static_cast<uint8_t>(storageType_));
+    buffer_.addOffset(wire::field::Index_storage, storage);
+    buffer_.finish(buffer_.endTable(), wire::FILE_IDENTIFIER);
+    sink.write(reinterpret_cast<const char*>(buffer_.data()), static_cast<std::streamsize>(buffer_.size()));
 }
 
 void Builder::save(const std::string& filename)
 {
-    std::ofstream f(filename, std::ios::binary);
-    if (!f) {
+    std::ofstream file(filename, std::ios::binary | std::ios::trunc);
+    if (!file) {
         throw std::runtime_error("failed opening file for writing: " + filename);
     }
-    dump(f);
+    dump(file);
+    file.flush();
+    if (!file) {
+        throw std::runtime_error("failed writing file: " + filename);
+    }
 }
 
 }  // namespace memb

@@ -1,12 +1,14 @@
-// memb::Builder -- the reference's write API (src/builder.h:11-26): collect
-// words, compress with the chosen strategy, write one "memb" file.
+// Write side of the file format. Interface of the reference's memb::Builder
+// (src/builder.h:11-26): words go in one at a time, dump()/save() compress them
+// with the storage's Compressor and emit one buffer: Index{dim, storage}.
 #pragma once
 
 #include "compression_strategy.h"
 
-#include <ostream>
-#include <set>
+#include <iosfwd>
+#include <memory>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 namespace memb {
@@ -16,17 +18,27 @@ public:
     Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight);
     Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight);
 
-    void addWord(const std::string& word, const std::vector<float>& embedding);
+    // Throws std::runtime_error for a vector of the wrong length and for a repeated word.
     void addWord(const std::string& word, const float* embedding, size_t size);
-    void dump(std::ostream& sink);
+    void addWord(const std::string& word, const std::vector<float>& embedding);
+    // Row i of the row-major matrix (rowLength floats per row) belongs to words[i]; the
+    // same checks, word by word, so a failure leaves the words before it added.
+    void addWords(const std::vector<std::string>& words, const float* matrix, size_t rowLength);
+
+    size_t dim() const { return dim_; }
+    size_t wordCount() const { return seen_.size(); }
+
+    void dump(std::ostream& sink);            // the finished buffer, as bytes
     void save(const std::string& filename);
 
 private:
-    size_t dim_;
-    wire::Storage storageType_;
-    wire::BufferBuilder builder_;
+    void attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight);
+
+    const size_t dim_;
+    wire::Storage storageType_ = wire::Storage_NONE;
+    wire::BufferBuilder buffer_;
     std::shared_ptr<Compressor> compressor_;
-    std::set<std::string> addedWords_;
+    std::unordered_set<std::string> seen_;
 };
 
 }  // namespace memb

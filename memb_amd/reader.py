@@ -1,3 +1,8 @@
+"""Read side: the reference's `memb.Reader` interface (python/memb/reader.py) over
+the HIP batch-lookup path. `reader[word]` / `reader[list_of_words]` return numpy
+float32 exactly as the reference does; words the model does not know give zeros.
+Everything below "additions" is new: row ids, strided outputs, results that stay
+on the GPU."""
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -6,32 +11,27 @@ from . import _memb
 
 
 class BaseReader(ABC):
+    """What Reader, ReadersUnion and ShardedReader have in common: indexing and the
+    exports built on batch_embedding."""
+
     def __getitem__(self, key):
-        '''Obtain vector representation for a word or a list of words
-        (reference python/memb/reader.py:6-17)
-        Parameters
-        ----------
-        key: str of list of str
-        '''
+        # a str selects one vector (1-D), a list a matrix (2-D); nothing else is accepted
         if isinstance(key, str):
             return self.word_embedding(key)
-        elif isinstance(key, list):
+        if isinstance(key, list):
             return self.batch_embedding(key)
-        else:
-            raise TypeError('Key type is not supported')
+        raise TypeError('Key type is not supported')
 
     def to_keyed_vectors(self):
-        '''Export model content to KeyedVectors object (reference python/memb/reader.py:19-30)'''
+        """The whole model as a gensim KeyedVectors (one full-vocabulary lookup)"""
         try:
             from gensim.models import KeyedVectors
         except ImportError:
             raise ImportError('You must install gensim for KeyedVectors export')
-
-        keyed_vectors = KeyedVectors(self.dim)
-        words = self.keys()
-        keyed_vectors.add(words, self.batch_embedding(words))
-
-        return keyed_vectors
+        vocabulary = self.keys()
+        exported = KeyedVectors(self.dim)
+        exported.add(vocabulary, self.batch_embedding(vocabulary))
+        return exported
 
     @abstractmethod
     def keys(self):
@@ -51,49 +51,45 @@ class BaseReader(ABC):
 
 
 def tokenizer_word_list(tokenizer):
-    '''Words of a keras Tokenizer laid out by index, '' in unused slots
-    (reference python/memb/reader.py:100-109)'''
-    word_indices = tokenizer.word_index.items()
-    if tokenizer.num_words is not None:
-        word_indices = [item for item in word_indices if item[1] < tokenizer.num_words]
-        max_index = tokenizer.num_words
+    """The words of a keras Tokenizer placed at their indices, '' where an index
+    has no word (index 0 never has one). With `num_words` set only indices below
+    it are kept, as the reference does (python/memb/reader.py:100-109); the
+    embedding matrix of the tokenizer is then batch_embedding of this list."""
+    entries = list(tokenizer.word_index.items())
+    limit = tokenizer.num_words
+    if limit is None:
+        limit = max(index for _, index in entries) + 1
     else:
-        max_index = max([item[1] for item in word_indices]) + 1
-
-    sorted_word_list = [''] * max_index
-    for word, idx in word_indices:
-        sorted_word_list[idx] = word
-    return sorted_word_list
+        entries = [(word, index) for word, index in entries if index < limit]
+    slots = [''] * limit
+    for word, index in entries:
+        slots[index] = word
+    return slots
 
 
 class Reader(BaseReader):
-    '''Reader object allows to obtain embeddings for requested words quickly,
-    decoding them on the GPU on the fly (reference python/memb/reader.py:49-111)
-    Parameters
-    ----------
-    filename : str or pathib.Path
-    num_threads : int
-        Number of host threads used to look up large batches of words.
-        Pass 0 to use as much threads as there are cores in the system
-    device : int, optional
-        HIP device that holds the model and runs the lookups (not in the
-        reference API). Default: environment variable MEMB_HIP_DEVICE, else 0
-    Attributes
-    ----------
-    dim : int
-        Embeddings dimension
-    '''
+    """One memb file, staged to a GPU on first use; lookups decode there.
+
+    filename     str or path-like
+    num_threads  host threads for the word search of large batches, 0 = one per core
+    device       HIP device index (not in the reference API); default: environment
+                 variable MEMB_HIP_DEVICE, else 0
+    max_direct_decode_bits
+                 width of the first-level decode table, 0 = library default (results
+                 never depend on it; the reference's tests force 1, src/tests.cpp:76-88)
+    """
 
     def __init__(self, filename, num_threads=0, device=None, max_direct_decode_bits=0):
         super().__init__()
+        name = str(filename)
         if device is None and not max_direct_decode_bits:
-            self._impl = _memb.Reader(str(filename), num_threads)
+            self._impl = _memb.Reader(name, num_threads)
         else:
-            self._impl = _memb.Reader(
-                str(filename), num_threads, -1 if device is None else int(device), max_direct_decode_bits)
+            self._impl = _memb.Reader(name, num_threads, -1 if device is None else int(device), max_direct_decode_bits)
 
     @property
     def dim(self):
+        """length of every vector"""
         return self._impl.dim()
 
     @property
@@ -104,33 +100,20 @@ class Reader(BaseReader):
         return self._impl.size()
 
     def keys(self):
-        '''List of words contained in model'''
+        """all words of the model, sorted"""
         return self._impl.keys()
 
     def word_embedding(self, word):
-        '''Obtain one-dimensional array of type float32 for a given word.
-        If word is not present in the model, array filled with zeros is returned
-        Parameters
-        ----------
-        word : str
-        '''
+        """float32 vector of shape (dim,); zeros for an unknown word"""
         return self._impl.word_embedding(word)
 
     def batch_embedding(self, words):
-        '''Obtain two-dimensional array of type float32 for a given list of words.
-        Positions for words not present in the model are filled with zeros
-        Parameters
-        ----------
-        words : list of str
-        '''
+        """float32 matrix of shape (len(words), dim), one row per word in the given
+        order; rows of unknown words are zeros"""
         return self._impl.batch_embedding(words)
 
     def tokenizer_embedding(self, tokenizer):
-        '''Convert keras.preprocessing.text.Tokenizer to weights of Embedding layer
-        Parameters
-        ----------
-        tokenizer : keras.preprocessing.text.Tokenizer
-        '''
+        """weights for an Embedding layer indexed like the keras Tokenizer"""
         return self.batch_embedding(tokenizer_word_list(tokenizer))
 
     # ---- additions: row ids and device-resident results ----

@@ -210,6 +210,32 @@ def test_tokenizer_embedding_host_and_device(native, make_model):
         assert bits_equal(merged[:, :300].cpu().numpy(), expected)
 
 
+def test_device_entry_point_can_be_captured_into_a_graph(native, make_model):
+    # memb_hip_decode_rows_device only enqueues (no allocation, no synchronisation once a kernel
+    # variant has been launched once), so a HIP graph can hold it; replays give the same bits
+    import torch
+    path, words = make_model(20000, 300, 'trained', 4)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    host_rows = np.random.default_rng(8).integers(0, len(words), size=5000).astype(np.uint32)
+    host_rows[::9] = 0xFFFFFFFF
+    rows = torch.from_numpy(host_rows.view(np.int32)).cuda()
+    out = torch.empty((len(host_rows), 300), dtype=torch.float32, device='cuda')
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        reader.rows_embedding_device(rows, out=out)   # first launch configures the kernel
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        reader.rows_embedding_device(rows, out=out)
+    expected = checker.rows_embedding(host_rows)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bits_equal(out.cpu().numpy(), expected)
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

@@ -65,7 +65,10 @@ typedef struct memb_hip_trained_desc {
      * counterpart of maxDirectDecodeBitLength (reference
      * src/trained_compression.h:11-16). 0 selects the library default. Results
      * do not depend on it; small values force the two-level path, which is how
-     * the reference tests that branch (reference src/tests.cpp:76-88).
+     * the reference tests that branch (reference src/tests.cpp:76-88). A hint:
+     * it is capped at 12 and raised as far as needed for the tables to fit into
+     * on-chip memory (codes of up to 16 bits make narrow first levels expensive);
+     * memb_hip_ctx_info.root_bits reports the width in use.
      */
     uint32_t max_direct_bits;
 } memb_hip_trained_desc;

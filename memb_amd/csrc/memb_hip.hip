@@ -712,8 +712,19 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
                 throw std::runtime_error("Huffman symbol without a centroid");
             }
         }
+        // First-level width: a hint (results never depend on it). With long codes a narrow first
+        // level makes the second-level tables large -- 2^(longest code - width) entries each --
+        // so the width is raised until the whole table takes at most 64 KiB of the 160 KiB of LDS,
+        // which leaves room for the bitstream slots of at least a few wavefronts.
         uint32_t limit = desc->max_direct_bits ? desc->max_direct_bits : envUint("MEMB_HIP_ROOT_BITS", 11);
-        ctx->hostTable = memb::buildDecodeTable(lengths, std::min<uint32_t>(limit, 12));
+        limit = std::max<uint32_t>(1, std::min<uint32_t>(limit, 12));
+        for (;;) {
+            ctx->hostTable = memb::buildDecodeTable(lengths, limit);
+            if (ctx->hostTable.entries.size() * 8 <= 64 * 1024 || limit >= 12) {
+                break;
+            }
+            ++limit;
+        }
     } catch (const std::exception& error) {
         return fail(MEMB_HIP_ERR_INVALID, error.what());
     }

@@ -236,6 +236,72 @@ def test_device_entry_point_can_be_captured_into_a_graph(native, make_model):
         assert bits_equal(out.cpu().numpy(), expected)
 
 
+def test_arbitrary_prefix_codes_through_the_c_abi(native):
+    # Storages the reference's writer cannot produce (its k-means prunes rare clusters, which bounds
+    # the code lengths): random complete prefix codes with up to 255 symbols and code lengths up to
+    # 16 bits -- the format's maximum, PrefixCode::code is a uint16 (reference src/prefix_code.h:10-13)
+    # -- handed to the C ABI as a crafted description, for several first-level table widths and
+    # batch sizes on both sides of the small-batch threshold. Expected rows: the symbols themselves.
+    import ctypes
+    from test_oracle_vs_reference import random_code
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+
+    class Desc(ctypes.Structure):
+        _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64),
+                    ('packed_values', ctypes.c_void_p), ('packed_values_bytes', ctypes.c_uint64),
+                    ('value_offsets', ctypes.c_void_p),
+                    ('keys', ctypes.c_void_p), ('n_keys', ctypes.c_uint32),
+                    ('size_offsets', ctypes.c_void_p), ('n_size_offsets', ctypes.c_uint32),
+                    ('centroids', ctypes.c_void_p), ('n_centroids', ctypes.c_uint32),
+                    ('max_direct_bits', ctypes.c_uint32)]
+
+    rng = np.random.default_rng(2024)
+    codec = oracle.Codec('oracle')
+    longest = 0
+    for trial, (symbols, dim, n_rows) in enumerate(((255, 61, 700), (200, 300, 40), (17, 5, 900), (2, 33, 64), (90, 128, 600), (254, 8, 513))):
+        while True:
+            keys, lengths, size_offsets = random_code(rng, symbols)
+            if trial != 0 or max(lengths) >= 15:   # the first storage must reach (nearly) the longest codes
+                break
+        longest = max(longest, max(lengths))
+        keys = np.ascontiguousarray(keys, dtype=np.uint8)
+        size_offsets = np.ascontiguousarray(size_offsets, dtype=np.uint32)
+        codes, bits = codec.canonical_codes(keys, lengths)
+        centroids = rng.standard_normal(255).astype(np.float32)
+        # symbol draws that favour the long codes (uniform over symbols, not over probability mass)
+        picks = rng.integers(0, symbols, size=(n_rows, dim))
+        symbol_rows = keys[picks]
+        streams, offsets = [], []
+        position = 0
+        for row in symbol_rows:
+            stream = codec.bitstream_pack(codes[row], bits[row])
+            offsets.append(position)
+            streams.append(stream)
+            position += len(stream)
+        packed = np.concatenate(streams) if position else np.zeros(1, dtype=np.uint8)
+        offsets = np.array(offsets, dtype=np.uint32)
+        expected = centroids[symbol_rows]
+        for max_direct_bits in (0, 1, 5, 12):
+            desc = Desc(dim, n_rows, packed.ctypes.data, position, offsets.ctypes.data, keys.ctypes.data, len(keys),
+                        size_offsets.ctypes.data, len(size_offsets), centroids.ctypes.data, len(centroids), max_direct_bits)
+            context = ctypes.c_void_p()
+            assert library.memb_hip_ctx_create_trained(ctypes.byref(context), 0, ctypes.byref(desc)) == 0, \
+                library.memb_hip_last_error()
+            for count in (n_rows, min(n_rows, 100)):
+                ids = rng.permutation(n_rows)[:count].astype(np.uint32)
+                ids[::7] = 0xFFFFFFFF
+                out = np.full((count, dim), 5.0, dtype=np.float32)
+                code = library.memb_hip_decode_rows(
+                    context, ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(count),
+                    out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(dim), ctypes.c_size_t(0))
+                assert code == 0, library.memb_hip_last_error()
+                want = np.where((ids == 0xFFFFFFFF)[:, None], np.float32(0), expected[np.minimum(ids, n_rows - 1)])
+                assert bits_equal(out, want), (trial, symbols, dim, max_direct_bits, count, max(lengths))
+            library.memb_hip_ctx_destroy(context)
+    assert longest >= 15
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

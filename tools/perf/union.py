@@ -41,3 +41,16 @@ wide=torch.empty((n,608),dtype=torch.float32,device='cuda')
 print('two launches, ld 608 (rows 32-B aligned): %.3f ms'%timeit(lambda: (a.rows_embedding_device(ta,out=wide,col_off=0), b.rows_embedding_device(tb,out=wide,col_off=304))))
 wide=torch.empty((n,640),dtype=torch.float32,device='cuda')
 print('two launches, ld 640, col_off 0 / 320 (halves 128-B aligned): %.3f ms'%timeit(lambda: (a.rows_embedding_device(ta,out=wide,col_off=0), b.rows_embedding_device(tb,out=wide,col_off=320))))
+s1=torch.cuda.Stream(); s2=torch.cuda.Stream()
+def concurrent():
+    cur=torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s1): a.rows_embedding_device(ta,out=out,col_off=0)
+    with torch.cuda.stream(s2): b.rows_embedding_device(tb,out=out,col_off=300)
+    cur.wait_stream(s1); cur.wait_stream(s2)
+t=timeit(concurrent); concurrent(); torch.cuda.synchronize()
+print('two launches on two streams (concurrent): %.3f ms  same bits: %s'%(t,bool(torch.equal(out.view(torch.int32),ref.view(torch.int32)))))
+for ld in (300, 304, 320, 400, 600, 1200):
+    wide=torch.empty((n,ld),dtype=torch.float32,device='cuda')
+    print('one reader, ld %4d: %.3f ms'%(ld,timeit(lambda: a.rows_embedding_device(ta,out=wide,col_off=0))))
+    del wide

@@ -18,6 +18,7 @@ struct TrainedParams {
     const uint32_t* streamStarts;   // [nRows + 1] first 16-byte piece of each row's run
     const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
+                                    // (both hold 32-bit entries when indexWide: rows longer than 65535 bits)
     const uint32_t* table;          // 8-byte entries, see TableEntry
     const float* codebook;          // 256 centroids, or 256 centroid pairs (FAST)
     unsigned long long nRows;
@@ -36,6 +37,7 @@ struct TrainedParams {
     uint32_t pieceMagic;      // fastDivide magic for dim / 4 (vector output)
     uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
     uint32_t indexSegmentSymbols;
+    uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
     uint32_t debugFlags;      // measurement only (MEMB_HIP_DEBUG): 1 = skip decode, 2 = skip output
     uint32_t accumulate;      // epilogue: add to what the output already holds ...
     float divisor;            // ... and / or divide by this (0 = no division)
@@ -101,8 +103,8 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     if (row < p.nRows) {
         meta.start = p.streamStarts[row];
         if (role.segment > 0) {
-            meta.segmentBits =
-                p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1];
+            const unsigned long long at = static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1;
+            meta.segmentBits = p.indexWide ? reinterpret_cast<const uint32_t*>(p.segmentIndex)[at] : p.segmentIndex[at];
         }
     }
     return meta;
@@ -204,8 +206,12 @@ __device__ __forceinline__ void decodeSegment(
             // one lane per word here; record where every indexSegmentSymbols-th symbol starts
             if (j == nextIndexSymbol) {
                 if (present && indexSlot + 1 < p.indexLanes) {
-                    p.segmentIndexOut[static_cast<unsigned long long>(meta.row) * (p.indexLanes - 1) + indexSlot] =
-                        static_cast<uint16_t>(bitPos);
+                    const unsigned long long at = static_cast<unsigned long long>(meta.row) * (p.indexLanes - 1) + indexSlot;
+                    if (p.indexWide) {
+                        reinterpret_cast<uint32_t*>(p.segmentIndexOut)[at] = bitPos;
+                    } else {
+                        p.segmentIndexOut[at] = static_cast<uint16_t>(bitPos);
+                    }
                 }
                 ++indexSlot;
                 nextIndexSymbol += p.indexSegmentSymbols;

@@ -124,7 +124,8 @@ struct memb_hip_ctx {
     uint32_t tableDwords = 0;
     uint32_t maxStreamBytes = 0;
     uint32_t slotDwords = 0;
-    uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]
+    uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
+    bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
@@ -313,6 +314,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.streams = ctx->streams;
     params.streamStarts = ctx->streamStarts;
     params.segmentIndex = ctx->segmentIndex;
+    params.indexWide = ctx->indexWide ? 1u : 0u;
     params.table = ctx->table;
     params.codebook = ctx->codebook;
     params.nRows = ctx->nRows;
@@ -423,22 +425,28 @@ int buildSegmentIndex(memb_hip_ctx* ctx)
     params.n = ctx->nRows;
     params.lanesPerWord = 1;
     params.laneMagic = 0;
-    params.wordsPerWave = WAVE;
     params.segmentSymbols = (ctx->dim + 7) / 8 * 8;
     params.keyRowBytes = 0;
     params.keyTileDwords = 0;
     params.indexLanes = ctx->lanesPerWord;
     params.indexSegmentSymbols = ctx->segmentSymbols;
 
+    // one lane per word, normally 64 words per wavefront; fewer (the other lanes idle) when
+    // 64 bitstream slots are more than LDS holds
+    uint32_t wordsPerWave = WAVE;
+    while (wordsPerWave > 1 && trainedLdsBytes(ctx, 1, wordsPerWave, false) > ctx->ldsLimit) {
+        wordsPerWave /= 2;
+    }
     uint32_t waves = 4;
-    while (waves > 1 && trainedLdsBytes(ctx, waves, WAVE, false) > ctx->ldsLimit) {
+    while (waves > 1 && trainedLdsBytes(ctx, waves, wordsPerWave, false) > ctx->ldsLimit) {
         waves /= 2;
     }
-    const uint32_t ldsBytes = trainedLdsBytes(ctx, waves, WAVE, false);
+    const uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, false);
     if (ldsBytes > ctx->ldsLimit) {
-        return fail(MEMB_HIP_ERR_INVALID, "bitstream slots do not fit into LDS");
+        return fail(MEMB_HIP_ERR_INVALID, "a row's bitstream does not fit into LDS");
     }
-    const size_t tiles = (ctx->nRows + WAVE - 1) / WAVE;
+    params.wordsPerWave = wordsPerWave;
+    const size_t tiles = (ctx->nRows + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
     hipError_t status = launchTrainedMode<OUT_INDEX>(ctx, params, blocks, waves * WAVE, ldsBytes, ctx->stream);
     if (status == hipSuccess) {
@@ -799,19 +807,6 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
         !envUint("MEMB_HIP_NO_FAST", 0);
     ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
 
-    // Lanes per word (G) and symbols per lane (S). The side index stores 16-bit
-    // bit offsets, so rows longer than 65535 bits keep one lane per word.
-    {
-        uint32_t lanes = envUint("MEMB_HIP_LANES", 8);
-        lanes = std::max<uint32_t>(1, std::min<uint32_t>(lanes, WAVE));
-        if (uint64_t(desc->dim) * std::max<uint32_t>(ctx->hostTable.maxCodeBits, 1) >= 65536 || desc->dim < 8) {
-            lanes = 1;
-        }
-        const uint32_t group = ctx->fast ? 8 : 4;
-        ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
-        ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
-    }
-
     const double tSorted = now();
     // Re-packed layout: row r's stream occupies ceil(bytes / 16) pieces from streamStarts[r].
     std::vector<uint32_t> streamStarts(desc->n_rows + 1, 0);
@@ -883,6 +878,26 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     }
     const double tRepacked = now();
     if (code == MEMB_HIP_OK) {
+        // Lanes per word (G) and symbols per lane (S): MEMB_HIP_LANES (default 8, the measured
+        // optimum for 300-dimensional rows) or, for rows so long that a wavefront's 64 / G
+        // bitstream slots and symbol rows would not fit into LDS, the next power of two that does;
+        // rows of fewer than 8 weights are not split.
+        uint32_t lanes = std::max<uint32_t>(1, std::min<uint32_t>(envUint("MEMB_HIP_LANES", 8), WAVE));
+        if (desc->dim < 8) {
+            lanes = 1;
+        }
+        const uint32_t group = ctx->fast ? 8 : 4;
+        for (;;) {
+            ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
+            ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
+            if (lanes >= WAVE || trainedLdsBytes(ctx, 1, WAVE / ctx->lanesPerWord, true) <= ctx->ldsLimit) {
+                break;
+            }
+            lanes = std::min<uint32_t>(WAVE, lanes < 8 ? 8 : 2 * lanes);
+        }
+        ctx->indexWide = uint64_t(ctx->maxStreamBytes) * 8 + 64 >= 65536;
+    }
+    if (code == MEMB_HIP_OK) {
         code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);
     }
     if (code == MEMB_HIP_OK) {
@@ -927,7 +942,9 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
         }
     }
     if (code == MEMB_HIP_OK && ctx->lanesPerWord > 1) {
-        code = deviceAlloc(ctx, &ctx->segmentIndex, size_t(desc->n_rows) * (ctx->lanesPerWord - 1) * sizeof(uint16_t));
+        code = deviceAlloc(
+            ctx, &ctx->segmentIndex,
+            size_t(desc->n_rows) * (ctx->lanesPerWord - 1) * (ctx->indexWide ? sizeof(uint32_t) : sizeof(uint16_t)));
     }
     if (code == MEMB_HIP_OK) {
         code = buildSegmentIndex(ctx);
@@ -1111,14 +1128,16 @@ int decode_rows_checked(
     // buffer instead: the kernel reads the ids from it and writes the rows into it
     // over PCIe, the host then copies them to the caller's (possibly strided) rows.
     constexpr size_t SMALL_WORDS = 512;
-    if (n <= SMALL_WORDS && !ctx->smallUnavailable) {
-        const size_t rowBytes = size_t(ctx->dim) * sizeof(float);
+    const size_t rowBytes = size_t(ctx->dim) * sizeof(float);
+    // (at most 2 MiB of rows that way: very wide rows leave the small path after fewer words)
+    const size_t smallWords = std::min<size_t>(SMALL_WORDS, (size_t(2) << 20) / rowBytes);
+    if (n <= smallWords && !ctx->smallUnavailable) {
         // row ids first, rows from the next 256-byte boundary
         constexpr size_t outOffset = (SMALL_WORDS * sizeof(uint32_t) + 255) / 256 * 256;
         if (!ctx->smallHost) {
             void* host = nullptr;
             void* device = nullptr;
-            if (hipHostMalloc(&host, outOffset + SMALL_WORDS * rowBytes, hipHostMallocMapped) == hipSuccess &&
+            if (hipHostMalloc(&host, outOffset + smallWords * rowBytes, hipHostMallocMapped) == hipSuccess &&
                 hipHostGetDevicePointer(&device, host, 0) == hipSuccess) {
                 ctx->smallHost = host;
                 ctx->smallDevice = device;

@@ -302,6 +302,25 @@ def test_arbitrary_prefix_codes_through_the_c_abi(native):
     assert longest >= 15
 
 
+@pytest.mark.parametrize('dim,bits,count', [(4096, 8, 120), (9000, 8, 40), (20000, 4, 30), (60000, 8, 10), (100000, 2, 6)])
+def test_very_wide_rows(native, tmp_path, dim, bits, count):
+    # the reference reads any dimension; here a row's bitstream has to fit into LDS (~140 KB). Wide
+    # rows take more lanes per word (up to one word per wavefront), rows longer than 65535 bits a
+    # 32-bit segment index, and the index-building pass fewer words per wavefront
+    from memb_amd import synthetic
+    path = str(tmp_path / 'wide.bin')
+    words = synthetic.build_file(path, count, dim, 'trained', bits, seed=dim)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    info = reader.info()
+    assert info['lanes_per_word'] * info['segment_symbols'] >= dim
+    batch = sorted(words)[::-1] + ['not there'] + sorted(words)[:3]
+    assert bits_equal(reader.batch_embedding(batch), checker.batch_embedding(batch))
+    assert bits_equal(reader[batch[0]], checker.word_embedding(batch[0]))
+    many = (batch * (600 // len(batch) + 1))[:600]   # past the small-batch path: centroid indices over PCIe
+    assert bits_equal(reader.batch_embedding(many), checker.batch_embedding(many))
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

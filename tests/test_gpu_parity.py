@@ -321,6 +321,40 @@ def test_very_wide_rows(native, tmp_path, dim, bits, count):
     assert bits_equal(reader.batch_embedding(many), checker.batch_embedding(many))
 
 
+def test_degenerate_models(native, tmp_path):
+    # one-symbol codes (every stream is empty), two-symbol codes, a single word, heavy tails,
+    # constant / subnormal / near-overflow uniform rows, special values in full storage, odd words
+    rng = np.random.default_rng(0)
+    words = ['w%04d' % i for i in range(300)]
+    special = rng.standard_normal((300, 40)).astype(np.float32)
+    special[0, 0], special[1, 1], special[2, 2], special[3, 3] = np.inf, -np.inf, np.nan, -0.0
+    cases = []
+    for bits in (1, 4, 8):
+        cases += [
+            ('trained', bits, words, np.full((300, 40), 0.25, dtype=np.float32)),
+            ('trained', bits, words, rng.choice(np.array([-1.0, 2.0], dtype=np.float32), size=(300, 40))),
+            ('trained', bits, words[:1], rng.standard_normal((1, 40)).astype(np.float32)),
+            ('trained', bits, words, rng.standard_t(1.5, size=(300, 64)).astype(np.float32)),
+        ]
+    cases += [
+        ('uniform', 8, words, np.full((300, 40), 3.0, dtype=np.float32)),
+        ('uniform', 8, words, (rng.standard_normal((300, 40)) * 1e-40).astype(np.float32)),
+        ('uniform', 8, words, (rng.standard_normal((300, 40)) * 1e37).astype(np.float32)),
+        ('full', 8, words, special),
+        ('trained', 4, ['\u00e9t\u00e9', '\u65e5\u672c', 'a b', '', '\U0001F600', 'z' * 300], rng.standard_normal((6, 8)).astype(np.float32)),
+    ]
+    for index, (storage, bits, names, vectors) in enumerate(cases):
+        path = str(tmp_path / 'degenerate_{}.bin'.format(index))
+        builder = native.Builder(vectors.shape[1], storage, bits)
+        builder.add_words(names, vectors)
+        builder.save(path)
+        reader, checker = native.Reader(path), oracle.OracleReader(path)
+        batch = list(names) + ['nope', '\u00e9', '\u65e5']
+        assert nan_aware_equal(reader.batch_embedding(batch), checker.batch_embedding(batch)), (index, storage, bits)
+        long_batch = (batch * (700 // len(batch) + 1))[:700]
+        assert nan_aware_equal(reader.batch_embedding(long_batch), checker.batch_embedding(long_batch)), (index, storage, bits)
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

@@ -95,3 +95,42 @@ def test_pure_c_client(native, tmp_path):
         '9 2.25 2.25 -1.5 -1.5 9',
     ], run.stdout
     assert lines[4] == 'error: ld must be at least col_off + dim'
+
+
+def test_malformed_trained_descriptions_are_refused_before_any_device_work(native):
+    # inconsistent decoder descriptions must come back as MEMB_HIP_ERR_INVALID with a message, on any
+    # machine (the checks run before a device is opened); none may crash or hang
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+
+    class Desc(ctypes.Structure):
+        _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64),
+                    ('packed_values', ctypes.c_void_p), ('packed_values_bytes', ctypes.c_uint64),
+                    ('value_offsets', ctypes.c_void_p),
+                    ('keys', ctypes.c_void_p), ('n_keys', ctypes.c_uint32),
+                    ('size_offsets', ctypes.c_void_p), ('n_size_offsets', ctypes.c_uint32),
+                    ('centroids', ctypes.c_void_p), ('n_centroids', ctypes.c_uint32),
+                    ('max_direct_bits', ctypes.c_uint32)]
+
+    def create(keys, size_offsets, n_centroids=255, offsets=(0,), dim=4):
+        keys = np.array(keys, dtype=np.uint8)
+        size_offsets = np.array(size_offsets, dtype=np.uint32)
+        centroids = np.zeros(255, dtype=np.float32)
+        offsets = np.array(offsets, dtype=np.uint32)
+        packed = np.zeros(4, dtype=np.uint8)
+        desc = Desc(dim, len(offsets), packed.ctypes.data, len(packed), offsets.ctypes.data, keys.ctypes.data, len(keys),
+                    size_offsets.ctypes.data, len(size_offsets), centroids.ctypes.data, n_centroids, 0)
+        context = ctypes.c_void_p()
+        code = library.memb_hip_ctx_create_trained(ctypes.byref(context), 0, ctypes.byref(desc))
+        if code == 0:
+            library.memb_hip_ctx_destroy(context)
+        return code, library.memb_hip_last_error().decode()
+
+    INVALID = 1
+    assert create([1, 2, 3], [0, 3]) == (INVALID, 'Huffman code does not fit its table')            # three 1-bit codes
+    assert create([1, 2, 3], [0, 2, 1, 3])[0] == INVALID                                            # counts go down
+    assert create(list(range(18)), list(range(18)) + [18])[0] == INVALID                            # a 17-bit code
+    assert create([1, 200], [0, 2], n_centroids=10) == (INVALID, 'Huffman symbol without a centroid')
+    assert create([1, 2], [0, 2], offsets=(100,)) == (INVALID, 'value offset beyond packed values')
+    assert create([1, 2], [])[0] == INVALID
+    assert create([1, 2], [0, 2], dim=0)[0] == INVALID

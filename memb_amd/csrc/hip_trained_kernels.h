@@ -17,6 +17,8 @@ struct TrainedParams {
     const uint4* streams;           // re-packed bitstreams: big-endian dwords, one 16-byte aligned run per row
     const uint32_t* streamStarts;   // [nRows + 1] first 16-byte piece of each row's run
     const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
+    const uint32_t* rowMeta;        // or null: one 16-byte record per row, {start, offsets of segments 1..7 in 13 bits
+                                    // each}: what streamStarts and segmentIndex hold, fetched by ONE load per lane
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
                                     // (both hold 32-bit entries when indexWide: rows longer than 65535 bits)
     const uint32_t* table;          // 8-byte entries, see TableEntry
@@ -88,19 +90,33 @@ __device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned
     return p.rows ? p.rows[index] : static_cast<uint32_t>(index);
 }
 
+constexpr uint32_t ROW_META_BITS = 13;        // a segment offset inside a rowMeta record: streams below 1 KiB
+constexpr uint32_t ROW_META_MAX_LANES = 8;    // 32 + 7 * 13 bits = 123 of 128
+
 struct WordMeta {
     uint32_t row;
     uint32_t start;         // first 16-byte piece of the word's bitstream
-    uint32_t segmentBits;   // bit offset of the lane's segment inside that stream
+    uint32_t segmentBits;   // bit offset of the lane's segment inside that stream; with rowMeta: dword 1 of the record
+    uint32_t packed2;       // with rowMeta: dwords 2 and 3 of the record, until unpackMeta has run
+    uint32_t packed3;
 };
 
+// Issues the loads only; the values may be used after unpackMeta.
 __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_t row, const LaneRole& role)
 {
     WordMeta meta;
     meta.row = row;
     meta.start = 0;
     meta.segmentBits = 0;
-    if (row < p.nRows) {
+    meta.packed2 = 0;
+    meta.packed3 = 0;
+    if (row < p.nRows && p.rowMeta) {
+        const uint4 record = reinterpret_cast<const uint4*>(p.rowMeta)[row];
+        meta.start = record.x;
+        meta.segmentBits = record.y;
+        meta.packed2 = record.z;
+        meta.packed3 = record.w;
+    } else if (row < p.nRows) {
         meta.start = p.streamStarts[row];
         if (role.segment > 0) {
             const unsigned long long at = static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1;
@@ -108,6 +124,26 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
         }
     }
     return meta;
+}
+
+// rowMeta: picks the lane's 13-bit field out of the record's 96 offset bits (field s - 1 of
+// segment s at bit 13 (s - 1)); no-op for the two-array layout.
+__device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRole& role, WordMeta& meta)
+{
+    if (!p.rowMeta) {
+        return;
+    }
+    // (two conditional moves per step, spelled out: a three-way select by index is turned into
+    // a table in scratch memory)
+    const uint32_t bit = role.segment ? ROW_META_BITS * (role.segment - 1) : 0u;
+    const bool second = bit >= 32;
+    const bool third = bit >= 64;
+    uint32_t low = second ? meta.packed2 : meta.segmentBits;
+    uint32_t high = second ? meta.packed3 : meta.packed2;
+    low = third ? meta.packed3 : low;
+    high = third ? 0u : high;
+    const uint32_t field = __builtin_amdgcn_alignbit(high, low, bit & 31) & ((1u << ROW_META_BITS) - 1);
+    meta.segmentBits = role.segment ? field : 0u;
 }
 
 constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
@@ -437,7 +473,8 @@ __global__ void decode_trained(TrainedParams p)
         static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
 
     const LaneRole role = laneRole(p, lane);
-    const WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
+    WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
+    unpackMeta(p, role, meta);
 
     const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
     for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
@@ -482,6 +519,8 @@ __global__ void decode_trained_persistent(TrainedParams p)
     WordMeta meta0 = loadWordMeta(p, loadTileRow(p, tile, role), role);
     WordMeta meta1 = loadWordMeta(p, loadTileRow(p, tile + stride, role), role);
     WordMeta metaLoading = loadWordMeta(p, loadTileRow(p, tile + 2 * stride, role), role);
+    unpackMeta(p, role, meta0);
+    unpackMeta(p, role, meta1);
     StreamRegisters streams;
     issueStreamLoads(p, meta0, lane, 0, streams);
     writeStreams(p, mem.slots, lane, 0, streams);
@@ -515,7 +554,10 @@ __global__ void decode_trained_persistent(TrainedParams p)
         asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
         asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
         asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed2) : "v"(metaLoading.packed2));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed3) : "v"(metaLoading.packed3));
         asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
+        unpackMeta(p, role, meta2);
         __builtin_amdgcn_sched_barrier(0);
 
         if (!(p.debugFlags & 2)) {
@@ -531,6 +573,28 @@ __global__ void decode_trained_persistent(TrainedParams p)
         meta1 = meta2;
         waveLdsFence();
     }
+}
+
+// Staging: streamStarts + segmentIndex -> rowMeta records (see TrainedParams::rowMeta). One thread per row.
+__global__ void pack_row_meta(
+    const uint32_t* streamStarts, const uint16_t* segmentIndex, uint32_t lanesPerWord, unsigned long long nRows,
+    uint32_t* rowMeta)
+{
+    const unsigned long long row = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= nRows) {
+        return;
+    }
+    uint32_t offsets[3] = {0, 0, 0};
+    for (uint32_t segment = 1; segment < lanesPerWord; ++segment) {
+        const unsigned long long value = segmentIndex[row * (lanesPerWord - 1) + segment - 1];
+        const uint32_t bit = ROW_META_BITS * (segment - 1);
+        const unsigned long long shifted = value << (bit & 31);
+        offsets[bit >> 5] |= static_cast<uint32_t>(shifted);
+        if ((bit >> 5) + 1 < 3) {
+            offsets[(bit >> 5) + 1] |= static_cast<uint32_t>(shifted >> 32);
+        }
+    }
+    reinterpret_cast<uint4*>(rowMeta)[row] = make_uint4(streamStarts[row], offsets[0], offsets[1], offsets[2]);
 }
 
 // Staging-time re-pack of the file's bitstreams (byte aligned, insertion order,

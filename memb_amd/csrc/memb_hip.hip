@@ -126,6 +126,7 @@ struct memb_hip_ctx {
     uint32_t slotDwords = 0;
     uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
     bool indexWide = false;              // some row is longer than 65535 bits
+    uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
@@ -315,6 +316,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.streamStarts = ctx->streamStarts;
     params.segmentIndex = ctx->segmentIndex;
     params.indexWide = ctx->indexWide ? 1u : 0u;
+    params.rowMeta = ctx->rowMeta;
     params.table = ctx->table;
     params.codebook = ctx->codebook;
     params.nRows = ctx->nRows;
@@ -948,6 +950,26 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     }
     if (code == MEMB_HIP_OK) {
         code = buildSegmentIndex(ctx);
+    }
+    // Lookups read a row's stream start and segment offsets as one 16-byte record with one load
+    // per lane: one request per word of a random batch (the two arrays cost two or three), one
+    // per tile of a key-order dump.
+    if (code == MEMB_HIP_OK && desc->n_rows && ctx->lanesPerWord > 1 && ctx->lanesPerWord <= ROW_META_MAX_LANES &&
+        uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && envUint("MEMB_HIP_ROW_META", 1)) {
+        code = deviceAlloc(ctx, &ctx->rowMeta, size_t(desc->n_rows) * 16 + 16);
+        if (code == MEMB_HIP_OK) {
+            const uint32_t threads = 256;
+            hipLaunchKernelGGL(
+                pack_row_meta, dim3(static_cast<uint32_t>((desc->n_rows + threads - 1) / threads)), dim3(threads), 0,
+                ctx->stream, ctx->streamStarts, ctx->segmentIndex, ctx->lanesPerWord, desc->n_rows, ctx->rowMeta);
+            hipError_t status = hipGetLastError();
+            if (status == hipSuccess) {
+                status = hipStreamSynchronize(ctx->stream);
+            }
+            if (status != hipSuccess) {
+                code = fail(MEMB_HIP_ERR_DEVICE, std::string("pack_row_meta: ") + hipGetErrorString(status));
+            }
+        }
     }
     if (verbose) {
         std::fprintf(stderr, "memb_hip: stage trained rows=%llu: host lengths %.3fs, device open + copy + repack %.3fs, tables + index %.3fs\n",

@@ -9,6 +9,7 @@ path,_=synthetic.cached_model(n,300,'trained',bits)
 out=torch.empty((n,300),dtype=torch.float32,device='cuda')
 rows=torch.arange(n,dtype=torch.int32,device='cuda')
 perm=torch.randperm(n,device='cuda').to(torch.int32)
+small=perm[:100000].contiguous(); small_out=torch.empty((100000,300),dtype=torch.float32,device='cuda')
 def timeit(f, reps=20):
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -28,5 +29,5 @@ for rnd in range(3):
     for name,flags in variants:
         os.environ['MEMB_HIP_DEBUG']=flags
         r=readers[name]
-        a=timeit(lambda: r.rows_embedding_device(rows,out=out)); b=timeit(lambda: r.rows_embedding_device(perm,out=out))
-        print('round %d %-8s sorted min %.3f med %.3f | random min %.3f med %.3f ms' % ((rnd,name)+a+b), flush=True)
+        a=timeit(lambda: r.rows_embedding_device(rows,out=out)); b=timeit(lambda: r.rows_embedding_device(perm,out=out)); c=timeit(lambda: r.rows_embedding_device(small,out=small_out))
+        print('round %d %-8s sorted min %.3f med %.3f | random min %.3f med %.3f | 100k random min %.4f med %.4f ms' % ((rnd,name)+a+b+c), flush=True)

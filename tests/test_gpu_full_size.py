@@ -85,3 +85,35 @@ def test_full_vocabulary_through_the_word_api(native, full_model):
     expected[::100] = 0
     assert bits_equal(wide[:, 10:], expected)
     assert (wide[:, :10] == 3.0).all()
+
+
+def test_large_batches_from_several_threads(native, full_model):
+    # batches above the search/decode overlap threshold from concurrent threads on one Reader: the
+    # word-search pool is taken by one caller (the others search on threads of their own), the
+    # context serialises the decodes; every caller must get its own rows
+    import threading
+    import torch
+    path, count = full_model
+    reader = native.Reader(path)
+    keys = reader.keys()
+    expected = reader.rows_embedding_device(torch.arange(count, dtype=torch.int32, device='cuda')).cpu().numpy()
+    spans = [(0, 300000), (500000, 830000), (count - 280000, count), (1000000, 1001500)]
+    results = [None] * len(spans)
+    errors = []
+
+    def work(index):
+        first, last = spans[index]
+        try:
+            for _ in range(2):
+                results[index] = reader.batch_embedding(keys[first:last])
+        except Exception as error:   # pragma: no cover
+            errors.append(error)
+
+    threads = [threading.Thread(target=work, args=(index,)) for index in range(len(spans))]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    assert not errors, errors
+    for (first, last), rows in zip(spans, results):
+        assert bits_equal(rows, expected[first:last]), (first, last)

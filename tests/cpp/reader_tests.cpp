@@ -5,9 +5,11 @@
 // counts failures, main() returns how many.
 //
 //   reader_tests            everything (the lookups need a HIP device)
-//   reader_tests --host     only the cases that never touch the device
+//   reader_tests --host     only the cases that never touch the device (refusals, and the two known answers
+//                           of the writer side: src/bit_stream_tests.cpp, src/kmeans_tests.cpp)
 #include "../../memb_amd/csrc/builder.h"
 #include "../../memb_amd/csrc/reader.h"
+#include "../../memb_amd/csrc/codec.h"
 
 #include <algorithm>
 #include <cmath>
@@ -145,6 +147,50 @@ void refusals()
     CHECK(memb::createCompressionStrategy("trained")->storageType() == memb::wire::Storage_Trained);
 }
 
+// reference src/bit_stream_tests.cpp:29-58 and src/kmeans_tests.cpp:9-37: the writer's two known answers
+void codecKnownAnswers()
+{
+    std::printf("bit packer and k-means known answers\n");
+    const std::vector<std::pair<uint32_t, uint32_t>> codes = {{1023, 14}, {33, 6}, {0, 4}, {1234, 11}, {7, 2}};
+    memb::BitWriter writer;
+    std::string expected;
+    for (const auto& code : codes) {
+        writer.push(code.first, code.second);
+        for (uint32_t bit = code.second; bit-- > 0;) {
+            expected.push_back(((code.first >> bit) & 1) ? '1' : '0');
+        }
+    }
+    writer.flushToByte();
+    expected.append((8 - expected.size() % 8) % 8, '0');   // 37 bits: three bits of padding
+    std::string packed;
+    for (uint8_t byte : writer.bytes()) {
+        for (int bit = 7; bit >= 0; --bit) {
+            packed.push_back(((byte >> bit) & 1) ? '1' : '0');
+        }
+    }
+    CHECK(packed == expected);
+
+    std::vector<float> data;
+    std::vector<uint8_t> expectedClusters;
+    for (int i = 0; i < 8; ++i) {
+        data.push_back(-0.5f + i * 0.125f);
+        expectedClusters.push_back(1);
+    }
+    for (int i = 0; i < 16; ++i) {
+        data.push_back(-9.f + i * 0.125f);
+        expectedClusters.push_back(0);
+    }
+    for (int i = 0; i < 4; ++i) {
+        data.push_back(11.75f + i * 0.125f);
+        expectedClusters.push_back(2);
+    }
+    memb::KMeansClusterizer clusterizer(3);
+    clusterizer.fit(data);
+    std::vector<uint8_t> clusters;
+    clusterizer.predict(data.data(), data.size(), &clusters);
+    CHECK(clusters == expectedClusters);
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -152,6 +198,7 @@ int main(int argc, char** argv)
     const bool hostOnly = argc > 1 && std::strcmp(argv[1], "--host") == 0;
     try {
         refusals();
+        codecKnownAnswers();
         if (!hostOnly) {
             roundTrip("full storage round trip", memb::wire::Storage_Full,
                       memb::createCompressionStrategy(memb::wire::Storage_Full));

@@ -325,6 +325,9 @@ PYBIND11_MODULE(_memb, m) {
         return py::make_tuple(table.rootBits, table.maxCodeBits, table.hasSubTables, table.entries);
     });
 
+    m.def("_writer_omits_default_scalars", [](bool enabled) {
+        memb::wire::BufferBuilder::omitDefaults() = enabled;
+    });
     m.def("hip_device_count", []() {
         int count = 0;
         memb_hip_device_count(&count);

@@ -271,9 +271,21 @@ public:
         tableStart_ = used_;
     }
 
+    // The official FlatBuffers writers leave out a scalar field whose value equals the schema
+    // default (all defaults are zero in memb's schemas) and readers supply the default. This
+    // writer stores every field unless told to mimic that (used by tests of the three parsers).
+    static bool& omitDefaults()
+    {
+        static bool enabled = false;
+        return enabled;
+    }
+
     template <typename T>
     void addScalar(size_t id, T value)
     {
+        if (omitDefaults() && value == T()) {
+            return;
+        }
         align(sizeof(T));
         pushScalar<T>(value);
         fields_.push_back({id, used_});

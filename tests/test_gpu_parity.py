@@ -355,6 +355,29 @@ def test_degenerate_models(native, tmp_path):
         assert nan_aware_equal(reader.batch_embedding(long_batch), checker.batch_embedding(long_batch)), (index, storage, bits)
 
 
+def test_omitted_default_scalars_on_device(native, tmp_path):
+    # see tests/test_host_logic.py::test_files_with_omitted_default_scalars
+    from memb_amd import _memb
+    rng = np.random.default_rng(6)
+    words = ['w%03d' % i for i in range(200)]
+    vectors = rng.standard_normal((200, 24)).astype(np.float32)
+    vectors[::3] = np.abs(vectors[::3])
+    vectors[::3, 0] = 0.0            # min exactly 0.0
+    vectors[1::3] = -np.abs(vectors[1::3])
+    vectors[1::3, 5] = 0.0           # max exactly 0.0
+    vectors[10] = 0.0
+    _memb._writer_omits_default_scalars(True)
+    try:
+        builder = native.Builder(24, 'uniform', 8)
+        builder.add_words(words, vectors)
+        path = str(tmp_path / 'omitted.bin')
+        builder.save(path)
+    finally:
+        _memb._writer_omits_default_scalars(False)
+    batch = words[::-1] + ['nope']
+    assert bits_equal(native.Reader(path).batch_embedding(batch), oracle.OracleReader(path).batch_embedding(batch))
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

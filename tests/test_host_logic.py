@@ -284,3 +284,34 @@ def test_product_never_touches_the_checker():
         entry = handle.read()
     build_body = entry[entry.index('def build('):entry.index('def smoke(')]
     assert not re.search(r'^\s*(import|from)\s+oracle\b', build_body, re.M)   # building the checker is not using it
+
+
+def test_files_with_omitted_default_scalars(native, tmp_path):
+    # The official FlatBuffers writers omit scalar fields that equal their default (here: a uniform
+    # row whose min or max is exactly 0.0) and readers supply it. Write such a file and read it with
+    # the C parser of the checker and the C++ reader of the package (the GPU half is in
+    # tests/test_gpu_parity.py::test_omitted_default_scalars_on_device).
+    from memb_amd import _memb
+    vectors = {
+        'low_zero': [0.0, 1.0, 2.0], 'high_zero': [-2.0, -1.0, 0.0], 'all_zero': [0.0, 0.0, 0.0], 'plain': [-1.0, 0.5, 3.0],
+    }
+    paths = {}
+    for omit in (False, True):
+        _memb._writer_omits_default_scalars(omit)
+        try:
+            builder = native.Builder(3, 'uniform', 8)
+            for word, vector in vectors.items():
+                builder.add_word(word, np.array(vector, dtype=np.float32))
+            paths[omit] = str(tmp_path / 'uniform_omit_{}.bin'.format(int(omit)))
+            builder.save(paths[omit])
+        finally:
+            _memb._writer_omits_default_scalars(False)
+    plain, omitted = (open(paths[flag], 'rb').read() for flag in (False, True))
+    assert len(omitted) < len(plain)   # the zero scalars really are gone
+    words = sorted(vectors) + ['missing']
+    reference_rows = oracle.OracleReader(paths[False]).batch_embedding(words)
+    assert np.array_equal(oracle.OracleReader(paths[True]).batch_embedding(words).view(np.uint32), reference_rows.view(np.uint32))
+    assert np.allclose(reference_rows[:4], [vectors[w] for w in sorted(vectors)], atol=0.02)
+    reader = native.Reader(paths[True])
+    assert reader.keys() == sorted(vectors) and reader.dim == 3
+    assert reader.resolve_rows(words).tolist() == [0, 1, 2, 3, 0xFFFFFFFF]

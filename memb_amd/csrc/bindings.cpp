@@ -325,7 +325,7 @@ PYBIND11_MODULE(_memb, m) {
         return py::make_tuple(table.rootBits, table.maxCodeBits, table.hasSubTables, table.entries);
     });
 
-    m.def("_writer_omits_default_scalars", [](bool enabled) {
+    m.def("_writer_mimics_official_layout", [](bool enabled) {
         memb::wire::BufferBuilder::omitDefaults() = enabled;
     });
     m.def("hip_device_count", []() {

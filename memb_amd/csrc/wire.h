@@ -271,9 +271,11 @@ public:
         tableStart_ = used_;
     }
 
-    // The official FlatBuffers writers leave out a scalar field whose value equals the schema
-    // default (all defaults are zero in memb's schemas) and readers supply the default. This
-    // writer stores every field unless told to mimic that (used by tests of the three parsers).
+    // The official FlatBuffers writers (a) leave out a scalar field whose value equals the schema
+    // default (all defaults are zero in memb's schemas; readers supply the default) and (b) share
+    // one vtable between tables with identical layouts, so that the vtable of a table can lie at a
+    // higher address than the table (negative soffset). This writer does neither unless told to
+    // mimic them (used by tests of the three parsers).
     static bool& omitDefaults()
     {
         static bool enabled = false;
@@ -317,6 +319,18 @@ public:
         }
         pushBytes(vtable.data(), 2 * vtable.size());
         size_t vtableRef = used_;
+        if (omitDefaults()) {
+            for (const auto& earlier : sharedVtables_) {
+                if (earlier.first == vtable) {
+                    used_ -= 2 * vtable.size();   // drop the copy just written, point at the earlier one
+                    vtableRef = earlier.second;
+                    break;
+                }
+            }
+            if (vtableRef == used_) {
+                sharedVtables_.push_back({vtable, vtableRef});
+            }
+        }
 
         int32_t soffset = static_cast<int32_t>(vtableRef - tableRef);
         std::memcpy(at(tableRef), &soffset, 4);
@@ -336,6 +350,7 @@ private:
         size_t id;
         size_t ref;
     };
+    std::vector<std::pair<std::vector<uint16_t>, size_t>> sharedVtables_;
 
     uint8_t* at(size_t ref) { return storage_.data() + storage_.size() - ref; }
 

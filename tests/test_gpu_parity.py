@@ -366,14 +366,14 @@ def test_omitted_default_scalars_on_device(native, tmp_path):
     vectors[1::3] = -np.abs(vectors[1::3])
     vectors[1::3, 5] = 0.0           # max exactly 0.0
     vectors[10] = 0.0
-    _memb._writer_omits_default_scalars(True)
+    _memb._writer_mimics_official_layout(True)
     try:
         builder = native.Builder(24, 'uniform', 8)
         builder.add_words(words, vectors)
         path = str(tmp_path / 'omitted.bin')
         builder.save(path)
     finally:
-        _memb._writer_omits_default_scalars(False)
+        _memb._writer_mimics_official_layout(False)
     batch = words[::-1] + ['nope']
     assert bits_equal(native.Reader(path).batch_embedding(batch), oracle.OracleReader(path).batch_embedding(batch))
 

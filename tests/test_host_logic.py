@@ -288,16 +288,17 @@ def test_product_never_touches_the_checker():
 
 def test_files_with_omitted_default_scalars(native, tmp_path):
     # The official FlatBuffers writers omit scalar fields that equal their default (here: a uniform
-    # row whose min or max is exactly 0.0) and readers supply it. Write such a file and read it with
-    # the C parser of the checker and the C++ reader of the package (the GPU half is in
-    # tests/test_gpu_parity.py::test_omitted_default_scalars_on_device).
+    # row whose min or max is exactly 0.0; readers supply it) and share one vtable between tables of
+    # the same layout (so a vtable can sit behind its table: negative soffset). Write such files and
+    # read them with the C parser of the checker and the C++ reader of the package (the GPU half is
+    # in tests/test_gpu_parity.py::test_omitted_default_scalars_on_device).
     from memb_amd import _memb
     vectors = {
         'low_zero': [0.0, 1.0, 2.0], 'high_zero': [-2.0, -1.0, 0.0], 'all_zero': [0.0, 0.0, 0.0], 'plain': [-1.0, 0.5, 3.0],
     }
     paths = {}
     for omit in (False, True):
-        _memb._writer_omits_default_scalars(omit)
+        _memb._writer_mimics_official_layout(omit)
         try:
             builder = native.Builder(3, 'uniform', 8)
             for word, vector in vectors.items():
@@ -305,9 +306,9 @@ def test_files_with_omitted_default_scalars(native, tmp_path):
             paths[omit] = str(tmp_path / 'uniform_omit_{}.bin'.format(int(omit)))
             builder.save(paths[omit])
         finally:
-            _memb._writer_omits_default_scalars(False)
+            _memb._writer_mimics_official_layout(False)
     plain, omitted = (open(paths[flag], 'rb').read() for flag in (False, True))
-    assert len(omitted) < len(plain)   # the zero scalars really are gone
+    assert len(omitted) <= len(plain) - 40   # the zero scalars and the repeated vtables really are gone
     words = sorted(vectors) + ['missing']
     reference_rows = oracle.OracleReader(paths[False]).batch_embedding(words)
     assert np.array_equal(oracle.OracleReader(paths[True]).batch_embedding(words).view(np.uint32), reference_rows.view(np.uint32))
@@ -315,3 +316,22 @@ def test_files_with_omitted_default_scalars(native, tmp_path):
     reader = native.Reader(paths[True])
     assert reader.keys() == sorted(vectors) and reader.dim == 3
     assert reader.resolve_rows(words).tolist() == [0, 1, 2, 3, 0xFFFFFFFF]
+    # full and trained storages in the same layout: one vtable for all FullNode tables
+    for storage in ('full', 'trained'):
+        files = {}
+        for mimic in (False, True):
+            _memb._writer_mimics_official_layout(mimic)
+            try:
+                builder = native.Builder(3, storage, 8)
+                for word, vector in SIX_WORDS.items():
+                    builder.add_word(word, np.array(vector, dtype=np.float32))
+                files[mimic] = str(tmp_path / '{}_{}.bin'.format(storage, int(mimic)))
+                builder.save(files[mimic])
+            finally:
+                _memb._writer_mimics_official_layout(False)
+        batch = sorted(SIX_WORDS) + ['o']
+        want = oracle.OracleReader(files[False]).batch_embedding(batch)
+        assert np.array_equal(oracle.OracleReader(files[True]).batch_embedding(batch).view(np.uint32), want.view(np.uint32))
+        assert native.Reader(files[True]).keys() == sorted(SIX_WORDS)
+        if storage == 'full':
+            assert os.path.getsize(files[True]) < os.path.getsize(files[False])

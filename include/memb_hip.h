@@ -39,6 +39,7 @@ extern "C" {
 #define MEMB_HIP_OK 0
 #define MEMB_HIP_ERR_INVALID 1   /* bad argument or inconsistent storage description */
 #define MEMB_HIP_ERR_DEVICE 2    /* HIP runtime error (no device, out of memory, launch failure) */
+#define MEMB_HIP_UNSUPPORTED 3   /* not an error: this combination has no fused kernel, use the plain calls */
 
 typedef struct memb_hip_ctx memb_hip_ctx;
 
@@ -170,6 +171,20 @@ int memb_hip_decode_rows_device(
 int memb_hip_decode_rows_device_ex(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream,
     uint32_t flags, float divisor);
+
+/*
+ * ReadersUnion 'concatenate' (reference python/memb/readers_union.py:21-32) as ONE launch:
+ * row i of the result is [model 0's vector of rows[0][i] | model 1's vector of rows[1][i] | ...],
+ * model m's block starting at column col_offs[m]. Same result as one
+ * memb_hip_decode_rows_device call per model, but the merged rows are written whole
+ * instead of one column block per launch. Device pointers, enqueued on `stream`.
+ * Returns MEMB_HIP_UNSUPPORTED (and does nothing) when the models cannot share a
+ * kernel: other than `count` = 2 trained storages of equal dim, lane geometry and key
+ * format on one device, or an output that is not 16-byte aligned in every block.
+ */
+int memb_hip_decode_rows_union_device(
+    memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n,
+    float* out, size_t ld, void* stream);
 
 /* Wait for the context's own stream (used by memb_hip_decode_rows). */
 int memb_hip_sync(memb_hip_ctx* ctx);

@@ -325,6 +325,45 @@ PYBIND11_MODULE(_memb, m) {
         return py::make_tuple(table.rootBits, table.maxCodeBits, table.hasSubTables, table.entries);
     });
 
+    // ReadersUnion 'concatenate' as one launch; false when the readers cannot share a kernel
+    // (the caller then decodes them one by one). Pointers are device pointers.
+    m.def(
+        "union_rows_to_device",
+        [](const std::vector<std::shared_ptr<memb::Reader>>& readers,
+           const std::vector<uintptr_t>& rows,
+           const std::vector<size_t>& colOffs,
+           size_t n,
+           uintptr_t out,
+           size_t ld,
+           uintptr_t stream)
+        {
+            if (readers.size() != rows.size() || readers.size() != colOffs.size() || readers.empty()) {
+                throw std::runtime_error("One row-id array and one column offset per reader are needed");
+            }
+            std::vector<memb_hip_ctx*> contexts;
+            std::vector<const uint32_t*> rowPointers;
+            for (size_t i = 0; i < readers.size(); ++i) {
+                contexts.push_back(readers[i]->deviceContext());
+                rowPointers.push_back(reinterpret_cast<const uint32_t*>(rows[i]));
+            }
+            int code = memb_hip_decode_rows_union_device(
+                contexts.data(), rowPointers.data(), colOffs.data(), readers.size(), n, reinterpret_cast<float*>(out), ld,
+                reinterpret_cast<void*>(stream));
+            if (code == MEMB_HIP_UNSUPPORTED) {
+                return false;
+            }
+            if (code != MEMB_HIP_OK) {
+                throw std::runtime_error(memb_hip_last_error());
+            }
+            return true;
+        },
+        py::arg("readers"),
+        py::arg("rows_ptrs"),
+        py::arg("col_offs"),
+        py::arg("n"),
+        py::arg("out_ptr"),
+        py::arg("ld"),
+        py::arg("stream") = 0);
     m.def("_writer_mimics_official_layout", [](bool enabled) {
         memb::wire::BufferBuilder::omitDefaults() = enabled;
     });

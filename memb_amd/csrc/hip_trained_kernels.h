@@ -575,6 +575,160 @@ __global__ void decode_trained_persistent(TrainedParams p)
     }
 }
 
+// ---------------------------------------------------------------------------
+// decode_trained_union: ReadersUnion 'concatenate' in one launch
+// ---------------------------------------------------------------------------
+// The reference concatenates the readers' results on the host (python/memb/readers_union.py:32).
+// Decoding every reader into its column block with a launch of its own makes each launch write
+// every other `dim` floats of the merged rows -- half lines, twice, far apart in time (2.7 TB/s
+// against 4.4 TB/s for dense rows). Here one wavefront decodes its tile of the batch for ALL
+// models (each into a symbol tile of its own) and then writes the merged rows whole.
+// One tile per wavefront (union batches are random lookups; the persistent pipeline buys
+// nothing there), COUNT models of the same geometry (dim, lanes per word) and key format.
+constexpr int UNION_MAX_MODELS = 2;
+
+struct UnionParams {
+    TrainedParams model[UNION_MAX_MODELS];   // out / ld shared, colOff per model; n, wordsPerWave etc. equal
+    uint32_t tableOffsetDwords[UNION_MAX_MODELS];
+    uint32_t keyTileOffsetDwords[UNION_MAX_MODELS];   // symbol tile inside a model's per-wave area (after its slots)
+    uint32_t codebookOffsetDwords;   // model m's codebook at this + m * 512 dwords
+    uint32_t sharedDwords;           // tables + codebooks
+    uint32_t perModelDwords;         // one model's slots + symbol tile of one wave
+    uint32_t rowPieces;              // COUNT * dim / 4: 16-byte pieces of a merged row
+    uint32_t rowMagic;               // fastDivide magic for rowPieces
+};
+
+template <bool HAS_SUB, bool FAST, int COUNT>
+__global__ void decode_trained_union(UnionParams u)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const TrainedParams& first = u.model[0];
+
+    // tables and codebooks of all models
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        const TrainedParams& p = u.model[m];
+        uint32_t* tableLds = lds + u.tableOffsetDwords[m];
+        for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
+            reinterpret_cast<uint4*>(tableLds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
+        }
+        uint32_t* codebookLds = lds + u.codebookOffsetDwords + m * 512;
+        for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
+            codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    const unsigned long long tileBase = tile * first.wordsPerWave;
+    if (tileBase >= first.n) {
+        return;
+    }
+    const uint32_t tileWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
+    const LaneRole role = laneRole(first, lane);
+    uint32_t* waveLds = lds + u.sharedDwords + wave * (COUNT * u.perModelDwords);
+
+    // the dependent hops of all models side by side: row ids, then offsets, then bitstreams
+    uint32_t rows[COUNT];
+    WordMeta meta[COUNT];
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        rows[m] = loadTileRow(u.model[m], tile, role);
+    }
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        meta[m] = loadWordMeta(u.model[m], rows[m], role);
+    }
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        const TrainedParams& p = u.model[m];
+        unpackMeta(p, role, meta[m]);
+        uint32_t* slots = waveLds + m * u.perModelDwords;
+        const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
+        for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
+            StreamRegisters v;
+            issueStreamLoads(p, meta[m], lane, round, v);
+            writeStreams(p, slots, lane, round, v);
+        }
+    }
+    waveLdsFence();
+
+    unsigned long long absent[COUNT];
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        const TrainedParams& p = u.model[m];
+        uint32_t* slots = waveLds + m * u.perModelDwords;
+        uint32_t* keyTile = slots + u.keyTileOffsetDwords[m];
+        decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+            p, reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots, keyTile, role, meta[m]);
+        // nibble keys have no code for "absent": remember which words of the tile are
+        absent[m] = __ballot(!(meta[m].row < p.nRows) && !role.spare && role.segment == 0 && role.word < tileWords);
+    }
+    waveLdsFence();
+
+    // merged rows, 16 bytes per lane, row contiguous when the column blocks are adjacent
+    const uint32_t piecesPerWord = first.dim / 4;
+    const uint32_t pieces = tileWords * u.rowPieces;
+    constexpr int BURST = 4;
+    for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+        uint32_t k[BURST];
+        uint32_t w[BURST];
+        uint32_t m[BURST];
+        uint32_t c[BURST];
+#pragma unroll
+        for (int b = 0; b < BURST; ++b) {
+            const uint32_t q = min(q0 + WAVE * b, pieces - 1);
+            w[b] = fastDivide(q, u.rowMagic, u.rowPieces);
+            const uint32_t inRow = q - w[b] * u.rowPieces;
+            m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
+            c[b] = inRow - m[b] * piecesPerWord;
+            uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
+#pragma unroll
+            for (int i = 1; i < COUNT; ++i) {
+                keyTileOffset = m[b] == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
+            }
+            const uint32_t* keyTile = waveLds + m[b] * u.perModelDwords + keyTileOffset;
+            const uint32_t at = w[b] * (first.keyRowBytes / (FAST ? 2 : 4)) + c[b];
+            k[b] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
+        }
+#pragma unroll
+        for (int b = 0; b < BURST; ++b) {
+            const uint32_t* codebook = lds + u.codebookOffsetDwords + m[b] * 512;
+            float4 f;
+            if (FAST) {
+                const float2 lo = reinterpret_cast<const float2*>(codebook)[k[b] & 0xff];
+                const float2 hi = reinterpret_cast<const float2*>(codebook)[k[b] >> 8];
+                f = make_float4(lo.x, lo.y, hi.x, hi.y);
+                unsigned long long mask = absent[0];
+#pragma unroll
+                for (int i = 1; i < COUNT; ++i) {
+                    mask = m[b] == static_cast<uint32_t>(i) ? absent[i] : mask;
+                }
+                if ((mask >> (w[b] * first.lanesPerWord)) & 1) {
+                    f = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                const float* centroids = reinterpret_cast<const float*>(codebook);
+                f.x = centroids[k[b] & 0xff];
+                f.y = centroids[(k[b] >> 8) & 0xff];
+                f.z = centroids[(k[b] >> 16) & 0xff];
+                f.w = centroids[k[b] >> 24];
+            }
+            if (q0 + WAVE * b < pieces) {
+                unsigned long long colOff = u.model[0].colOff;
+#pragma unroll
+                for (int i = 1; i < COUNT; ++i) {
+                    colOff = m[b] == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
+                }
+                *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + colOff + 4 * c[b]) = f;
+            }
+        }
+    }
+}
+
 // Staging: streamStarts + segmentIndex -> rowMeta records (see TrainedParams::rowMeta). One thread per row.
 __global__ void pack_row_meta(
     const uint32_t* streamStarts, const uint16_t* segmentIndex, uint32_t lanesPerWord, unsigned long long nRows,

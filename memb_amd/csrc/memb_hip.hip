@@ -412,6 +412,117 @@ int launchTrained(
     return MEMB_HIP_OK;
 }
 
+template <bool HAS_SUB, bool FAST>
+hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    static thread_local int configuredDevice = -1;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (configuredDevice != device) {
+        hipError_t status = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (status != hipSuccess) {
+            return status;
+        }
+        configuredDevice = device;
+    }
+    hipLaunchKernelGGL(
+        (decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+    return hipGetLastError();
+}
+
+// See memb_hip_decode_rows_union_device. MEMB_HIP_UNSUPPORTED when the models cannot share the kernel.
+int launchTrainedUnion(
+    memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* colOffs, size_t count, size_t n, float* out,
+    size_t ld, hipStream_t stream)
+{
+    if (count != UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
+        return MEMB_HIP_UNSUPPORTED;
+    }
+    const memb_hip_ctx* first = ctxs[0];
+    bool hasSub = false;
+    for (size_t m = 0; m < count; ++m) {
+        const memb_hip_ctx* ctx = ctxs[m];
+        if (ctx->storage != memb::wire::Storage_Trained || ctx->device != first->device || ctx->dim != first->dim ||
+            ctx->fast != first->fast || ctx->lanesPerWord != first->lanesPerWord ||
+            ctx->segmentSymbols != first->segmentSymbols || ctx->dim % 4 != 0 || colOffs[m] % 4 != 0 ||
+            ld < colOffs[m] + ctx->dim) {
+            return MEMB_HIP_UNSUPPORTED;
+        }
+        hasSub = hasSub || ctx->hostTable.hasSubTables;
+    }
+    if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 || n > (size_t(1) << 37)) {
+        return MEMB_HIP_UNSUPPORTED;
+    }
+    const uint32_t wordsPerWave = WAVE / first->lanesPerWord;
+    UnionParams params{};
+    uint32_t sharedDwords = 0;
+    uint32_t perModelDwords = 0;
+    for (size_t m = 0; m < count; ++m) {
+        memb_hip_ctx* ctx = ctxs[m];
+        TrainedParams& p = params.model[m];
+        p = baseTrainedParams(ctx);
+        p.rows = rows[m];
+        p.out = out;
+        p.n = n;
+        p.ld = ld;
+        p.colOff = colOffs[m];
+        p.lanesPerWord = ctx->lanesPerWord;
+        p.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
+        p.wordsPerWave = wordsPerWave;
+        p.segmentSymbols = ctx->segmentSymbols;
+        p.keyRowBytes = keyRowBytes(ctx);
+        p.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
+        p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(count) * (ctx->dim / 4));
+        params.tableOffsetDwords[m] = sharedDwords;
+        sharedDwords += ctx->tableDwords;
+        params.keyTileOffsetDwords[m] = wordsPerWave * ctx->slotDwords;
+        perModelDwords = std::max(perModelDwords, wordsPerWave * ctx->slotDwords + p.keyTileDwords);
+    }
+    perModelDwords = (perModelDwords + 3) / 4 * 4;
+    params.codebookOffsetDwords = sharedDwords;
+    sharedDwords += static_cast<uint32_t>(count) * 512;
+    params.sharedDwords = sharedDwords;
+    params.perModelDwords = perModelDwords;
+    params.rowPieces = static_cast<uint32_t>(count) * (first->dim / 4);
+    params.rowMagic = magicFor(params.rowPieces, uint64_t(wordsPerWave) * params.rowPieces);
+
+    // waves per block: most resident wavefronts per CU, larger blocks on ties (as chooseGeometry)
+    uint32_t waves = 0;
+    uint32_t ldsBytes = 0;
+    double bestResident = -1;
+    for (uint32_t candidate : {8u, 4u, 2u, 1u}) {
+        const uint32_t bytes = 4u * (sharedDwords + candidate * static_cast<uint32_t>(count) * perModelDwords);
+        if (bytes > first->ldsLimit) {
+            continue;
+        }
+        const uint32_t blocksPerCu = std::min<uint32_t>(first->ldsLimit / ((bytes + 1023) / 1024 * 1024), 32 / candidate);
+        if (double(blocksPerCu) * candidate > bestResident) {
+            bestResident = double(blocksPerCu) * candidate;
+            waves = candidate;
+            ldsBytes = bytes;
+        }
+    }
+    if (!waves) {
+        return MEMB_HIP_UNSUPPORTED;
+    }
+    const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
+    const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+    hipError_t status;
+    if (first->fast) {
+        status = launchUnionVariant<false, true>(params, blocks, waves * WAVE, ldsBytes, stream);
+    } else if (hasSub) {
+        status = launchUnionVariant<true, false>(params, blocks, waves * WAVE, ldsBytes, stream);
+    } else {
+        status = launchUnionVariant<false, false>(params, blocks, waves * WAVE, ldsBytes, stream);
+    }
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
 // One pass over every row with one lane per word: records the bit position at
 // which each segment of each row starts (segmentIndex), so that lanesPerWord
 // lanes can later decode a row side by side.
@@ -1253,6 +1364,25 @@ int decode_rows_checked(
     return result;
 }
 
+int decode_rows_union_device_checked(
+    memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n, float* out,
+    size_t ld, void* stream)
+{
+    if (!ctxs || !rows || !col_offs || count == 0 || (n && !out)) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    for (size_t m = 0; m < count; ++m) {
+        if (!ctxs[m] || (n && !rows[m])) {
+            return fail(MEMB_HIP_ERR_INVALID, "null argument");
+        }
+    }
+    if (n == 0) {
+        return MEMB_HIP_OK;
+    }
+    HIP_TRY(hipSetDevice(ctxs[0]->device));
+    return launchTrainedUnion(ctxs, rows, col_offs, count, n, out, ld, static_cast<hipStream_t>(stream));
+}
+
 int sync_checked(memb_hip_ctx* ctx)
 {
     if (!ctx) {
@@ -1360,6 +1490,13 @@ int memb_hip_decode_rows_device_ex(memb_hip_ctx* ctx, const uint32_t* rows, size
 int memb_hip_decode_rows(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
 {
     return guarded([&] { return decode_rows_checked(ctx, rows, n, out, ld, col_off); });
+}
+
+int memb_hip_decode_rows_union_device(
+    memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n, float* out,
+    size_t ld, void* stream)
+{
+    return guarded([&] { return decode_rows_union_device_checked(ctxs, rows, col_offs, count, n, out, ld, stream); });
 }
 
 int memb_hip_sync(memb_hip_ctx* ctx)

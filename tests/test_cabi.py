@@ -20,7 +20,7 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'memb_hip_device_count', 'memb_hip_ctx_create_trained', 'memb_hip_ctx_create_uniform',
         'memb_hip_ctx_create_full', 'memb_hip_ctx_destroy', 'memb_hip_ctx_get_info', 'memb_hip_decode_rows',
-        'memb_hip_decode_rows_device', 'memb_hip_decode_rows_device_ex', 'memb_hip_sync', 'memb_hip_algorithmic_bytes', 'memb_hip_last_error',
+        'memb_hip_decode_rows_device', 'memb_hip_decode_rows_device_ex', 'memb_hip_decode_rows_union_device', 'memb_hip_sync', 'memb_hip_algorithmic_bytes', 'memb_hip_last_error',
     ])
 
 

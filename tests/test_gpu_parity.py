@@ -378,6 +378,51 @@ def test_omitted_default_scalars_on_device(native, tmp_path):
     assert bits_equal(native.Reader(path).batch_embedding(batch), oracle.OracleReader(path).batch_embedding(batch))
 
 
+def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
+    # memb_hip_decode_rows_union_device: two trained models of one geometry decoded by one kernel that
+    # writes the merged rows whole. Same bits as one launch per reader (MEMB_HIP_UNION_FUSED=0) and as
+    # numpy's concatenation of the checker's rows; nibble and byte keys, two-level tables, batches
+    # that end inside a tile, words missing from one or both models, a model paired with itself.
+    import torch
+    cases = [((20000, 300, 4, 1234), (15000, 300, 4, 99)),      # nibble keys
+             ((20000, 300, 6, 1234), (15000, 300, 8, 99)),      # byte keys, the second with two-level tables
+             ((3000, 64, 2, 5), (3000, 64, 4, 6))]              # small dim, different codebooks
+    for first, second in cases:
+        path_a, words_a = make_model(first[0], first[1], 'trained', first[2], seed=first[3])
+        path_b, words_b = make_model(second[0], second[1], 'trained', second[2], seed=second[3])
+        dim = first[1]
+        readers = [native.Reader(path_a), native.Reader(path_b)]
+        checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+        union = native.ReadersUnion(readers, 'concatenate')
+        rng = np.random.default_rng(first[2])
+        for count in (1, 7, 8, 9, 513, 4001):
+            pool = sorted(set(words_a[:3000]) | set(words_b[:3000]))
+            batch = [pool[i] for i in rng.integers(0, len(pool), size=count)]
+            batch[::11] = ['in neither'] * len(batch[::11])
+            expected = np.concatenate([checker.batch_embedding(batch) for checker in checkers], axis=1)
+            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+            fused = union.batch_embedding_device(batch).cpu().numpy()
+            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '0')
+            separate = union.batch_embedding_device(batch).cpu().numpy()
+            assert fused.shape == (count, 2 * dim)
+            assert bits_equal(fused, expected), (first, second, count)
+            assert bits_equal(separate, expected), (first, second, count)
+        monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+        twice = native.ReadersUnion([readers[0], readers[0]], 'concatenate').batch_embedding_device(words_a[:100])
+        assert bits_equal(twice[:, :dim].cpu().numpy(), twice[:, dim:].cpu().numpy())
+    # the C entry point says so when it has no kernel for a combination; the Python layer then launches per reader
+    from memb_amd import _memb
+    path_c, words_c = make_model(2000, 100, 'trained', 4, seed=3)
+    path_u, words_u = make_model(2000, 300, 'uniform', 8, seed=3)
+    odd = [native.Reader(path_c), native.Reader(path_u)]
+    rows = [torch.from_numpy(reader.resolve_rows(words_c[:50]).view(np.int32)).cuda() for reader in odd]
+    out = torch.empty((50, 400), dtype=torch.float32, device='cuda')
+    assert _memb.union_rows_to_device([reader._impl for reader in odd], [r.data_ptr() for r in rows], [0, 100], 50,
+                                      out.data_ptr(), 400, 0) is False
+    mixed = native.ReadersUnion(odd, 'concatenate')
+    assert bits_equal(mixed.batch_embedding_device(words_c[:50]).cpu().numpy(), mixed.batch_embedding(words_c[:50]))
+
+
 @pytest.mark.parametrize('dim', [1, 3, 4, 5, 8, 64, 100, 302, 1024])
 def test_other_dimensions(native, make_model, dim):
     for storage, bits in (('trained', 4), ('trained', 8), ('uniform', 8), ('full', 8)):

@@ -41,6 +41,12 @@ wide=torch.empty((n,608),dtype=torch.float32,device='cuda')
 print('two launches, ld 608 (rows 32-B aligned): %.3f ms'%timeit(lambda: (a.rows_embedding_device(ta,out=wide,col_off=0), b.rows_embedding_device(tb,out=wide,col_off=304))))
 wide=torch.empty((n,640),dtype=torch.float32,device='cuda')
 print('two launches, ld 640, col_off 0 / 320 (halves 128-B aligned): %.3f ms'%timeit(lambda: (a.rows_embedding_device(ta,out=wide,col_off=0), b.rows_embedding_device(tb,out=wide,col_off=320))))
+u=memb_amd.ReadersUnion([a,b],'concatenate')
+from memb_amd import _memb
+def fused():
+    assert _memb.union_rows_to_device([a._impl,b._impl],[ta.data_ptr(),tb.data_ptr()],[0,300],n,out.data_ptr(),600,torch.cuda.current_stream().cuda_stream)
+t=timeit(fused); out.zero_(); fused(); torch.cuda.synchronize()
+print('ONE fused launch (decode_trained_union): %.3f ms  same bits: %s'%(t,bool(torch.equal(out.view(torch.int32),ref.view(torch.int32)))))
 s1=torch.cuda.Stream(); s2=torch.cuda.Stream()
 def concurrent():
     cur=torch.cuda.current_stream()

@@ -178,13 +178,17 @@ int memb_hip_decode_rows_device_ex(
  * model m's block starting at column col_offs[m]. Same result as one
  * memb_hip_decode_rows_device call per model, but the merged rows are written whole
  * instead of one column block per launch. Device pointers, enqueued on `stream`.
+ * With MEMB_HIP_UNION_AVERAGE in `flags` the 'average' mode instead (readers_union.py:5-18):
+ * row i = (vector 0 + vector 1 + ...) / count, added in model order in fp32 and divided once,
+ * as numpy.mean does, written at column col_offs[0].
  * Returns MEMB_HIP_UNSUPPORTED (and does nothing) when the models cannot share a
  * kernel: other than `count` = 2 trained storages of equal dim, lane geometry and key
  * format on one device, or an output that is not 16-byte aligned in every block.
  */
+#define MEMB_HIP_UNION_AVERAGE 1u
 int memb_hip_decode_rows_union_device(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n,
-    float* out, size_t ld, void* stream);
+    float* out, size_t ld, void* stream, uint32_t flags);
 
 /* Wait for the context's own stream (used by memb_hip_decode_rows). */
 int memb_hip_sync(memb_hip_ctx* ctx);

@@ -335,7 +335,8 @@ PYBIND11_MODULE(_memb, m) {
            size_t n,
            uintptr_t out,
            size_t ld,
-           uintptr_t stream)
+           uintptr_t stream,
+           bool average)
         {
             if (readers.size() != rows.size() || readers.size() != colOffs.size() || readers.empty()) {
                 throw std::runtime_error("One row-id array and one column offset per reader are needed");
@@ -348,7 +349,7 @@ PYBIND11_MODULE(_memb, m) {
             }
             int code = memb_hip_decode_rows_union_device(
                 contexts.data(), rowPointers.data(), colOffs.data(), readers.size(), n, reinterpret_cast<float*>(out), ld,
-                reinterpret_cast<void*>(stream));
+                reinterpret_cast<void*>(stream), average ? MEMB_HIP_UNION_AVERAGE : 0u);
             if (code == MEMB_HIP_UNSUPPORTED) {
                 return false;
             }
@@ -363,7 +364,8 @@ PYBIND11_MODULE(_memb, m) {
         py::arg("n"),
         py::arg("out_ptr"),
         py::arg("ld"),
-        py::arg("stream") = 0);
+        py::arg("stream") = 0,
+        py::arg("average") = false);
     m.def("_writer_mimics_official_layout", [](bool enabled) {
         memb::wire::BufferBuilder::omitDefaults() = enabled;
     });

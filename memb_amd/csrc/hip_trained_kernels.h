@@ -585,6 +585,10 @@ __global__ void decode_trained_persistent(TrainedParams p)
 // models (each into a symbol tile of its own) and then writes the merged rows whole.
 // One tile per wavefront (union batches are random lookups; the persistent pipeline buys
 // nothing there), COUNT models of the same geometry (dim, lanes per word) and key format.
+// AVERAGE: the 'average' mode instead (python/memb/readers_union.py:5-18, numpy.mean over the
+// readers): the models' vectors are added in reader order and divided by COUNT in registers --
+// the operations numpy performs, so the same bits -- and the row is written once, where separate
+// launches store, then read, add, divide and store again.
 constexpr int UNION_MAX_MODELS = 2;
 
 struct UnionParams {
@@ -594,11 +598,11 @@ struct UnionParams {
     uint32_t codebookOffsetDwords;   // model m's codebook at this + m * 512 dwords
     uint32_t sharedDwords;           // tables + codebooks
     uint32_t perModelDwords;         // one model's slots + symbol tile of one wave
-    uint32_t rowPieces;              // COUNT * dim / 4: 16-byte pieces of a merged row
+    uint32_t rowPieces;              // 16-byte pieces of a merged row: COUNT * dim / 4, or dim / 4 when averaging
     uint32_t rowMagic;               // fastDivide magic for rowPieces
 };
 
-template <bool HAS_SUB, bool FAST, int COUNT>
+template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE>
 __global__ void decode_trained_union(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -669,12 +673,104 @@ __global__ void decode_trained_union(UnionParams u)
     }
     waveLdsFence();
 
+    if (!AVERAGE) {
+        // merged rows, 16 bytes per lane, row contiguous when the column blocks are adjacent
+        const uint32_t piecesPerWord = first.dim / 4;
+        const uint32_t pieces = tileWords * u.rowPieces;
+        constexpr int BURST = 4;
+        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+            uint32_t k[BURST];
+            uint32_t w[BURST];
+            uint32_t m[BURST];
+            uint32_t c[BURST];
+#pragma unroll
+            for (int b = 0; b < BURST; ++b) {
+                const uint32_t q = min(q0 + WAVE * b, pieces - 1);
+                w[b] = fastDivide(q, u.rowMagic, u.rowPieces);
+                const uint32_t inRow = q - w[b] * u.rowPieces;
+                m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
+                c[b] = inRow - m[b] * piecesPerWord;
+                uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
+#pragma unroll
+                for (int i = 1; i < COUNT; ++i) {
+                    keyTileOffset = m[b] == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
+                }
+                const uint32_t* keyTile = waveLds + m[b] * u.perModelDwords + keyTileOffset;
+                const uint32_t at = w[b] * (first.keyRowBytes / (FAST ? 2 : 4)) + c[b];
+                k[b] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
+            }
+#pragma unroll
+            for (int b = 0; b < BURST; ++b) {
+                const uint32_t* codebook = lds + u.codebookOffsetDwords + m[b] * 512;
+                float4 f;
+                if (FAST) {
+                    const float2 lo = reinterpret_cast<const float2*>(codebook)[k[b] & 0xff];
+                    const float2 hi = reinterpret_cast<const float2*>(codebook)[k[b] >> 8];
+                    f = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    unsigned long long mask = absent[0];
+#pragma unroll
+                    for (int i = 1; i < COUNT; ++i) {
+                        mask = m[b] == static_cast<uint32_t>(i) ? absent[i] : mask;
+                    }
+                    if ((mask >> (w[b] * first.lanesPerWord)) & 1) {
+                        f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    const float* centroids = reinterpret_cast<const float*>(codebook);
+                    f.x = centroids[k[b] & 0xff];
+                    f.y = centroids[(k[b] >> 8) & 0xff];
+                    f.z = centroids[(k[b] >> 16) & 0xff];
+                    f.w = centroids[k[b] >> 24];
+                }
+                if (q0 + WAVE * b < pieces) {
+                    unsigned long long colOff = u.model[0].colOff;
+#pragma unroll
+                    for (int i = 1; i < COUNT; ++i) {
+                        colOff = m[b] == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
+                    }
+                    *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + colOff + 4 * c[b]) = f;
+                }
+            }
+        }
+        return;
+    }
     // merged rows, 16 bytes per lane, row contiguous when the column blocks are adjacent
     const uint32_t piecesPerWord = first.dim / 4;
     const uint32_t pieces = tileWords * u.rowPieces;
-    constexpr int BURST = 4;
+    // two steps, so that a burst's symbol reads are all issued before the codebook reads that
+    // depend on them
+    auto readKey = [&](uint32_t model, uint32_t word, uint32_t column) -> uint32_t {
+        uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
+#pragma unroll
+        for (int i = 1; i < COUNT; ++i) {
+            keyTileOffset = model == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
+        }
+        const uint32_t* keyTile = waveLds + model * u.perModelDwords + keyTileOffset;
+        const uint32_t at = word * (first.keyRowBytes / (FAST ? 2 : 4)) + column;
+        return FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
+    };
+    auto lookUp = [&](uint32_t model, uint32_t word, uint32_t k) -> float4 {
+        const uint32_t* codebook = lds + u.codebookOffsetDwords + model * 512;
+        if (FAST) {
+            unsigned long long mask = absent[0];
+#pragma unroll
+            for (int i = 1; i < COUNT; ++i) {
+                mask = model == static_cast<uint32_t>(i) ? absent[i] : mask;
+            }
+            const float2 lo = reinterpret_cast<const float2*>(codebook)[k & 0xff];
+            const float2 hi = reinterpret_cast<const float2*>(codebook)[k >> 8];
+            if ((mask >> (word * first.lanesPerWord)) & 1) {
+                return make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        const float* centroids = reinterpret_cast<const float*>(codebook);
+        return make_float4(centroids[k & 0xff], centroids[(k >> 8) & 0xff], centroids[(k >> 16) & 0xff], centroids[k >> 24]);
+    };
+    constexpr int BURST = AVERAGE ? 2 : 4;
+    constexpr int KEYS = AVERAGE ? COUNT : 1;   // symbol words a piece needs
     for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
-        uint32_t k[BURST];
+        uint32_t k[BURST][KEYS];
         uint32_t w[BURST];
         uint32_t m[BURST];
         uint32_t c[BURST];
@@ -683,46 +779,43 @@ __global__ void decode_trained_union(UnionParams u)
             const uint32_t q = min(q0 + WAVE * b, pieces - 1);
             w[b] = fastDivide(q, u.rowMagic, u.rowPieces);
             const uint32_t inRow = q - w[b] * u.rowPieces;
-            m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
-            c[b] = inRow - m[b] * piecesPerWord;
-            uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
+            if (AVERAGE) {
+                m[b] = 0;
+                c[b] = inRow;
 #pragma unroll
-            for (int i = 1; i < COUNT; ++i) {
-                keyTileOffset = m[b] == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
+                for (int i = 0; i < COUNT; ++i) {
+                    k[b][i] = readKey(i, w[b], inRow);
+                }
+            } else {
+                m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
+                c[b] = inRow - m[b] * piecesPerWord;
+                k[b][0] = readKey(m[b], w[b], c[b]);
             }
-            const uint32_t* keyTile = waveLds + m[b] * u.perModelDwords + keyTileOffset;
-            const uint32_t at = w[b] * (first.keyRowBytes / (FAST ? 2 : 4)) + c[b];
-            k[b] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
         }
 #pragma unroll
         for (int b = 0; b < BURST; ++b) {
-            const uint32_t* codebook = lds + u.codebookOffsetDwords + m[b] * 512;
             float4 f;
-            if (FAST) {
-                const float2 lo = reinterpret_cast<const float2*>(codebook)[k[b] & 0xff];
-                const float2 hi = reinterpret_cast<const float2*>(codebook)[k[b] >> 8];
-                f = make_float4(lo.x, lo.y, hi.x, hi.y);
-                unsigned long long mask = absent[0];
+            unsigned long long colOff = u.model[0].colOff;
+            if (AVERAGE) {
+                f = lookUp(0, w[b], k[b][0]);
 #pragma unroll
                 for (int i = 1; i < COUNT; ++i) {
-                    mask = m[b] == static_cast<uint32_t>(i) ? absent[i] : mask;
+                    const float4 next = lookUp(i, w[b], k[b][i]);
+                    f.x = addRn(f.x, next.x);
+                    f.y = addRn(f.y, next.y);
+                    f.z = addRn(f.z, next.z);
+                    f.w = addRn(f.w, next.w);
                 }
-                if ((mask >> (w[b] * first.lanesPerWord)) & 1) {
-                    f = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                const float count = static_cast<float>(COUNT);
+                f = make_float4(__fdiv_rn(f.x, count), __fdiv_rn(f.y, count), __fdiv_rn(f.z, count), __fdiv_rn(f.w, count));
             } else {
-                const float* centroids = reinterpret_cast<const float*>(codebook);
-                f.x = centroids[k[b] & 0xff];
-                f.y = centroids[(k[b] >> 8) & 0xff];
-                f.z = centroids[(k[b] >> 16) & 0xff];
-                f.w = centroids[k[b] >> 24];
-            }
-            if (q0 + WAVE * b < pieces) {
-                unsigned long long colOff = u.model[0].colOff;
+                f = lookUp(m[b], w[b], k[b][0]);
 #pragma unroll
                 for (int i = 1; i < COUNT; ++i) {
                     colOff = m[b] == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
                 }
+            }
+            if (q0 + WAVE * b < pieces) {
                 *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + colOff + 4 * c[b]) = f;
             }
         }

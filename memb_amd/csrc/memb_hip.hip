@@ -412,7 +412,7 @@ int launchTrained(
     return MEMB_HIP_OK;
 }
 
-template <bool HAS_SUB, bool FAST>
+template <bool HAS_SUB, bool FAST, bool AVERAGE>
 hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
     static thread_local int configuredDevice = -1;
@@ -420,7 +420,7 @@ hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32
     (void)hipGetDevice(&device);
     if (configuredDevice != device) {
         hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS>),
+            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS, AVERAGE>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (status != hipSuccess) {
             return status;
@@ -428,14 +428,14 @@ hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32
         configuredDevice = device;
     }
     hipLaunchKernelGGL(
-        (decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+        (decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS, AVERAGE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
 }
 
 // See memb_hip_decode_rows_union_device. MEMB_HIP_UNSUPPORTED when the models cannot share the kernel.
 int launchTrainedUnion(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* colOffs, size_t count, size_t n, float* out,
-    size_t ld, hipStream_t stream)
+    size_t ld, hipStream_t stream, bool average)
 {
     if (count != UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
         return MEMB_HIP_UNSUPPORTED;
@@ -485,7 +485,7 @@ int launchTrainedUnion(
     sharedDwords += static_cast<uint32_t>(count) * 512;
     params.sharedDwords = sharedDwords;
     params.perModelDwords = perModelDwords;
-    params.rowPieces = static_cast<uint32_t>(count) * (first->dim / 4);
+    params.rowPieces = (average ? 1u : static_cast<uint32_t>(count)) * (first->dim / 4);
     params.rowMagic = magicFor(params.rowPieces, uint64_t(wordsPerWave) * params.rowPieces);
 
     // waves per block: most resident wavefronts per CU, larger blocks on ties (as chooseGeometry)
@@ -510,12 +510,16 @@ int launchTrainedUnion(
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
     hipError_t status;
+    const uint32_t threads = waves * WAVE;
     if (first->fast) {
-        status = launchUnionVariant<false, true>(params, blocks, waves * WAVE, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, true, true>(params, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<false, true, false>(params, blocks, threads, ldsBytes, stream);
     } else if (hasSub) {
-        status = launchUnionVariant<true, false>(params, blocks, waves * WAVE, ldsBytes, stream);
+        status = average ? launchUnionVariant<true, false, true>(params, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<true, false, false>(params, blocks, threads, ldsBytes, stream);
     } else {
-        status = launchUnionVariant<false, false>(params, blocks, waves * WAVE, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, false, true>(params, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<false, false, false>(params, blocks, threads, ldsBytes, stream);
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
@@ -1366,8 +1370,11 @@ int decode_rows_checked(
 
 int decode_rows_union_device_checked(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n, float* out,
-    size_t ld, void* stream)
+    size_t ld, void* stream, uint32_t flags)
 {
+    if (flags & ~uint32_t(MEMB_HIP_UNION_AVERAGE)) {
+        return fail(MEMB_HIP_ERR_INVALID, "unknown flags");
+    }
     if (!ctxs || !rows || !col_offs || count == 0 || (n && !out)) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
@@ -1380,7 +1387,8 @@ int decode_rows_union_device_checked(
         return MEMB_HIP_OK;
     }
     HIP_TRY(hipSetDevice(ctxs[0]->device));
-    return launchTrainedUnion(ctxs, rows, col_offs, count, n, out, ld, static_cast<hipStream_t>(stream));
+    return launchTrainedUnion(
+        ctxs, rows, col_offs, count, n, out, ld, static_cast<hipStream_t>(stream), (flags & MEMB_HIP_UNION_AVERAGE) != 0);
 }
 
 int sync_checked(memb_hip_ctx* ctx)
@@ -1494,9 +1502,9 @@ int memb_hip_decode_rows(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, floa
 
 int memb_hip_decode_rows_union_device(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n, float* out,
-    size_t ld, void* stream)
+    size_t ld, void* stream, uint32_t flags)
 {
-    return guarded([&] { return decode_rows_union_device_checked(ctxs, rows, col_offs, count, n, out, ld, stream); });
+    return guarded([&] { return decode_rows_union_device_checked(ctxs, rows, col_offs, count, n, out, ld, stream, flags); });
 }
 
 int memb_hip_sync(memb_hip_ctx* ctx)

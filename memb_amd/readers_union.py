@@ -83,15 +83,17 @@ class ReadersUnion(BaseReader):
         device = 'cuda:{}'.format(readers[0].device)
         row_ids = [torch.from_numpy(reader.resolve_rows(words).view('int32')).to(device) for reader in readers]
         merged = torch.empty((len(words), self.dim), dtype=torch.float32, device=device)
-        if self._mode == CONCATENATE:
-            # one launch that writes the merged rows whole, where the readers can share a kernel
-            from . import _memb
-            columns = [sum(self._widths[:i]) for i in range(len(readers))]
-            stream = torch.cuda.current_stream(merged.device).cuda_stream
-            if len(words) and _memb.union_rows_to_device(
-                    [reader._impl for reader in readers], [ids.data_ptr() for ids in row_ids], columns,
-                    len(words), merged.data_ptr(), merged.stride(0), stream):
-                return merged
+        # one launch that decodes every reader's words of a tile and writes the merged rows once,
+        # where the readers can share a kernel
+        from . import _memb
+        concatenate = self._mode == CONCATENATE
+        columns = [sum(self._widths[:i]) if concatenate else 0 for i in range(len(readers))]
+        stream = torch.cuda.current_stream(merged.device).cuda_stream
+        if len(words) and _memb.union_rows_to_device(
+                [reader._impl for reader in readers], [ids.data_ptr() for ids in row_ids], columns,
+                len(words), merged.data_ptr(), merged.stride(0), stream, not concatenate):
+            return merged
+        if concatenate:
             column = 0
             for reader, ids, width in zip(readers, row_ids, self._widths):
                 reader.rows_embedding_device(ids, out=merged, col_off=column)

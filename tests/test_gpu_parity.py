@@ -407,6 +407,13 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
             assert fused.shape == (count, 2 * dim)
             assert bits_equal(fused, expected), (first, second, count)
             assert bits_equal(separate, expected), (first, second, count)
+            # the 'average' mode through the same kernel: numpy.mean of the checker's rows, bit for bit
+            mean = native.ReadersUnion(readers, 'average')
+            expected_mean = np.mean([checker.batch_embedding(batch) for checker in checkers], axis=0)
+            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+            assert bits_equal(mean.batch_embedding_device(batch).cpu().numpy(), expected_mean), (first, second, count)
+            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '0')
+            assert bits_equal(mean.batch_embedding_device(batch).cpu().numpy(), expected_mean), (first, second, count)
         monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
         twice = native.ReadersUnion([readers[0], readers[0]], 'concatenate').batch_embedding_device(words_a[:100])
         assert bits_equal(twice[:, :dim].cpu().numpy(), twice[:, dim:].cpu().numpy())
@@ -418,7 +425,7 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
     rows = [torch.from_numpy(reader.resolve_rows(words_c[:50]).view(np.int32)).cuda() for reader in odd]
     out = torch.empty((50, 400), dtype=torch.float32, device='cuda')
     assert _memb.union_rows_to_device([reader._impl for reader in odd], [r.data_ptr() for r in rows], [0, 100], 50,
-                                      out.data_ptr(), 400, 0) is False
+                                      out.data_ptr(), 400, 0, False) is False
     mixed = native.ReadersUnion(odd, 'concatenate')
     assert bits_equal(mixed.batch_embedding_device(words_c[:50]).cpu().numpy(), mixed.batch_embedding(words_c[:50]))
 

@@ -60,3 +60,11 @@ for ld in (300, 304, 320, 400, 600, 1200):
     wide=torch.empty((n,ld),dtype=torch.float32,device='cuda')
     print('one reader, ld %4d: %.3f ms'%(ld,timeit(lambda: a.rows_embedding_device(ta,out=wide,col_off=0))))
     del wide
+avg=torch.empty((n,300),dtype=torch.float32,device='cuda')
+def average_two():
+    a.rows_embedding_device(ta,out=avg); b.rows_embedding_device(tb,out=avg,accumulate=True,divisor=2.0)
+def average_fused():
+    assert _memb.union_rows_to_device([a._impl,b._impl],[ta.data_ptr(),tb.data_ptr()],[0,0],n,avg.data_ptr(),300,torch.cuda.current_stream().cuda_stream,True)
+average_two(); torch.cuda.synchronize(); want=avg.clone()
+t2=timeit(average_two); t1=timeit(average_fused); average_fused(); torch.cuda.synchronize()
+print('average of the two models: two launches %.3f ms, one fused launch %.3f ms, same bits: %s'%(t2,t1,bool(torch.equal(avg.view(torch.int32),want.view(torch.int32)))))

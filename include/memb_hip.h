@@ -182,7 +182,7 @@ int memb_hip_decode_rows_device_ex(
  * row i = (vector 0 + vector 1 + ...) / count, added in model order in fp32 and divided once,
  * as numpy.mean does, written at column col_offs[0].
  * Returns MEMB_HIP_UNSUPPORTED (and does nothing) when the models cannot share a
- * kernel: other than `count` = 2 trained storages of equal dim, lane geometry and key
+ * kernel: other than 2 to 4 trained storages of equal dim, lane geometry and key
  * format on one device, or an output that is not 16-byte aligned in every block.
  */
 #define MEMB_HIP_UNION_AVERAGE 1u

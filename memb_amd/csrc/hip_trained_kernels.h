@@ -589,7 +589,7 @@ __global__ void decode_trained_persistent(TrainedParams p)
 // readers): the models' vectors are added in reader order and divided by COUNT in registers --
 // the operations numpy performs, so the same bits -- and the row is written once, where separate
 // launches store, then read, add, divide and store again.
-constexpr int UNION_MAX_MODELS = 2;
+constexpr int UNION_MAX_MODELS = 4;
 
 struct UnionParams {
     TrainedParams model[UNION_MAX_MODELS];   // out / ld shared, colOff per model; n, wordsPerWave etc. equal

@@ -412,15 +412,15 @@ int launchTrained(
     return MEMB_HIP_OK;
 }
 
-template <bool HAS_SUB, bool FAST, bool AVERAGE>
-hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+template <bool HAS_SUB, bool FAST, bool AVERAGE, int COUNT>
+hipError_t launchUnionCount(const UnionParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
     static thread_local int configuredDevice = -1;
     int device = 0;
     (void)hipGetDevice(&device);
     if (configuredDevice != device) {
         hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS, AVERAGE>),
+            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (status != hipSuccess) {
             return status;
@@ -428,8 +428,22 @@ hipError_t launchUnionVariant(const UnionParams& params, uint32_t blocks, uint32
         configuredDevice = device;
     }
     hipLaunchKernelGGL(
-        (decode_trained_union<HAS_SUB, FAST, UNION_MAX_MODELS, AVERAGE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+        (decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
+}
+
+template <bool HAS_SUB, bool FAST, bool AVERAGE>
+hipError_t launchUnionVariant(
+    const UnionParams& params, size_t count, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    switch (count) {
+        case 2:
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 2>(params, blocks, threads, ldsBytes, stream);
+        case 3:
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 3>(params, blocks, threads, ldsBytes, stream);
+        default:
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 4>(params, blocks, threads, ldsBytes, stream);
+    }
 }
 
 // See memb_hip_decode_rows_union_device. MEMB_HIP_UNSUPPORTED when the models cannot share the kernel.
@@ -437,7 +451,7 @@ int launchTrainedUnion(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* colOffs, size_t count, size_t n, float* out,
     size_t ld, hipStream_t stream, bool average)
 {
-    if (count != UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
+    if (count < 2 || count > UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
         return MEMB_HIP_UNSUPPORTED;
     }
     const memb_hip_ctx* first = ctxs[0];
@@ -512,14 +526,14 @@ int launchTrainedUnion(
     hipError_t status;
     const uint32_t threads = waves * WAVE;
     if (first->fast) {
-        status = average ? launchUnionVariant<false, true, true>(params, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<false, true, false>(params, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, true, true>(params, count, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<false, true, false>(params, count, blocks, threads, ldsBytes, stream);
     } else if (hasSub) {
-        status = average ? launchUnionVariant<true, false, true>(params, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<true, false, false>(params, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<true, false, true>(params, count, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<true, false, false>(params, count, blocks, threads, ldsBytes, stream);
     } else {
-        status = average ? launchUnionVariant<false, false, true>(params, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<false, false, false>(params, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, false, true>(params, count, blocks, threads, ldsBytes, stream)
+                         : launchUnionVariant<false, false, false>(params, count, blocks, threads, ldsBytes, stream);
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));

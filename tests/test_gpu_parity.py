@@ -417,6 +417,20 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
         monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
         twice = native.ReadersUnion([readers[0], readers[0]], 'concatenate').batch_embedding_device(words_a[:100])
         assert bits_equal(twice[:, :dim].cpu().numpy(), twice[:, dim:].cpu().numpy())
+    # three and four readers through the same kernel (and five: no kernel, one launch per reader)
+    models = [make_model(4000, 300, 'trained', bits, seed=40 + bits) for bits in (2, 4, 4, 2, 4)]
+    models[2] = make_model(5000, 300, 'trained', 4, seed=77)
+    many_readers = [native.Reader(path) for path, _ in models]
+    many_checkers = [oracle.OracleReader(path) for path, _ in models]
+    pool = sorted(set().union(*[set(words[:1500]) for _, words in models]))
+    batch = [pool[i] for i in np.random.default_rng(9).integers(0, len(pool), size=2500)] + ['nowhere']
+    monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+    for count in (3, 4, 5):
+        rows = [checker.batch_embedding(batch) for checker in many_checkers[:count]]
+        concatenated = native.ReadersUnion(many_readers[:count], 'concatenate').batch_embedding_device(batch)
+        assert bits_equal(concatenated.cpu().numpy(), np.concatenate(rows, axis=1)), count
+        averaged = native.ReadersUnion(many_readers[:count], 'average').batch_embedding_device(batch)
+        assert bits_equal(averaged.cpu().numpy(), np.mean(rows, axis=0)), count
     # the C entry point says so when it has no kernel for a combination; the Python layer then launches per reader
     from memb_amd import _memb
     path_c, words_c = make_model(2000, 100, 'trained', 4, seed=3)

@@ -31,6 +31,8 @@ WORKLOADS = {
     # name: (words, bits, batch) ; batch None = every key (full dump)
     'glove840b-300d-4bit-fullvocab': (2196017, 4, None),     # north-star headline (SURVEY 8d "H")
     'glove840b-300d-4bit-100k': (2196017, 4, 100000),        # BASELINE.json configs[1]
+    'fasttext2m-300d-6bit-fullvocab': (1999995, 6, None),    # BASELINE.json configs[2]
+    'glove840b-300d-2bit-fullvocab': (2196017, 2, None),     # BASELINE.json configs[3] (per GPU)
     'small-4bit': (50000, 4, None),                          # quick functional run
 }
 
@@ -302,7 +304,7 @@ def main():
             traffic = json.load(f).get(args.workload)
 
     result = {
-        'metric': 'embeddings/sec (and HBM GB/s vs roofline), 300-dim 4-bit batch lookup',
+        'metric': 'embeddings/sec (and HBM GB/s vs roofline), 300-dim {}-bit batch lookup'.format(bits),
         'value': args.gpus * n * args.steps / elapsed,
         'unit': 'embeddings/s',
         'n_gpus': args.gpus,

@@ -96,10 +96,13 @@ int streamRowsToHost(memb_hip_ctx* ctx, const void* deviceRows, size_t rowBytes,
     // chunks of at most 32 MiB of device rows and at most 32 MiB worth of result rows
     // (tests shrink the chunk and force the threads to run every branch on small batches)
     size_t chunkRows = std::min(RING_CHUNK_BYTES / rowBytes, std::max<size_t>(1, RING_CHUNK_BYTES / resultRowBytes));
-    chunkRows = std::max<size_t>(1, std::min<size_t>(chunkRows, envUint("MEMB_HIP_COPY_CHUNK_ROWS", ~0u)));
+    if (ctx->switches.copyChunkRows) {
+        chunkRows = std::min<size_t>(chunkRows, ctx->switches.copyChunkRows);
+    }
+    chunkRows = std::max<size_t>(1, chunkRows);
     const size_t chunks = (words + chunkRows - 1) / chunkRows;
-    const size_t wanted = std::min<size_t>(envUint("MEMB_HIP_COPY_THREADS", 16), 64);
-    const bool parallel = words * resultRowBytes >= (size_t(8) << 20) || envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0) != 0;
+    const size_t wanted = ctx->switches.copyThreads;
+    const bool parallel = words * resultRowBytes >= (size_t(8) << 20) || ctx->switches.copyChunkRows != 0;
     const size_t threads = parallel ? wanted : 0;   // 0: this thread does the rows
 
     std::mutex mutex;

@@ -105,7 +105,21 @@ uint32_t envUint(const char* name, uint32_t fallback)
 // Context
 // ---------------------------------------------------------------------------
 
+// Measurement / test switches (environment variables, see tools/perf/README.md), read once
+// when a context is created.
+struct Switches {
+    uint32_t waves = 0;            // MEMB_HIP_WAVES: force the wavefronts per block (0 = choose)
+    uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG: 1 = skip decode, 2 = skip output
+    bool persistent = true;        // MEMB_HIP_PERSISTENT
+    bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
+    uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
+    uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
+    uint32_t copyThreads = 16;     // MEMB_HIP_COPY_THREADS
+    bool verbose = false;          // MEMB_HIP_VERBOSE
+};
+
 struct memb_hip_ctx {
+    Switches switches;
     int device = 0;
     uint32_t storage = 0;
     uint32_t dim = 0;
@@ -201,7 +215,7 @@ TrainedGeometry chooseGeometry(
 {
     TrainedGeometry best{};
     double bestWaves = -1;
-    const uint32_t forcedWaves = envUint("MEMB_HIP_WAVES", 0);
+    const uint32_t forcedWaves = ctx->switches.waves;
     for (uint32_t waves : {8u, 4u, 2u, 1u}) {
         if (forcedWaves && waves != forcedWaves) {
             continue;
@@ -326,7 +340,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.dim = ctx->dim;
     params.slotDwords = ctx->slotDwords;
     params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4) * 5);
-    params.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
+    params.debugFlags = ctx->switches.debugFlags;
     return params;
 }
 
@@ -386,7 +400,7 @@ int launchTrained(
     // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
     // (long streams with few lanes per word) take the one-shot kernel.
     const uint32_t streamRounds = (wordsPerWave * (ctx->slotDwords / 4) + WAVE - 1) / WAVE;
-    const bool persistent = streamRounds <= STREAM_REGISTERS && envUint("MEMB_HIP_PERSISTENT", 1) != 0;
+    const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
     hipError_t status;
     switch (geometry.mode) {
         case OUT_FLAT:
@@ -747,6 +761,20 @@ int openDevice(memb_hip_ctx* ctx, int device)
     return MEMB_HIP_OK;
 }
 
+Switches readSwitches()
+{
+    Switches switches;
+    switches.waves = envUint("MEMB_HIP_WAVES", 0);
+    switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
+    switches.persistent = envUint("MEMB_HIP_PERSISTENT", 1) != 0;
+    switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
+    switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
+    switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
+    switches.copyThreads = std::min<uint32_t>(envUint("MEMB_HIP_COPY_THREADS", 16), 64);
+    switches.verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
+    return switches;
+}
+
 void destroy(memb_hip_ctx* ctx)
 {
     if (!ctx) {
@@ -839,6 +867,7 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     const double tStart = now();
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
+    ctx->switches = readSwitches();
     ctx->storage = memb::wire::Storage_Trained;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -1122,6 +1151,7 @@ int ctx_create_uniform_checked(memb_hip_ctx** out, int device, const memb_hip_un
     }
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
+    ctx->switches = readSwitches();
     ctx->storage = memb::wire::Storage_Uniform;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -1172,6 +1202,7 @@ int ctx_create_full_checked(memb_hip_ctx** out, int device, const memb_hip_full_
     }
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
+    ctx->switches = readSwitches();
     ctx->storage = memb::wire::Storage_Full;
     ctx->dim = desc->dim;
     ctx->nRows = desc->n_rows;
@@ -1321,9 +1352,9 @@ int decode_rows_checked(
     // fp32 rows) are processed in slices.
     const size_t dim = ctx->dim;
     const bool asKeys = ctx->storage == memb::wire::Storage_Trained && !ctx->hostCodebook.empty() &&
-        keyRowBytes(ctx) <= RING_CHUNK_BYTES && envUint("MEMB_HIP_HOST_EXPAND", 1) != 0 && ensureRing(ctx);
+        keyRowBytes(ctx) <= RING_CHUNK_BYTES && ctx->switches.hostExpand && ensureRing(ctx);
     const size_t stagedRowBytes = asKeys ? keyRowBytes(ctx) : dim * sizeof(float);
-    const size_t sliceLimit = std::min<size_t>((size_t(4) << 30) / (dim * sizeof(float)), envUint("MEMB_HIP_SLICE_WORDS", ~0u));
+    const size_t sliceLimit = std::min<size_t>((size_t(4) << 30) / (dim * sizeof(float)), ctx->switches.sliceWords);
     const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, sliceLimit));
     if (ctx->stagedCapacity < sliceWords || ctx->stagedRowBytes < stagedRowBytes) {
         if (ctx->stagedRows) {
@@ -1340,7 +1371,7 @@ int decode_rows_checked(
         ctx->stagedCapacity = sliceWords;
         ctx->stagedRowBytes = stagedRowBytes;
     }
-    const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
+    const bool verbose = ctx->switches.verbose;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     int result = MEMB_HIP_OK;

@@ -18,6 +18,8 @@ for m in (10000, 100000, 400000, n):
     r.rows_embedding(rows)
     for threads in (0, 4, 8, 16, 32, 64):
         os.environ['MEMB_HIP_COPY_THREADS']=str(threads)
+        r=memb_amd.Reader(path); r.info(); handle=r._impl.context_handle()   # switches are read when a context is created
+        r.rows_embedding(rows)
         best=1e9; reuse=1e9
         out=np.empty((m,300),dtype=np.float32)
         for rep in range(5):

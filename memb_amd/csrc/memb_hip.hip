@@ -851,27 +851,11 @@ int device_count_checked(int* count)
     return MEMB_HIP_OK;
 }
 
-int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
-{
-    if (!out || !desc) {
-        return fail(MEMB_HIP_ERR_INVALID, "null argument");
-    }
-    *out = nullptr;
-    if (desc->dim == 0 || desc->n_keys == 0 || desc->n_keys > 256 || desc->n_centroids > 255 ||
-        (desc->n_rows && !desc->value_offsets) || (desc->packed_values_bytes && !desc->packed_values)) {
-        return fail(MEMB_HIP_ERR_INVALID, "inconsistent trained storage description");
-    }
+// ---- staging of a trained storage, step by step (memb_hip_ctx_create_trained) ----
 
-    const bool verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tStart = now();
-    memb_hip_ctx* ctx = new memb_hip_ctx();
-    ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
-    ctx->switches = readSwitches();
-    ctx->storage = memb::wire::Storage_Trained;
-    ctx->dim = desc->dim;
-    ctx->nRows = desc->n_rows;
-    int code = MEMB_HIP_OK;
+// Code lengths -> two-level lookup table (host form).
+int buildHostTable(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
     try {
         auto lengths = memb::codeLengthsFromSizeOffsets(
             desc->keys, desc->n_keys, desc->size_offsets, desc->n_size_offsets);
@@ -897,10 +881,15 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
         return fail(MEMB_HIP_ERR_INVALID, error.what());
     }
 
-    // Per-row stream length: streams are laid out back to back, so a stream ends
-    // where the next one (in storage order) begins. Every start is marked in a
-    // bitmap over the byte positions; each row then scans forward to the next
-    // mark. Both passes run on a few host threads.
+    return MEMB_HIP_OK;
+}
+
+// Per-row stream length: streams are laid out back to back, so a stream ends where the
+// next one (in storage order) begins. Sets ctx->streamBytes and ctx->maxStreamBytes.
+int measureStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
+    // Every start is marked in a bitmap over the byte positions; each row then scans forward
+    // to the next mark. Both passes run on a few host threads.
     {
         for (uint64_t r = 0; r < desc->n_rows; ++r) {
             if (desc->value_offsets[r] > desc->packed_values_bytes) {
@@ -959,15 +948,12 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
         });
         ctx->maxStreamBytes = *std::max_element(threadMax.begin(), threadMax.end());
     }
-    // Slot: stream plus the 12-byte window the decoder reads at its last
-    // position; whole 16-byte pieces, an odd number of them so that equal
-    // positions in consecutive slots fall into different LDS banks.
-    ctx->slotDwords = (((ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
-    ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
-        !envUint("MEMB_HIP_NO_FAST", 0);
-    ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
+    return MEMB_HIP_OK;
+}
 
-    const double tSorted = now();
+// Re-packed layout on the device: streamStarts, then the bitstreams themselves (repack_streams).
+int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
     // Re-packed layout: row r's stream occupies ceil(bytes / 16) pieces from streamStarts[r].
     std::vector<uint32_t> streamStarts(desc->n_rows + 1, 0);
     {
@@ -983,12 +969,9 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     }
     const size_t streamPieces = size_t(streamStarts[desc->n_rows]) + ctx->slotDwords / 4 + 1;   // + guard of one slot
 
-    code = openDevice(ctx, device);
+    int code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
     uint8_t* filePacked = nullptr;      // temporary device copies of the file's arrays
     uint32_t* fileOffsets = nullptr;
-    if (code == MEMB_HIP_OK) {
-        code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
-    }
     if (code == MEMB_HIP_OK) {
         hipError_t status = hipMemset(ctx->streams, 0, streamPieces * 16);
         if (status != hipSuccess) {
@@ -1036,27 +1019,36 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
             (void)hipFree(fileOffsets);
         }
     }
-    const double tRepacked = now();
-    if (code == MEMB_HIP_OK) {
-        // Lanes per word (G) and symbols per lane (S): MEMB_HIP_LANES (default 8, the measured
-        // optimum for 300-dimensional rows) or, for rows so long that a wavefront's 64 / G
-        // bitstream slots and symbol rows would not fit into LDS, the next power of two that does;
-        // rows of fewer than 8 weights are not split.
-        uint32_t lanes = std::max<uint32_t>(1, std::min<uint32_t>(envUint("MEMB_HIP_LANES", 8), WAVE));
-        if (desc->dim < 8) {
-            lanes = 1;
-        }
-        const uint32_t group = ctx->fast ? 8 : 4;
-        for (;;) {
-            ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
-            ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
-            if (lanes >= WAVE || trainedLdsBytes(ctx, 1, WAVE / ctx->lanesPerWord, true) <= ctx->ldsLimit) {
-                break;
-            }
-            lanes = std::min<uint32_t>(WAVE, lanes < 8 ? 8 : 2 * lanes);
-        }
-        ctx->indexWide = uint64_t(ctx->maxStreamBytes) * 8 + 64 >= 65536;
+    return code;
+}
+
+// Lanes per word (G), symbols per lane (S) and the width of the segment index.
+void chooseLanes(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
+    // MEMB_HIP_LANES (default 8, the measured
+    // optimum for 300-dimensional rows) or, for rows so long that a wavefront's 64 / G
+    // bitstream slots and symbol rows would not fit into LDS, the next power of two that does;
+    // rows of fewer than 8 weights are not split.
+    uint32_t lanes = std::max<uint32_t>(1, std::min<uint32_t>(envUint("MEMB_HIP_LANES", 8), WAVE));
+    if (desc->dim < 8) {
+        lanes = 1;
     }
+    const uint32_t group = ctx->fast ? 8 : 4;
+    for (;;) {
+        ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
+        ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
+        if (lanes >= WAVE || trainedLdsBytes(ctx, 1, WAVE / ctx->lanesPerWord, true) <= ctx->ldsLimit) {
+            break;
+        }
+        lanes = std::min<uint32_t>(WAVE, lanes < 8 ? 8 : 2 * lanes);
+    }
+    ctx->indexWide = uint64_t(ctx->maxStreamBytes) * 8 + 64 >= 65536;
+}
+
+// Lookup table and codebook in their device forms.
+int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
+    int code = MEMB_HIP_OK;
     if (code == MEMB_HIP_OK) {
         code = deviceAlloc(ctx, &ctx->table, size_t(ctx->tableDwords) * 4);
     }
@@ -1095,6 +1087,13 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
         code = copyToDevice(ctx->codebook, codebook.data(), 512 * 4);
         ctx->hostCodebook = codebook;
     }
+    return code;
+}
+
+// Segment index (one decode pass over every row) and the rowMeta records packed from it.
+int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
+{
+    int code = MEMB_HIP_OK;
     if (code == MEMB_HIP_OK) {
         TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
         if (!geometry.waves) {
@@ -1129,7 +1128,60 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
             }
         }
     }
-    if (verbose) {
+    return code;
+}
+
+int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_trained_desc* desc)
+{
+    if (!out || !desc) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    *out = nullptr;
+    if (desc->dim == 0 || desc->n_keys == 0 || desc->n_keys > 256 || desc->n_centroids > 255 ||
+        (desc->n_rows && !desc->value_offsets) || (desc->packed_values_bytes && !desc->packed_values)) {
+        return fail(MEMB_HIP_ERR_INVALID, "inconsistent trained storage description");
+    }
+
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tStart = now();
+    memb_hip_ctx* ctx = new memb_hip_ctx();
+    ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
+    ctx->switches = readSwitches();
+    ctx->storage = memb::wire::Storage_Trained;
+    ctx->dim = desc->dim;
+    ctx->nRows = desc->n_rows;
+
+    // host side: tables and stream lengths (everything that can refuse a description does so
+    // before a device is opened)
+    int code = buildHostTable(ctx, desc);
+    if (code == MEMB_HIP_OK) {
+        code = measureStreams(ctx, desc);
+    }
+    if (code != MEMB_HIP_OK) {
+        return code;
+    }
+    // Slot: stream plus the 12-byte window the decoder reads at its last
+    // position; whole 16-byte pieces, an odd number of them so that equal
+    // positions in consecutive slots fall into different LDS banks.
+    ctx->slotDwords = (((ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
+    ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
+        !envUint("MEMB_HIP_NO_FAST", 0);
+    ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
+    const double tSorted = now();
+
+    code = openDevice(ctx, device);
+    if (code == MEMB_HIP_OK) {
+        code = stageStreams(ctx, desc);
+    }
+    const double tRepacked = now();
+    if (code == MEMB_HIP_OK) {
+        chooseLanes(ctx, desc);
+        code = stageTables(ctx, desc);
+    }
+    if (code == MEMB_HIP_OK) {
+        code = stageIndex(ctx, desc);
+    }
+    if (ctx->switches.verbose) {
         std::fprintf(stderr, "memb_hip: stage trained rows=%llu: host lengths %.3fs, device open + copy + repack %.3fs, tables + index %.3fs\n",
                      static_cast<unsigned long long>(desc->n_rows), tSorted - tStart, tRepacked - tSorted, now() - tRepacked);
     }

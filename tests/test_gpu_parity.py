@@ -712,8 +712,9 @@ def test_generic_path_on_a_small_codebook(native, make_model, monkeypatch):
 def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
     """Seeded sweep: random dimension, vocabulary, storage, bit width, lanes per word, batch make-up,
     output stride / column offset -- HIP path vs CPU checker, bit for bit."""
-    rng = np.random.default_rng(2024)
-    for trial in range(40):
+    # (MEMB_TEST_SWEEP_TRIALS / MEMB_TEST_SWEEP_SEED: longer one-off sweeps with other seeds)
+    rng = np.random.default_rng(int(os.environ.get('MEMB_TEST_SWEEP_SEED', 2024)))
+    for trial in range(int(os.environ.get('MEMB_TEST_SWEEP_TRIALS', 40))):
         dim = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 20, 31, 32, 48, 63, 64, 96, 100, 128, 200, 257, 300, 512]))
         count = int(rng.integers(1, 2500))
         storage = str(rng.choice(['trained', 'trained', 'trained', 'uniform', 'full']))
@@ -741,6 +742,7 @@ def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
         batch = [w if rng.random() >= miss_rate else w + '?' for w in batch]
         expected = checker.batch_embedding(batch)
         assert nan_aware_equal(reader.batch_embedding(batch), expected), (trial, dim, count, storage, bits)
+        assert nan_aware_equal(reader.batch_embedding_device(batch).cpu().numpy(), expected), (trial, 'device', dim, storage, bits)
 
         pad = int(rng.choice([0, 1, 4, 5, 64]))
         col_off = int(rng.choice([0, 1, 4, 8]))

@@ -1,0 +1,54 @@
+"""Soak: Readers created and dropped in a loop, host and device lookups of random sizes, unions, several threads --
+every result checked against the CPU checker. Exits non-zero on the first mismatch; prints progress every 50 rounds."""
+import os, sys, time, threading
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import memb_amd, oracle
+from memb_amd import synthetic
+seconds=float(os.environ.get('SOAK_SECONDS','240'))
+rng=np.random.default_rng(int(os.environ.get('SOAK_SEED','1')))
+models=[]
+for i,(count,dim,storage,bits) in enumerate([(30000,300,'trained',4),(20000,300,'trained',6),(5000,64,'trained',2),(8000,300,'uniform',8),(3000,100,'full',8),(12000,300,'trained',8)]):
+    path='/tmp/soak_%d.bin'%i
+    words=synthetic.build_file(path,count,dim,storage,bits,seed=100+i)
+    models.append((path,words,oracle.OracleReader(path)))
+start=time.time(); rounds=0; lookups=0
+def check(got, want, what):
+    if not np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32)):
+        print('MISMATCH', what, flush=True); os._exit(1)
+while time.time()-start < seconds:
+    path,words,checker=models[int(rng.integers(0,len(models)))]
+    reader=memb_amd.Reader(path)
+    for _ in range(int(rng.integers(1,6))):
+        n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000]))
+        batch=[words[i] for i in rng.integers(0,len(words),size=n)]
+        if rng.random()<0.5: batch[::7]=['?']*len(batch[::7])
+        want=checker.batch_embedding(batch)
+        kind=int(rng.integers(0,4))
+        if kind==0: check(reader.batch_embedding(batch), want, 'host')
+        elif kind==1: check(reader.batch_embedding_device(batch).cpu().numpy(), want, 'device')
+        elif kind==2:
+            wide=np.zeros((n,reader.dim+9),dtype=np.float32); reader.batch_embedding_into(batch,wide,5); check(np.ascontiguousarray(wide[:,5:5+reader.dim]), want, 'strided')
+        else:
+            results=[None,None]
+            def work(i):
+                results[i]=reader.batch_embedding(batch)
+            ts=[threading.Thread(target=work,args=(i,)) for i in range(2)]
+            [t.start() for t in ts]; [t.join() for t in ts]
+            check(results[0], want, 'thread0'); check(results[1], want, 'thread1')
+        lookups+=1
+    if rng.random()<0.3:
+        a=memb_amd.Reader(models[0][0]); b=memb_amd.Reader(models[1][0])
+        pool=models[0][1][:2000]+models[1][1][:2000]
+        batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000])))]
+        for mode in ('concatenate','average'):
+            u=memb_amd.ReadersUnion([a,b],mode)
+            rows=[models[0][2].batch_embedding(batch), models[1][2].batch_embedding(batch)]
+            want=np.concatenate(rows,axis=1) if mode=='concatenate' else np.mean(rows,axis=0)
+            check(u.batch_embedding_device(batch).cpu().numpy(), want, 'union '+mode)
+            check(u.batch_embedding(batch), want, 'union host '+mode)
+        del a,b
+    del reader
+    rounds+=1
+    if rounds%50==0: print('round %d, %d lookups, %.0f s'%(rounds,lookups,time.time()-start), flush=True)
+print('soak ok: %d rounds, %d lookups in %.0f s'%(rounds,lookups,time.time()-start))

@@ -183,6 +183,7 @@ PYBIND11_MODULE(_memb, m) {
         .def("device", [](memb::Reader& reader) { return reader.device(); })
         .def("storage_name", [](memb::Reader& reader) { return reader.storageName(); })
         .def("info", &contextInfo)
+        .def("has_word_index", [](memb::Reader& reader) { return reader.hasWordIndex(); })
         .def(
             "context_handle",
             [](memb::Reader& reader) { return reinterpret_cast<uintptr_t>(reader.deviceContext()); })

@@ -116,6 +116,11 @@ std::vector<std::string> Reader::keys() const
     return compressedStorage_->keys();
 }
 
+bool Reader::hasWordIndex() const
+{
+    return compressedStorage_->hasWordIndex();
+}
+
 memb_hip_ctx* Reader::deviceContext() const
 {
     return compressedStorage_->deviceContext();
@@ -159,7 +164,8 @@ void Reader::startSearch(const char* const* words, size_t count, uint32_t* rows,
 void Reader::resolveRows(const char* const* words, size_t count, uint32_t* rows) const
 {
     const CompressedStorage* storage = compressedStorage_.get();
-    const bool useIndex = count >= INDEX_THRESHOLD || storage->hasWordIndex();
+    const bool useIndex = count >= INDEX_THRESHOLD || storage->hasWordIndex() ||
+        wordsResolved_.fetch_add(count, std::memory_order_relaxed) + count >= INDEX_THRESHOLD;
 
     if (count < THREADED_DECODER_THRESHOLD || numThreads_ == 1) {
         storage->resolveMany(words, count, rows, useIndex);

@@ -6,6 +6,7 @@
 #include "compression_strategy.h"
 #include "worker_pool.h"
 
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
@@ -73,6 +74,7 @@ public:
         bool accumulate = false, float divisor = 0.f) const;
 
     memb_hip_ctx* deviceContext() const;
+    bool hasWordIndex() const;   // whether lookups go through the hash index by now
 
 private:
     wire::TableView getIndexChecked() const;
@@ -86,6 +88,9 @@ private:
     size_t numThreads_;
     // threads for the word search: created with the first large batch, used by one batch at
     // a time (a second concurrent caller falls back to threads of its own)
+    // words looked up so far: the hash index is built once this passes the size of a batch that
+    // would have built it, so that a stream of small batches gets it too
+    mutable std::atomic<size_t> wordsResolved_{0};
     mutable std::mutex poolMutex_;
     mutable std::unique_ptr<WorkerPool> pool_;
     MappedFile mappedFile_;

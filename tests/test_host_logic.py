@@ -92,6 +92,15 @@ def test_hash_index_lookup_equals_binary_search(native, make_model):
         assert np.array_equal(small, expected[:100])
         assert np.array_equal(reader.resolve_rows(probes), expected)          # builds + uses the index
         assert np.array_equal(reader.resolve_rows(tuple(probes[:100])), expected[:100])  # index reused; any sequence
+    # a stream of small batches gets the index too, once it has looked up as many words as a batch that builds it
+    reader = native.Reader(path)
+    assert not reader._impl.has_word_index()
+    for start in range(0, 4000, 500):
+        assert np.array_equal(reader.resolve_rows(probes[start:start + 500]), expected[start:start + 500])
+    assert not reader._impl.has_word_index()
+    assert np.array_equal(reader.resolve_rows(probes[4000:4500]), expected[4000:4500])
+    assert reader._impl.has_word_index()
+    assert np.array_equal(reader.resolve_rows(probes[:300]), expected[:300])
     with pytest.raises(TypeError):
         native.Reader(path).resolve_rows(['ok', 3])
     for storage in ('uniform', 'full'):

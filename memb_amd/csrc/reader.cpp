@@ -126,13 +126,14 @@ memb_hip_ctx* Reader::deviceContext() const
     return compressedStorage_->deviceContext();
 }
 
-// reference src/reader.cpp:41-47
+// reference src/reader.cpp:41-47 (extract, zeros for a word that is not there): a batch of one.
+// It goes through the same search as batches, i.e. through the hash index once that exists.
 void Reader::wordEmbeddingToBuffer(const std::string& word, float* buffer) const
 {
-    auto extractResult = compressedStorage_->extract(word, buffer);
-    if (!extractResult) {
-        std::fill(buffer, buffer + dim(), 0);
-    }
+    const char* pointer = word.c_str();
+    uint32_t row = MEMB_HIP_MISSING_ROW;
+    resolveRows(&pointer, 1, &row);
+    compressedStorage_->decodeRows(&row, 1, buffer, dim(), 0);
 }
 
 // The search half of the reference's batch driver (src/reader.cpp:59-86): the
@@ -167,7 +168,8 @@ void Reader::resolveRows(const char* const* words, size_t count, uint32_t* rows)
     const bool useIndex = count >= INDEX_THRESHOLD || storage->hasWordIndex() ||
         wordsResolved_.fetch_add(count, std::memory_order_relaxed) + count >= INDEX_THRESHOLD;
 
-    if (count < THREADED_DECODER_THRESHOLD || numThreads_ == 1) {
+    // (the reference goes threaded at 1024 words; here a second thread only pays from two jobs' worth on)
+    if (count < std::max(THREADED_DECODER_THRESHOLD, 2 * MIN_JOB_SIZE) || numThreads_ == 1) {
         storage->resolveMany(words, count, rows, useIndex);
         return;
     }

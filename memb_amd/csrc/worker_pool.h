@@ -58,7 +58,14 @@ public:
             remaining_ = jobs;
             error_ = nullptr;
         }
-        wake_.notify_all();
+        // wake no more threads than there are jobs (a small batch must not pay for rousing everyone)
+        if (jobs >= threads_.size()) {
+            wake_.notify_all();
+        } else {
+            for (size_t i = 0; i < jobs; ++i) {
+                wake_.notify_one();
+            }
+        }
     }
 
     // The calling thread takes jobs too, until none is left unclaimed.

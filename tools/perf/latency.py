@@ -6,7 +6,7 @@ import memb_amd
 from memb_amd import synthetic
 path,_=synthetic.cached_model(2196017,300,'trained',4)
 r=memb_amd.Reader(path); keys=r.keys(); r['x']
-for m in (1, 64, 256, 512, 513, 1024):
+for m in (1, 64, 512, 513, 1024, 2048, 4096, 8192, 20000):
     words=keys[1000:1000+m]
     for _ in range(200): r[words] if m>1 else r[words[0]]
     t=time.perf_counter()

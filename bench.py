@@ -7,16 +7,30 @@ A step is one pass of the hot path over one batch: every word of a synthetic
 GloVe-840B-shaped model (2,196,017 words x 300, trained 4-bit) is looked up
 once, row ids and the fp32 output resident in HBM (BASELINE.json north_star:
 ">= 50 % of HBM bandwidth on a 2.2M-word x 300-dim 4-bit batch lookup").
-With N > 1 (one process per GPU, launched by torch.distributed.run) every rank
-holds a replica of the model and looks up its own full-size batch -- shards of
-a vocabulary N times as large -- with no collective on the data path (weak
-scaling); value = words all ranks decoded / max-over-ranks time.
+
+N > 1: one process per GPU. Started by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) the script is a rank; started plainly as `python bench.py --gpus N` it first
+spawns those N ranks as child processes -- before it makes any GPU call itself -- and relays
+rank 0's line. Every rank holds a replica of the model; there is no collective on the data
+path. Two measurements:
+  * the main line (`scaling: weak`): every rank looks up its own full-size batch -- shards of a
+    vocabulary N times as large; value = words all ranks decoded / max-over-ranks time;
+  * `strong_scaling`: BASELINE.json configs[3], ONE 2,196,017-word 2-bit dump split N ways as
+    memb_amd.sharding.shard_range does (the reference's own split, src/reader.cpp:65-79), per-rank
+    kernel time, kernel-only and with the D2H copy of each rank's slice into pinned host memory.
+    `--scaling strong` makes that split the main line instead.
+
+At N = 1 the line also carries `configs`: every configuration of BASELINE.json measured in this
+run (outside the timed region), each with its kernel time, algorithmic bytes, fraction of the HBM
+peak and a sampled bit-compare against the CPU checker.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,15 +40,19 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy on MI355X (same guide)
+GLOVE_WORDS = 2196017
+FASTTEXT_WORDS = 1999995
+MISSING = 0xFFFFFFFF
 
 WORKLOADS = {
     # name: (words, bits, batch) ; batch None = every key (full dump)
-    'glove840b-300d-4bit-fullvocab': (2196017, 4, None),     # north-star headline (SURVEY 8d "H")
-    'glove840b-300d-4bit-100k': (2196017, 4, 100000),        # BASELINE.json configs[1]
-    'fasttext2m-300d-6bit-fullvocab': (1999995, 6, None),    # BASELINE.json configs[2]
-    'glove840b-300d-2bit-fullvocab': (2196017, 2, None),     # BASELINE.json configs[3] (per GPU)
-    'small-4bit': (50000, 4, None),                          # quick functional run
+    'glove840b-300d-4bit-fullvocab': (GLOVE_WORDS, 4, None),     # north-star headline (SURVEY 8d "H")
+    'glove840b-300d-4bit-100k': (GLOVE_WORDS, 4, 100000),        # BASELINE.json configs[1]
+    'fasttext2m-300d-6bit-fullvocab': (FASTTEXT_WORDS, 6, None),  # BASELINE.json configs[2]
+    'glove840b-300d-2bit-fullvocab': (GLOVE_WORDS, 2, None),     # BASELINE.json configs[3]
+    'small-4bit': (50000, 4, None),                              # quick functional run
 }
+STRONG_WORKLOAD = 'glove840b-300d-2bit-fullvocab'
 
 
 def parse_args():
@@ -43,11 +61,104 @@ def parse_args():
     parser.add_argument('--steps', type=int, default=20)
     parser.add_argument('--warmup', type=int, default=5)
     parser.add_argument('--workload', default='glove840b-300d-4bit-fullvocab', choices=sorted(WORKLOADS))
+    parser.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                        help='strong: the main line is ONE batch split over the ranks (default workload then: configs[3])')
     parser.add_argument('--cache-dir', default=os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench'))
     parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--secondary', action='store_true',
-                        help='also time the 100k-row batch of configs[1] (extra launches of the same kernel)')
+    parser.add_argument('--no-configs', action='store_true',
+                        help='skip the per-configuration array and the strong-scaling leg (profiling runs: only the timed kernel)')
+    parser.add_argument('--small', action='store_true', help='shrink every model to 50 000 words (plumbing rehearsal)')
     return parser.parse_args()
+
+
+# --------------------------------------------------------------------------------------------
+# launching the ranks
+# --------------------------------------------------------------------------------------------
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process.
+
+    This parent makes no GPU call (it builds the native code, which needs none, and counts devices,
+    which does not initialise the runtime), so nothing that has touched the GPU is ever replaced by
+    another program; the ranks are ordinary child processes and their output passes through."""
+    import socket
+    import build_native
+    build_native.build_all()
+    rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
+    if not rehearsal:
+        import torch
+        available = torch.cuda.device_count()
+        if available < args.gpus:
+            raise SystemExit('--gpus {}: this node has {} HIP device(s)'.format(args.gpus, available))
+    with socket.socket() as probe:
+        probe.bind(('127.0.0.1', 0))
+        port = probe.getsockname()[1]
+    command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MEMB_BENCH_PREBUILT='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.run(command, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+
+class Timer:
+    """Per-launch device time from HIP events on torch's current stream (the stream the
+    kernels are enqueued on: Reader.rows_embedding_device passes it into the C ABI)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def launches(self, call, count, warmup=3):
+        torch = self.torch
+        for _ in range(warmup):
+            call()
+        torch.cuda.synchronize()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+        for begin, end in events:
+            begin.record()
+            call()
+            end.record()
+        torch.cuda.synchronize()
+        return sorted(begin.elapsed_time(end) for begin, end in events)
+
+
+def algorithmic_bytes(library, reader, rows_host):
+    """per word the row id, the index entry, the compressed payload and the fp32 row."""
+    import numpy as np
+    rows_host = np.ascontiguousarray(rows_host, dtype=np.uint32)
+    total = ctypes.c_uint64(0)
+    status = library.memb_hip_algorithmic_bytes(
+        ctypes.c_void_p(reader._impl.context_handle()), rows_host.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_size_t(len(rows_host)), ctypes.byref(total))
+    if status != 0:
+        raise RuntimeError('memb_hip_algorithmic_bytes failed')
+    return total.value
+
+
+def sampled_parity(path, rows_host, got_rows, sample=20000, seed=5):
+    """Bit-compare `sample` rows of a device result (a callable index array -> numpy rows) with the CPU checker."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(seed)
+    count = len(rows_host)
+    picks = np.sort(rng.choice(count, size=min(sample, count), replace=False))
+    expected = oracle.OracleReader(path, os.cpu_count() or 1).rows_embedding(np.ascontiguousarray(rows_host[picks]))
+    got = got_rows(picks)
+    same = np.array_equal(np.ascontiguousarray(got).view(np.uint32), expected.view(np.uint32))
+    return ('bit-exact ({} sampled rows)'.format(len(picks))) if same else 'MISMATCH'
+
+
+def batch_rows(count, batch, np):
+    if batch is None:
+        return np.arange(count, dtype=np.uint32)   # batch = keys(): rows in sorted-word order
+    rng = np.random.default_rng(11)
+    rows = rng.integers(0, count, size=batch).astype(np.uint32)
+    rows[rng.integers(0, batch, size=batch // 100)] = MISSING   # 1 % misses
+    return rows
 
 
 def cpu_baseline(path, rows_host, dim):
@@ -101,8 +212,9 @@ def cpu_baseline(path, rows_host, dim):
 
 
 def host_api_timings(reader, path, rows_host):
-    """reader[words] -> numpy for the whole batch and for 100 000 of its words, best of 3; and the CPU
-    restatement's Reader.batch_embedding (word search + decode, all host threads) on the 100 000."""
+    """reader[words] -> numpy for the whole batch and for 100 000 of its words, best of 3, with the
+    stages of the whole-batch call timed one by one; and the CPU restatement's Reader.batch_embedding
+    (word search + decode, all host threads) on the 100 000."""
     import numpy as np
     import oracle
     keys = reader.keys()
@@ -121,6 +233,14 @@ def host_api_timings(reader, path, rows_host):
 
     whole = best_of(lambda: reader.batch_embedding(words))
     part = best_of(lambda: reader.batch_embedding(sample))
+    # the stages of the whole-batch call, each on its own
+    search = best_of(lambda: reader.resolve_rows(words))
+    resolved = reader.resolve_rows(words)
+    fresh = best_of(lambda: reader.rows_embedding(resolved))
+    reused = np.empty((len(words), reader.dim), dtype=np.float32)
+    reused[:] = 0   # pages touched
+    into = best_of(lambda: reader.rows_embedding_into(resolved, reused))
+    del reused
     checker = oracle.OracleReader(path, os.cpu_count() or 1)
     cpu_part = best_of(lambda: checker.batch_embedding(sample))
     return {
@@ -128,6 +248,12 @@ def host_api_timings(reader, path, rows_host):
         'batch_words': len(words),
         'batch_seconds': whole,
         'batch_embeddings_per_s': len(words) / whole,
+        'batch_breakdown_seconds': {
+            'word_search (resolve_rows, host threads)': search,
+            'rows -> fresh numpy result (kernel, PCIe, host expansion, first touch of the result pages)': fresh,
+            'rows -> reused, already touched result': into,
+            'first touch of the result pages (difference of the two)': fresh - into,
+        },
         'sample_words': len(sample),
         'sample_seconds': part,
         'sample_embeddings_per_s': len(sample) / part,
@@ -136,22 +262,246 @@ def host_api_timings(reader, path, rows_host):
     }
 
 
+def open_reader(memb_amd, path, device):
+    start = time.time()
+    reader = memb_amd.Reader(path, device=device)
+    info = reader.info()   # stages the model to HBM
+    return reader, info, time.time() - start
+
+
+# --------------------------------------------------------------------------------------------
+# one configuration of BASELINE.json: kernel time, algorithmic bytes, parity sample
+# --------------------------------------------------------------------------------------------
+
+def measure_config(name, what, reader, path, rows_host, timer, library, torch, np, launches=15):
+    rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
+    out = torch.empty((len(rows_host), reader.dim), dtype=torch.float32, device='cuda')
+    ms = timer.launches(lambda: reader.rows_embedding_device(rows, out=out), launches)
+    median = ms[len(ms) // 2]
+    nbytes = algorithmic_bytes(library, reader, rows_host)
+    parity = sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy())
+    info = reader.info()
+    result = {
+        'workload': name,
+        'what': what,
+        'batch': len(rows_host),
+        'kernel': info.get('kernel', ''),
+        'kernel_ms': median,
+        'kernel_min_ms': ms[0],
+        'embeddings_per_s': len(rows_host) / (median * 1e-3),
+        'algorithmic_bytes': nbytes,
+        'algorithmic_GBps': nbytes / (median * 1e-3) / 1e9,
+        'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        'parity': parity,
+    }
+    del rows, out
+    return result
+
+
+def measure_union(reader_a, path_a, reader_b, path_b, timer, library, torch, np, batch=500000, launches=15):
+    """BASELINE.json configs[4]: ReadersUnion 'concatenate' of two 4-bit models, 500 000 words, (n, 600) output;
+    a quarter of the words is missing from each model (so about half of the words are known to both)."""
+    import oracle
+    from memb_amd import _memb
+    rng = np.random.default_rng(17)
+    rows_a = rng.integers(0, len(reader_a), size=batch).astype(np.uint32)
+    rows_a[rng.random(batch) < 0.25] = MISSING
+    rows_b = rng.integers(0, len(reader_b), size=batch).astype(np.uint32)
+    rows_b[rng.random(batch) < 0.25] = MISSING
+    ids = [torch.from_numpy(rows_a.view(np.int32)).cuda(), torch.from_numpy(rows_b.view(np.int32)).cuda()]
+    width = reader_a.dim + reader_b.dim
+    merged = torch.empty((batch, width), dtype=torch.float32, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fused():
+        return _memb.union_rows_to_device(
+            [reader_a._impl, reader_b._impl], [ids[0].data_ptr(), ids[1].data_ptr()], [0, reader_a.dim], batch,
+            merged.data_ptr(), merged.stride(0), stream, False)
+
+    def per_reader():   # models of different key formats cannot share the kernel: one launch per column block
+        reader_a.rows_embedding_device(ids[0], out=merged, col_off=0)
+        reader_b.rows_embedding_device(ids[1], out=merged, col_off=reader_a.dim)
+
+    one_launch = bool(fused())
+    ms = timer.launches(fused if one_launch else per_reader, launches)
+    median = ms[len(ms) // 2]
+    nbytes = algorithmic_bytes(library, reader_a, rows_a) + algorithmic_bytes(library, reader_b, rows_b) - 4 * batch
+    picks = np.sort(rng.choice(batch, size=20000, replace=False))
+    cores = os.cpu_count() or 1
+    expected = np.concatenate([
+        oracle.OracleReader(path_a, cores).rows_embedding(np.ascontiguousarray(rows_a[picks])),
+        oracle.OracleReader(path_b, cores).rows_embedding(np.ascontiguousarray(rows_b[picks]))], axis=-1)
+    got = merged[torch.from_numpy(picks).cuda()].cpu().numpy()
+    parity = 'bit-exact (20000 sampled rows)' if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
+    return {
+        'workload': 'union-concat-glove4bit+fasttext4bit-500k (BASELINE.json configs[4])',
+        'what': 'ReadersUnion concatenate, two 4-bit models, 500 000 words, 25 % of them missing per model, (n, 600) fp32 output, ' +
+                ('one decode_trained_union launch' if one_launch else 'one launch per reader (key formats differ)'),
+        'batch': batch,
+        'kernel': 'decode_trained_union' if one_launch else 'decode_trained x 2',
+        'kernel_ms': median,
+        'kernel_min_ms': ms[0],
+        'embeddings_per_s': batch / (median * 1e-3),
+        'algorithmic_bytes': nbytes,
+        'algorithmic_GBps': nbytes / (median * 1e-3) / 1e9,
+        'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        'parity': parity,
+    }
+
+
+def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, sizes):
+    """Every BASELINE.json configuration, measured on cuda:0 outside the timed region."""
+    glove, fasttext = sizes
+    reader4, path4 = headline
+    results = []
+    build_seconds = 0.0
+
+    # configs[0]: 1k-word uniform 8-bit (the reference's CPU-runnable plumbing case), here through the HIP path
+    path, spent = synthetic.cached_model(1000, 300, 'uniform', 8)
+    build_seconds += spent
+    reader = memb_amd.Reader(path, device=0)
+    rows = np.concatenate([np.arange(1000, dtype=np.uint32), np.full(100, MISSING, dtype=np.uint32)])
+    results.append(measure_config(
+        'uniform-8bit-1k (BASELINE.json configs[0])', '1 000-word uniform 8-bit model, all keys + 10 % misses; 7 us of kernel: launch latency, not bandwidth',
+        reader, path, rows, timer, library, torch, np))
+    del reader
+
+    rows = batch_rows(len(reader4), 100000, np)
+    results.append(measure_config(
+        'glove840b-300d-4bit-100k (BASELINE.json configs[1])', '100 000 uniformly random rows of the 2.2 M-word 4-bit model, 1 % misses',
+        reader4, path4, rows, timer, library, torch, np, launches=30))
+
+    path, spent = synthetic.cached_model(fasttext, 300, 'trained', 6)
+    build_seconds += spent
+    reader = memb_amd.Reader(path, device=0)
+    results.append(measure_config(
+        'fasttext2m-300d-6bit-fullvocab (BASELINE.json configs[2])', 'full dump of a 2.0 M-word 6-bit model (byte keys, codes up to 10 bits)',
+        reader, path, np.arange(len(reader), dtype=np.uint32), timer, library, torch, np))
+    del reader
+
+    path, spent = synthetic.cached_model(glove, 300, 'trained', 2)
+    build_seconds += spent
+    reader = memb_amd.Reader(path, device=0)
+    results.append(measure_config(
+        'glove840b-300d-2bit-fullvocab (BASELINE.json configs[3], one GPU\'s view: the whole dump)', 'full dump of the 2.2 M-word 2-bit model on one GPU',
+        reader, path, np.arange(len(reader), dtype=np.uint32), timer, library, torch, np))
+    del reader
+
+    path, spent = synthetic.cached_model(fasttext, 300, 'trained', 4, seed=4321)
+    build_seconds += spent
+    reader = memb_amd.Reader(path, device=0)
+    results.append(measure_union(reader4, path4, reader, path, timer, library, torch, np,
+                                 batch=min(500000, len(reader4))))
+    del reader
+
+    count = min(500000, glove)
+    path, spent = synthetic.cached_model(count, 300, 'uniform', 8)
+    build_seconds += spent
+    reader = memb_amd.Reader(path, device=0)
+    results.append(measure_config(
+        'uniform-8bit-500k', 'full dump of a 500 000-word uniform 8-bit model (bit-exact dequantisation, four IEEE fp32 operations per weight)',
+        reader, path, np.arange(len(reader), dtype=np.uint32), timer, library, torch, np))
+    del reader
+    return results, build_seconds
+
+
+# --------------------------------------------------------------------------------------------
+# strong scaling: ONE dump split over the ranks
+# --------------------------------------------------------------------------------------------
+
+def strong_scaling(args, memb_amd, synthetic, rank, world_size, local_rank, dist, torch, np, library, words, bits, name):
+    from memb_amd.sharding import shard_range
+    distributed = world_size > 1
+    build_seconds = 0.0
+    if rank == 0:
+        path, build_seconds = synthetic.cached_model(words, 300, 'trained', bits)
+    if distributed:
+        dist.barrier()
+    path, _ = synthetic.cached_model(words, 300, 'trained', bits)
+    reader, info, _ = open_reader(memb_amd, path, local_rank)
+    count = len(reader)
+    start, stop = shard_range(count, rank, world_size)   # the reference's thread split, src/reader.cpp:65-79
+    mine = np.arange(start, stop, dtype=np.uint32)
+    rows = torch.from_numpy(mine.view(np.int32)).cuda()
+    out = torch.empty((len(mine), reader.dim), dtype=torch.float32, device='cuda')
+    host = torch.empty((len(mine), reader.dim), dtype=torch.float32, pin_memory=True)
+    steps = args.steps
+
+    def timed(call):
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        begin = time.perf_counter()
+        for _ in range(steps):
+            call()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - begin
+        if distributed:
+            slowest = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+            elapsed = float(slowest.item())
+        return elapsed
+
+    def kernel_only():
+        reader.rows_embedding_device(rows, out=out)
+
+    def with_d2h():
+        reader.rows_embedding_device(rows, out=out)
+        host.copy_(out, non_blocking=True)
+
+    elapsed_kernel = timed(kernel_only)
+    kernel_ms = Timer(torch).launches(kernel_only, steps)
+    elapsed_d2h = timed(with_d2h)
+    nbytes = algorithmic_bytes(library, reader, mine)
+    parity = sampled_parity(path, mine, lambda picks: host[torch.from_numpy(picks)].numpy(), sample=5000)
+    mine_summary = {
+        'rank': rank, 'device': local_rank, 'rows': [int(start), int(stop)],
+        'kernel_avg_ms': sum(kernel_ms) / len(kernel_ms), 'kernel_min_ms': kernel_ms[0],
+        'algorithmic_GBps': nbytes / (sum(kernel_ms) / len(kernel_ms) * 1e-3) / 1e9, 'parity': parity,
+    }
+    if distributed:
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, mine_summary)
+    else:
+        gathered = [mine_summary]
+    del reader, rows, out, host
+    return {
+        'workload': name + ' (BASELINE.json configs[3])',
+        'what': 'ONE {}-word {}-bit dump split over {} rank(s), rank g decodes rows [g*ceil(n/G), (g+1)*ceil(n/G)) into its own device buffer; no collective'.format(count, bits, world_size),
+        'scaling': 'strong',
+        'n_gpus': world_size,
+        'ranks_seen': len(gathered),
+        'steps': steps,
+        'kernel_only': {'value': count * steps / elapsed_kernel, 'unit': 'embeddings/s', 'ms_per_step': elapsed_kernel / steps * 1e3},
+        'with_d2h': {'value': count * steps / elapsed_d2h, 'unit': 'embeddings/s', 'ms_per_step': elapsed_d2h / steps * 1e3,
+                     'note': 'each rank also copies its slice of the fp32 result into its own pinned host buffer (PCIe-bound); the disjoint slices of those buffers are the host-side gather'},
+        'per_rank': gathered,
+    }, build_seconds
+
+
+# --------------------------------------------------------------------------------------------
+
 def main():
     args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit('--gpus {} needs torch.distributed.run with one process per GPU'.format(args.gpus))
-        args.gpus = world_size
+    args.gpus = world_size
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import __graft_entry__
-    if rank == 0:
+    if rank == 0 and os.environ.get('MEMB_BENCH_PREBUILT') != '1':
         __graft_entry__.build()
     distributed = world_size > 1
     # Rehearsal of the multi-rank plumbing on a one-GPU box: MEMB_BENCH_REHEARSAL=1 puts every rank on
@@ -168,9 +518,17 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         dist.barrier()
     import memb_amd
-
-    words, bits, batch = WORKLOADS[args.workload]
     from memb_amd import synthetic
+    from memb_amd.sharding import shard_range
+
+    strong_main = args.scaling == 'strong'
+    workload = args.workload
+    if strong_main and workload == 'glove840b-300d-4bit-fullvocab':
+        workload = STRONG_WORKLOAD
+    words, bits, batch = WORKLOADS[workload]
+    glove, fasttext = GLOVE_WORDS, FASTTEXT_WORDS
+    if args.small:
+        words, glove, fasttext = min(words, 50000), 50000, 49999
     os.environ['MEMB_BENCH_CACHE'] = args.cache_dir
     build_seconds = 0.0
     if rank == 0:
@@ -179,29 +537,20 @@ def main():
         dist.barrier()
     path, _ = synthetic.cached_model(words, 300, 'trained', bits)
 
-    open_start = time.time()
-    reader = memb_amd.Reader(path, device=local_rank)
-    info = reader.info()   # stages the model to HBM
-    open_seconds = time.time() - open_start
+    reader, info, open_seconds = open_reader(memb_amd, path, local_rank)
     dim = reader.dim
     count = len(reader)
-
-    if batch is None:
-        rows_host = np.arange(count, dtype=np.uint32)   # batch = keys(): rows in sorted-word order
-    else:
-        rng = np.random.default_rng(11)
-        rows_host = rng.integers(0, count, size=batch).astype(np.uint32)
-        rows_host[rng.integers(0, batch, size=batch // 100)] = 0xFFFFFFFF   # 1 % misses
-    n = len(rows_host)
-
-    import ctypes
     library = ctypes.CDLL(memb_amd.HIP_LIBRARY_PATH)
-    algorithmic = ctypes.c_uint64(0)
-    library.memb_hip_algorithmic_bytes(
-        ctypes.c_void_p(reader._impl.context_handle()), rows_host.ctypes.data_as(ctypes.c_void_p),
-        ctypes.c_size_t(n), ctypes.byref(algorithmic))
-    algorithmic_bytes = algorithmic.value
+    timer = Timer(torch)
 
+    rows_all = batch_rows(count, batch, np)
+    if strong_main:
+        start, stop = shard_range(len(rows_all), rank, world_size)
+        rows_host = np.ascontiguousarray(rows_all[start:stop])
+    else:
+        rows_host = rows_all
+    n = len(rows_host)
+    nbytes = algorithmic_bytes(library, reader, rows_host)
     rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
     out = torch.empty((n, dim), dtype=torch.float32, device='cuda')
 
@@ -212,7 +561,8 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # per-launch kernel durations from HIP events on the stream the kernel runs on
+    # the timed region: exactly `steps` steps between barrier + synchronize on both sides; per-launch
+    # kernel durations from HIP events on the stream the kernel runs on
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     if distributed:
@@ -234,6 +584,20 @@ def main():
         elapsed = float(slowest.item())
     kernel_ms = sorted(starts[i].elapsed_time(stops[i]) for i in range(args.steps))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    rank_summary = {'rank': rank, 'device': local_rank, 'batch': n, 'kernel_avg_ms': kernel_avg_ms, 'kernel_min_ms': kernel_ms[0]}
+    if distributed:
+        per_rank = [None] * world_size
+        dist.all_gather_object(per_rank, rank_summary)
+    else:
+        per_rank = [rank_summary]
+
+    # BASELINE.json configs[3] split over the ranks (every rank takes part; outside the timed region)
+    strong = None
+    if not strong_main and not args.no_configs and distributed:
+        strong, spent = strong_scaling(
+            args, memb_amd, synthetic, rank, world_size, local_rank, dist, torch, np, library,
+            glove, 2, STRONG_WORKLOAD)
+        build_seconds += spent
 
     if rank != 0:
         if distributed:
@@ -241,38 +605,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # BASELINE.json configs[1] on the same model: a 100 000-row random batch with 1 % misses
-    # (rank 0 only, outside the timed region; kernel time from HIP events).
-    secondary = None
-    if batch is None and args.secondary:
-        rng = np.random.default_rng(11)
-        small_host = rng.integers(0, count, size=100000).astype(np.uint32)
-        small_host[rng.integers(0, 100000, size=1000)] = 0xFFFFFFFF
-        small_rows = torch.from_numpy(small_host.view(np.int32)).cuda()
-        small_out = torch.empty((100000, dim), dtype=torch.float32, device='cuda')
-        for _ in range(5):
-            reader.rows_embedding_device(small_rows, out=small_out)
-        torch.cuda.synchronize()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-        for begin, end in events:
-            begin.record()
-            reader.rows_embedding_device(small_rows, out=small_out)
-            end.record()
-        torch.cuda.synchronize()
-        small_ms = sorted(begin.elapsed_time(end) for begin, end in events)
-        small_bytes = ctypes.c_uint64(0)
-        library.memb_hip_algorithmic_bytes(
-            ctypes.c_void_p(reader._impl.context_handle()), small_host.ctypes.data_as(ctypes.c_void_p),
-            ctypes.c_size_t(len(small_host)), ctypes.byref(small_bytes))
-        median = small_ms[len(small_ms) // 2]
-        secondary = {
-            'workload': 'glove840b-300d-4bit-100k (BASELINE.json configs[1])',
-            'kernel_median_ms': median,
-            'embeddings_per_s': 100000 / (median * 1e-3),
-            'algorithmic_GBps': small_bytes.value / (median * 1e-3) / 1e9,
-        }
-
-    # parity spot check of the timed output against the CPU checker, and the CPU baseline
+    # parity of the timed output against the CPU checker, and the CPU baseline
     baseline = None
     parity = 'skipped'
     # (the CPU legs run at N = 1 only: with more ranks the others would wait at the final barrier)
@@ -281,14 +614,10 @@ def main():
         baseline, expected = cpu_baseline(path, rows_host, dim)
         got = out.cpu().numpy()
         parity = 'bit-exact' if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
+        del expected, got
     elif not args.no_cpu_baseline:
-        # N > 1: no timed CPU leg, but rank 0's output is still checked on a sample of the batch
-        import oracle
-        sample = min(n, 20000)
-        expected = oracle.OracleReader(path, os.cpu_count() or 1).rows_embedding(rows_host[:sample])
-        got = out[:sample].cpu().numpy()
-        parity = ('bit-exact (first {} rows)'.format(sample)
-                  if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH')
+        # N > 1: no timed CPU leg, but rank 0's output is still checked on a sample of its batch
+        parity = sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy())
 
     # Not part of `value`: what a caller of the reference's API sees (words in, numpy out; word search,
     # PCIe and host memory included), next to the restated CPU Reader on the same words and host cores.
@@ -296,34 +625,46 @@ def main():
     if cpu_legs:
         host_api = host_api_timings(reader, path, rows_host)
 
-    achieved_gbps = algorithmic_bytes / (kernel_avg_ms * 1e-3) / 1e9
-    traffic = None
-    traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(traffic_file):
-        with open(traffic_file) as f:
-            traffic = json.load(f).get(args.workload)
+    configs = None
+    if world_size == 1 and not args.no_configs:
+        del out, rows
+        configs, spent = all_configs(args, memb_amd, synthetic, (reader, path), timer, library, torch, np, (glove, fasttext))
+        build_seconds += spent
 
+    achieved_gbps = nbytes / (kernel_avg_ms * 1e-3) / 1e9
+    traffic = None
+    traffic_source = None
+    traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(traffic_file) and not strong_main:
+        with open(traffic_file) as f:
+            recorded = json.load(f)
+        traffic = recorded.get(workload)
+        if traffic is not None:
+            traffic_source = 'static: profiles/hbm_traffic.json ({})'.format(recorded.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/perf/traffic.sh'))
+
+    total_words = sum(entry['batch'] for entry in per_rank)
     result = {
         'metric': 'embeddings/sec (and HBM GB/s vs roofline), 300-dim {}-bit batch lookup'.format(bits),
-        'value': args.gpus * n * args.steps / elapsed,
+        'value': total_words * args.steps / elapsed,
         'unit': 'embeddings/s',
         'n_gpus': args.gpus,
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if strong_main else 'weak',
         'vs_baseline': None,
         'dtype': 'u32',
         'data': 'synthetic',
         'config': {
-            'workload': args.workload,
+            'workload': workload,
             'vocabulary': count,
             'dim': dim,
             'storage': 'trained',
             'bits_per_weight': bits,
             'batch_per_gpu': n,
-            'batch': 'keys() full dump' if batch is None else 'uniform random rows, 1% misses, seed 11',
+            'batch': ('keys() full dump' if batch is None else 'uniform random rows, 1% misses, seed 11') +
+                     (', ONE batch split over the ranks as sharding.shard_range does' if strong_main else ''),
             'vectors': 'N(0, 0.4^2) seed 1234, written by memb_amd.Builder',
             'parallelism': 'batch shards, model replicated per GPU, no collective',
         },
@@ -334,18 +675,25 @@ def main():
             'unit': 'GB/s',
             'frac': achieved_gbps / HBM_PEAK_GBPS,
             'traffic': traffic,
-            'kernel': 'decode_trained_persistent',
+            'traffic_source': traffic_source,
+            'kernel': info.get('kernel', 'decode_trained_persistent'),
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_min_ms': kernel_ms[0],
-            'algorithmic_bytes_per_launch': algorithmic_bytes,
-            'algorithmic_bytes_per_word': algorithmic_bytes / n,
+            'kernel_median_ms': kernel_ms[len(kernel_ms) // 2],
+            'kernel_ms_in_launch_order': [round(starts[i].elapsed_time(stops[i]), 4) for i in range(args.steps)],
+            'algorithmic_bytes_per_launch': nbytes,
+            'algorithmic_bytes_per_word': nbytes / max(n, 1),
             'frac_of_copy_ceiling': achieved_gbps / HBM_COPY_CEILING_GBPS,
+            'rank': 0,
         },
         'cpu_baseline': baseline,
         'parity_vs_cpu_checker': parity,
+        'ranks_seen': len(per_rank),
+        'per_rank': per_rank,
+        'strong_scaling': strong,
+        'configs': configs,
         'host_api': host_api,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
-        'secondary': secondary,
         'geometry': {k: info[k] for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
                                           'max_code_bits', 'max_stream_bytes', 'device_bytes')},
         'model_build_s': build_seconds,

@@ -116,6 +116,7 @@ typedef struct memb_hip_ctx_info {
     uint32_t lanes_per_word;     /* trained: lanes that decode one word side by side */
     uint32_t segment_symbols;    /* trained: symbols decoded by each of those lanes */
     uint32_t lds_bytes_per_block;
+    char kernel[96];             /* the kernel a dense device-resident batch runs, spelled as rocprofv3 prints it */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);

@@ -100,10 +100,46 @@ py::dict contextInfo(memb::Reader& reader)
     result["lanes_per_word"] = info.lanes_per_word;
     result["segment_symbols"] = info.segment_symbols;
     result["lds_bytes_per_block"] = info.lds_bytes_per_block;
+    result["kernel"] = std::string(info.kernel);
     return result;
 }
 
 }  // namespace
+
+// The caller's output matrix for the *_into calls, used in place: float32, writeable, two-dimensional,
+// unit column stride; rows may be strided (a column or row range of a wider matrix). Anything
+// else is refused -- letting pybind11 convert it would fill a temporary copy and leave the
+// caller's matrix untouched without a word.
+struct OutputMatrix {
+    float* data;
+    size_t rows;
+    size_t columns;
+    size_t ld;   // floats between the starts of consecutive rows
+};
+
+OutputMatrix outputMatrix(const py::array& out)
+{
+    if (!py::isinstance<py::array_t<float>>(out) || !py::dtype::of<float>().is(out.dtype())) {
+        throw py::type_error("out must be a numpy float32 array (no conversion is made: the result is written in place)");
+    }
+    if (!out.writeable()) {
+        throw py::type_error("out is read-only");
+    }
+    if (out.ndim() != 2) {
+        throw py::type_error("out must be 2-dimensional");
+    }
+    const py::ssize_t item = static_cast<py::ssize_t>(sizeof(float));
+    if ((out.shape(1) > 1 && out.strides(1) != item) || out.strides(0) < 0 || out.strides(0) % item != 0 ||
+        (out.shape(0) > 1 && out.strides(0) < out.shape(1) * item)) {
+        throw py::type_error("out must have unit column stride and non-overlapping rows (row slices and column ranges of a C-contiguous matrix are fine)");
+    }
+    OutputMatrix matrix;
+    matrix.data = static_cast<float*>(const_cast<void*>(out.data()));
+    matrix.rows = static_cast<size_t>(out.shape(0));
+    matrix.columns = static_cast<size_t>(out.shape(1));
+    matrix.ld = out.shape(0) > 1 ? static_cast<size_t>(out.strides(0) / item) : matrix.columns;
+    return matrix;
+}
 
 PYBIND11_MODULE(_memb, m) {
     py::class_<memb::Builder>(m, "Builder")
@@ -205,19 +241,16 @@ PYBIND11_MODULE(_memb, m) {
             "batch_embedding_into",
             [](memb::Reader& reader,
                const py::sequence& wordList,
-               py::array_t<float, py::array::c_style> out,
+               const py::array& out,
                size_t colOff)
             {
                 WordPointers words(wordList);
-                auto buffer = out.request(true);
-                if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size() ||
-                    static_cast<size_t>(buffer.shape[1]) < colOff + reader.dim()) {
+                const OutputMatrix matrix = outputMatrix(out);
+                if (matrix.rows != words.size() || matrix.columns < colOff + reader.dim()) {
                     throw std::runtime_error("Output must be a (len(words), >= col_off + dim) float32 matrix");
                 }
-                float* destination = reinterpret_cast<float*>(buffer.ptr);
-                size_t ld = static_cast<size_t>(buffer.shape[1]);
                 py::gil_scoped_release release;
-                reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, ld, colOff);
+                reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), matrix.data, matrix.ld, colOff);
             })
         .def(
             "rows_embedding",
@@ -243,21 +276,19 @@ PYBIND11_MODULE(_memb, m) {
             "rows_embedding_into",
             [](memb::Reader& reader,
                py::array_t<uint32_t, py::array::c_style | py::array::forcecast> rows,
-               py::array_t<float, py::array::c_style> out,
+               const py::array& out,
                size_t colOff)
             {
                 auto rowsBuffer = rows.request();
-                auto buffer = out.request(true);
-                if (rowsBuffer.ndim != 1 || buffer.ndim != 2 || buffer.shape[0] != rowsBuffer.shape[0] ||
-                    static_cast<size_t>(buffer.shape[1]) < colOff + reader.dim()) {
+                const OutputMatrix matrix = outputMatrix(out);
+                if (rowsBuffer.ndim != 1 || matrix.rows != static_cast<size_t>(rowsBuffer.shape[0]) ||
+                    matrix.columns < colOff + reader.dim()) {
                     throw std::runtime_error("Output must be a (len(rows), >= col_off + dim) float32 matrix");
                 }
                 const uint32_t* source = reinterpret_cast<const uint32_t*>(rowsBuffer.ptr);
-                float* destination = reinterpret_cast<float*>(buffer.ptr);
-                const size_t n = static_cast<size_t>(rowsBuffer.shape[0]);
-                const size_t ld = static_cast<size_t>(buffer.shape[1]);
+                const size_t n = matrix.rows;
                 py::gil_scoped_release release;
-                reader.rowsToBuffer(source, n, destination, ld, colOff);
+                reader.rowsToBuffer(source, n, matrix.data, matrix.ld, colOff);
             },
             py::arg("rows"),
             py::arg("out"),

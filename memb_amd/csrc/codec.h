@@ -61,6 +61,11 @@ inline std::vector<PrefixCode> canonicalCodes(const std::vector<CodeInfo>& codeL
         }
         code <<= (info.length - bits);
         bits = info.length;
+        // an over-subscribed description (lengths that break the Kraft inequality) runs out of
+        // codes of this length: the next one would need bits + 1 bits
+        if (bits < 32 && (code >> bits) != 0) {
+            throw std::runtime_error("Huffman code lengths describe no prefix code");
+        }
         codes.push_back({code, bits});
         ++code;
     }
@@ -116,6 +121,9 @@ inline DecodeTable buildDecodeTable(const std::vector<CodeInfo>& codeLengths, ui
     for (size_t i = 0; i < codes.size(); ++i) {
         if (codes[i].bitsCount > rootBits) {
             uint32_t prefix = codes[i].code >> (codes[i].bitsCount - rootBits);
+            if (prefix >= rootSize) {
+                throw std::runtime_error("Huffman code does not fit its table");
+            }
             prefixMaxBits[prefix] = std::max(prefixMaxBits[prefix], codes[i].bitsCount);
         }
     }

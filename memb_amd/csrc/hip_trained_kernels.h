@@ -8,6 +8,8 @@
 // decode_trained
 // ---------------------------------------------------------------------------
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain SSA value (HIP's uint4 is a class)
+
 struct TrainedParams {
     const uint32_t* rows;        // batch -> row id; null = identity (row = batch position)
     float* out;
@@ -87,7 +89,7 @@ __device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned
     if (role.spare || index >= p.n) {
         return MISSING;
     }
-    return p.rows ? p.rows[index] : static_cast<uint32_t>(index);
+    return p.rows && !(p.debugFlags & 4) ? p.rows[index] : static_cast<uint32_t>(index);
 }
 
 constexpr uint32_t ROW_META_BITS = 13;        // a segment offset inside a rowMeta record: streams below 1 KiB
@@ -110,8 +112,12 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     meta.segmentBits = 0;
     meta.packed2 = 0;
     meta.packed3 = 0;
+    if (p.debugFlags & 4) {
+        return meta;
+    }
     if (row < p.nRows && p.rowMeta) {
-        const uint4 record = reinterpret_cast<const uint4*>(p.rowMeta)[row];
+        const u32x4* source = reinterpret_cast<const u32x4*>(p.rowMeta) + row;
+        const u32x4 record = (p.debugFlags & 0x200) ? __builtin_nontemporal_load(source) : *source;
         meta.start = record.x;
         meta.segmentBits = record.y;
         meta.packed2 = record.z;
@@ -150,7 +156,6 @@ constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a 
 
 // Named members, not an array: indexed storage ends up in scratch memory, and a
 // load whose result goes to scratch is waited for at once, which would undo the prefetch.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain SSA value (HIP's uint4 is a class)
 
 struct StreamRegisters {
     u32x4 r0, r1, r2, r3;
@@ -166,12 +171,13 @@ __device__ __forceinline__ void issueStreamLoad(
 {
     const uint32_t piecesPerWord = p.slotDwords / 4;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-    if (round * WAVE < totalPieces) {   // wave-uniform
+    if (round * WAVE < totalPieces && !(p.debugFlags & 4)) {   // wave-uniform
         const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
         const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
         const uint32_t piece = q - w * piecesPerWord;
         const uint32_t wordStart = __shfl(sourceStart, w * p.lanesPerWord);
-        destination = reinterpret_cast<const u32x4*>(p.streams)[static_cast<unsigned long long>(wordStart) + piece];
+        const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
+        destination = (p.debugFlags & 0x100) ? __builtin_nontemporal_load(source) : *source;
     }
 }
 
@@ -300,11 +306,43 @@ __device__ __forceinline__ void decodeSegment(
     }
 }
 
+// Measurement switches carried in TrainedParams::debugFlags (MEMB_HIP_DEBUG):
+//   bit 0 skip decode, bit 1 skip output, bit 2 skip the row id / rowMeta / bitstream loads (the
+//   decoder then chews on whatever LDS holds: output values are garbage, the access pattern is kept),
+//   bits 4..6 cache policy of the output stores as a mask (16 = sc0, 32 = sc1, 64 = nt),
+//   bit 7 that policy only for tiles whose rows are consecutive, bits 10..12 the mask of the other tiles,
+//   bit 8 non-temporal bitstream loads, bit 9 non-temporal rowMeta loads.
+__device__ __forceinline__ void storeOutput16(float* destination, const float4& value, uint32_t policy)
+{
+    if (policy == 0) {
+        *reinterpret_cast<float4*>(destination) = value;
+        return;
+    }
+    u32x4 bits;
+    bits.x = __float_as_uint(value.x);
+    bits.y = __float_as_uint(value.y);
+    bits.z = __float_as_uint(value.z);
+    bits.w = __float_as_uint(value.w);
+    // (the s_nop keeps the next instruction from overwriting the data registers before the store has read them)
+#define MEMB_HIP_STORE16(BITS) \
+    asm volatile("global_store_dwordx4 %0, %1, off " BITS "\n\ts_nop 1" : : "v"(destination), "v"(bits) : "memory")
+    switch (policy) {
+        case 1: MEMB_HIP_STORE16("sc0"); break;
+        case 2: MEMB_HIP_STORE16("sc1"); break;
+        case 3: MEMB_HIP_STORE16("sc0 sc1"); break;
+        case 4: MEMB_HIP_STORE16("nt"); break;
+        case 5: MEMB_HIP_STORE16("sc0 nt"); break;
+        case 6: MEMB_HIP_STORE16("sc1 nt"); break;
+        default: MEMB_HIP_STORE16("sc0 sc1 nt"); break;
+    }
+#undef MEMB_HIP_STORE16
+}
+
 // Symbol tile -> fp32 rows: codebook gather and row-contiguous stores.
 template <int MODE, bool FAST>
 __device__ __forceinline__ void outputTile(
     const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
-    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
+    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present, bool sequentialTile = false)
 {
     if (MODE == OUT_KEYS) {
         // rows of a tile are dense in LDS and in the output; absent words carry whatever was
@@ -342,6 +380,10 @@ __device__ __forceinline__ void outputTile(
         absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
     }
     const bool checkWords = FAST && absent != 0;
+    uint32_t storePolicy = (p.debugFlags >> 4) & 7;   // wave-uniform
+    if (p.debugFlags & 0x80) {
+        storePolicy = sequentialTile ? storePolicy : (p.debugFlags >> 10) & 7;
+    }
 
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
         // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
@@ -392,7 +434,7 @@ __device__ __forceinline__ void outputTile(
                     if (hasEpilogue) {   // off the common path
                         f[u] = epilogue4(f[u], destination, p.accumulate, p.divisor);
                     }
-                    *reinterpret_cast<float4*>(destination) = f[u];
+                    storeOutput16(destination, f[u], storePolicy);
                 }
             }
         }
@@ -499,8 +541,14 @@ __global__ void decode_trained(TrainedParams p)
 // of tile t + 3 are on their way. Each of those hops depends on the previous
 // one (row id -> offset -> stream bytes); issued back to back they are what a
 // one-tile wavefront spends most of its life waiting for.
+#ifdef MEMB_HIP_BOUNDS_WAVES   // measurement builds: register budget for more resident wavefronts
+#define MEMB_HIP_PERSISTENT_BOUNDS __launch_bounds__(MEMB_HIP_BOUNDS_THREADS, MEMB_HIP_BOUNDS_WAVES)
+#else
+#define MEMB_HIP_PERSISTENT_BOUNDS
+#endif
+
 template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained_persistent(TrainedParams p)
+__global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -561,7 +609,11 @@ __global__ void decode_trained_persistent(TrainedParams p)
         __builtin_amdgcn_sched_barrier(0);
 
         if (!(p.debugFlags & 2)) {
-            outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta0.row < p.nRows);
+            // rows of the tile consecutive (a dump in key order, or a run of one)?
+            const uint32_t firstRow = __shfl(meta0.row, 0);
+            const bool sequentialTile = __all(role.spare || meta0.row == firstRow + role.word);
+            outputTile<MODE, FAST>(
+                p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta0.row < p.nRows, sequentialTile);
         }
         __builtin_amdgcn_sched_barrier(0);
 

@@ -737,6 +737,61 @@ int copyToDevice(void* dst, const void* src, size_t bytes)
     return MEMB_HIP_OK;
 }
 
+// Makes the context's device current for the duration of an entry point and puts the caller's
+// device back afterwards (the calling thread may belong to PyTorch, whose current device must not
+// change under it).
+class DeviceScope {
+public:
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous_) != hipSuccess) {
+            (void)hipGetLastError();
+            previous_ = -1;
+        }
+        status_ = previous_ == device ? hipSuccess : hipSetDevice(device);
+        changed_ = status_ == hipSuccess && previous_ != device;
+    }
+    ~DeviceScope()
+    {
+        if (changed_ && previous_ >= 0) {
+            (void)hipSetDevice(previous_);
+        }
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    hipError_t status() const { return status_; }
+
+private:
+    int previous_ = -1;
+    hipError_t status_ = hipSuccess;
+    bool changed_ = false;
+};
+
+// Puts the calling thread's current device back when it goes out of scope (context creation and
+// destruction switch devices as they go).
+class DeviceRestore {
+public:
+    DeviceRestore()
+    {
+        if (hipGetDevice(&previous_) != hipSuccess) {
+            (void)hipGetLastError();
+            previous_ = -1;
+        }
+    }
+    ~DeviceRestore()
+    {
+        if (previous_ >= 0) {
+            (void)hipSetDevice(previous_);
+        }
+    }
+    DeviceRestore(const DeviceRestore&) = delete;
+    DeviceRestore& operator=(const DeviceRestore&) = delete;
+
+private:
+    int previous_ = -1;
+};
+
+// (callers hold a DeviceRestore: the context's device stays current for the staging that follows)
 int openDevice(memb_hip_ctx* ctx, int device)
 {
     int count = 0;
@@ -780,6 +835,7 @@ void destroy(memb_hip_ctx* ctx)
     if (!ctx) {
         return;
     }
+    DeviceRestore restore;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -1144,6 +1200,7 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tStart = now();
+    DeviceRestore restore;
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->switches = readSwitches();
@@ -1201,6 +1258,7 @@ int ctx_create_uniform_checked(memb_hip_ctx** out, int device, const memb_hip_un
     if (desc->dim == 0 || (desc->n_rows && !desc->rows)) {
         return fail(MEMB_HIP_ERR_INVALID, "inconsistent uniform storage description");
     }
+    DeviceRestore restore;
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->switches = readSwitches();
@@ -1252,6 +1310,7 @@ int ctx_create_full_checked(memb_hip_ctx** out, int device, const memb_hip_full_
     if (desc->dim == 0 || (desc->n_rows && !desc->rows)) {
         return fail(MEMB_HIP_ERR_INVALID, "inconsistent full storage description");
     }
+    DeviceRestore restore;
     memb_hip_ctx* ctx = new memb_hip_ctx();
     ContextGuard guard(ctx);   // destroys the context unless it is handed to the caller
     ctx->switches = readSwitches();
@@ -1303,8 +1362,18 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->lanes_per_word = ctx->lanesPerWord;
         info->segment_symbols = ctx->segmentSymbols;
         info->lds_bytes_per_block = geometry.ldsBytes;
+        // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys>
+        const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+        const uint32_t streamRounds = (wordsPerWave * (ctx->slotDwords / 4) + WAVE - 1) / WAVE;
+        const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
+        std::snprintf(
+            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", persistent ? "decode_trained_persistent" : "decode_trained",
+            ctx->hostTable.hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT), ctx->fast ? "true" : "false");
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
+        std::snprintf(
+            info->kernel, sizeof(info->kernel), "%s<true>",
+            ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");
     }
     return MEMB_HIP_OK;
 }
@@ -1318,7 +1387,8 @@ int decode_rows_device_checked(
     if (ld < col_off + ctx->dim) {
         return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope deviceScope(ctx->device);
+    HIP_TRY(deviceScope.status());
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream));
 }
 
@@ -1335,7 +1405,8 @@ int decode_rows_device_ex_checked(
     if ((flags & ~uint32_t(MEMB_HIP_ACCUMULATE)) || !(divisor == divisor)) {
         return fail(MEMB_HIP_ERR_INVALID, "unknown flags or NaN divisor");
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope deviceScope(ctx->device);
+    HIP_TRY(deviceScope.status());
     Epilogue epilogue;
     epilogue.accumulate = (flags & MEMB_HIP_ACCUMULATE) ? 1u : 0u;
     epilogue.divisor = divisor;
@@ -1355,7 +1426,8 @@ int decode_rows_checked(
         return MEMB_HIP_OK;
     }
     std::lock_guard<std::mutex> lock(ctx->mutex);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope deviceScope(ctx->device);
+    HIP_TRY(deviceScope.status());
 
     // Small batches (single words above all): two tiny copies cost more than the
     // decode. Row ids and results go through one pinned, device-mapped host
@@ -1483,7 +1555,8 @@ int decode_rows_union_device_checked(
     if (n == 0) {
         return MEMB_HIP_OK;
     }
-    HIP_TRY(hipSetDevice(ctxs[0]->device));
+    DeviceScope deviceScope(ctxs[0]->device);
+    HIP_TRY(deviceScope.status());
     return launchTrainedUnion(
         ctxs, rows, col_offs, count, n, out, ld, static_cast<hipStream_t>(stream), (flags & MEMB_HIP_UNION_AVERAGE) != 0);
 }
@@ -1493,7 +1566,8 @@ int sync_checked(memb_hip_ctx* ctx)
     if (!ctx) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope deviceScope(ctx->device);
+    HIP_TRY(deviceScope.status());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MEMB_HIP_OK;
 }

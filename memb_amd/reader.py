@@ -153,6 +153,10 @@ class Reader(BaseReader):
             out = torch.empty((n, col_off + self.dim), dtype=torch.float32, device=rows.device)
         if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n:
             raise TypeError('out must be a float32 (n, width) tensor with unit column stride')
+        # the kernel runs on this reader's device with these pointers: both tensors must live there
+        if rows.device.index != self.device or out.device != rows.device:
+            raise ValueError('rows and out must be on cuda:{} (the device this reader is staged on), got {} and {}'.format(
+                self.device, rows.device, out.device))
         stream = torch.cuda.current_stream(rows.device).cuda_stream
         self._impl.rows_to_device(
             rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, stream, accumulate, float(divisor))

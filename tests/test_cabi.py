@@ -128,7 +128,12 @@ def test_malformed_trained_descriptions_are_refused_before_any_device_work(nativ
         return code, library.memb_hip_last_error().decode()
 
     INVALID = 1
-    assert create([1, 2, 3], [0, 3]) == (INVALID, 'Huffman code does not fit its table')            # three 1-bit codes
+    OVERSUBSCRIBED = (INVALID, 'Huffman code lengths describe no prefix code')
+    assert create([1, 2, 3], [0, 3]) == OVERSUBSCRIBED                                              # three 1-bit codes
+    # three 1-bit codes and a 13-bit one: the long code's first-level prefix lies past the table
+    # (a heap overflow in buildDecodeTable before the Kraft check; the CPU ASan build runs this too)
+    assert create([1, 2, 3, 4], [0, 3] + [3] * 11 + [4]) == OVERSUBSCRIBED
+    assert create([1, 2, 3, 4, 5], [0, 1, 2, 5]) == OVERSUBSCRIBED                                  # 1 + 1 + 3 codes of 1, 2, 3 bits
     assert create([1, 2, 3], [0, 2, 1, 3])[0] == INVALID                                            # counts go down
     assert create(list(range(18)), list(range(18)) + [18])[0] == INVALID                            # a 17-bit code
     assert create([1, 200], [0, 2], n_centroids=10) == (INVALID, 'Huffman symbol without a centroid')

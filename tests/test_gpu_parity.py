@@ -524,6 +524,25 @@ def test_strided_output_leaves_other_columns_alone(native, make_model):
         assert (untouched == 7.5).all()
 
 
+def test_row_strided_views_are_filled_in_place(native, make_model):
+    # column ranges and row ranges of a wider matrix are written where they are (no temporary copy)
+    path, words = make_model(20000, 300, 'trained', 4)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    batch = sorted(words)[:900] + ['zz-missing']
+    want = checker.batch_embedding(batch)
+    merged = np.full((len(batch), 640), -3.0, dtype=np.float32)
+    reader.batch_embedding_into(batch, merged[:, 320:620], 0)      # view: ld 640, 300 columns
+    assert bits_equal(merged[:, 320:620], want)
+    assert (merged[:, :320] == -3.0).all() and (merged[:, 620:] == -3.0).all()
+    rows = reader.resolve_rows(batch)
+    tall = np.full((len(batch) + 10, 300), -3.0, dtype=np.float32)
+    reader.rows_embedding_into(rows, tall[5:-5], 0)                  # row range
+    assert bits_equal(tall[5:-5], want) and (tall[:5] == -3.0).all() and (tall[-5:] == -3.0).all()
+    reader.rows_embedding_into(rows[:1], merged[:1, 10:310], 0)      # a single row of a view
+    assert bits_equal(merged[:1, 10:310], want[:1])
+
+
 def test_readers_union_concatenate_and_average(native, make_model):
     # config 5 of BASELINE.json in small: two models with overlapping keys, (n, 600) output
     path_a, words_a = make_model(20000, 300, 'trained', 4)
@@ -621,6 +640,10 @@ def test_boundary_argument_errors(native, make_model):
         reader.rows_embedding_device(rows, out=torch.empty((4, 8), device='cuda'), col_off=4)
     with pytest.raises(TypeError):
         reader.rows_embedding_device(rows.cpu())
+    if torch.cuda.device_count() > 1:   # tensors on another GPU than the reader's are refused, not decoded into
+        with pytest.raises(ValueError, match='must be on cuda:0'):
+            reader.rows_embedding_device(rows.to('cuda:1'))
+    before = torch.cuda.current_device()
     with pytest.raises(TypeError):
         reader.rows_embedding_device(rows.to(torch.int64))
     with pytest.raises(TypeError):
@@ -638,6 +661,7 @@ def test_boundary_argument_errors(native, make_model):
     assert call(*args, ctypes.c_uint32(0), ctypes.c_float(float('nan'))) == 1
     assert call(*args, ctypes.c_uint32(0), ctypes.c_float(0.0)) == 0
     torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before   # entry points leave the caller's current device alone
     assert bits_equal(out.cpu().numpy(), oracle.OracleReader(path).rows_embedding(np.zeros(4, dtype=np.uint32)))
     total = ctypes.c_uint64(0)
     ids = np.array([0, 0xFFFFFFFF, 5], dtype=np.uint32)
@@ -661,12 +685,15 @@ def test_empty_models(native, tmp_path):
 
 def test_sharded_reader_in_one_process(native, make_model):
     # the node-level path of north_star: one replica per device, host-side gather into one buffer
-    # (this box has one GPU: the same device listed three times exercises the split and the threads)
+    # (distinct devices where the box has them; on a one-GPU box the same device listed three times
+    # still exercises the split and the threads)
     path, words = make_model(20000, 300, 'trained', 4)
-    sharded = native.ShardedReader(path, devices=[0, 0, 0])
+    available = native.hip_device_count()
+    devices = [0, 1 % available, 2 % available]
+    sharded = native.ShardedReader(path, devices=devices)
     checker = oracle.OracleReader(path)
     batch = sorted(words)[:7001:3] + ['missing'] * 5
-    assert sharded.devices == [0, 0, 0] and sharded.dim == 300 and len(sharded) == 20000
+    assert sharded.devices == devices and sharded.dim == 300 and len(sharded) == 20000
     assert bits_equal(sharded[batch], checker.batch_embedding(batch))
     assert bits_equal(sharded[batch[:2]], checker.batch_embedding(batch[:2]))   # fewer entries than devices
     assert bits_equal(sharded['missing'], np.zeros(300, dtype=np.float32))

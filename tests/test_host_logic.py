@@ -185,6 +185,37 @@ def test_lookup_without_device_fails_loudly(native):
         reader[['the', 'of']]
 
 
+def test_into_calls_refuse_arrays_they_could_not_fill_in_place(native):
+    # pybind11 would convert a float64 / float16 / non-contiguous array into a temporary copy, fill
+    # that, and leave the caller's matrix untouched: such arrays are refused before any lookup
+    reader = native.Reader(os.path.join(GOLDEN, 'six_words_trained.bin'))
+    words = ['the', 'of']
+    rows = np.zeros(2, dtype=np.uint32)
+    good = np.zeros((2, 6), dtype=np.float32)
+    bad = [
+        np.zeros((2, 6), dtype=np.float64),
+        np.zeros((2, 6), dtype=np.float16),
+        np.zeros((2, 6), dtype=np.int32),
+        np.zeros((6, 2), dtype=np.float32).T,          # column-major view
+        good[:, ::2],                                   # strided columns
+        good[::-1],                                     # negative row stride
+        np.zeros(12, dtype=np.float32),                 # one-dimensional
+    ]
+    for out in bad:
+        with pytest.raises(TypeError):
+            reader.batch_embedding_into(words, out, 0)
+        with pytest.raises(TypeError):
+            reader.rows_embedding_into(rows, out, 0)
+    frozen = np.zeros((2, 6), dtype=np.float32)
+    frozen.setflags(write=False)
+    with pytest.raises(TypeError, match='read-only'):
+        reader.rows_embedding_into(rows, frozen, 0)
+    with pytest.raises(RuntimeError, match='Output must be'):   # right kind of array, wrong shape
+        reader.rows_embedding_into(rows, np.zeros((3, 6), dtype=np.float32), 0)
+    with pytest.raises(RuntimeError, match='Output must be'):
+        reader.batch_embedding_into(words, np.zeros((2, 6), dtype=np.float32), 4)
+
+
 def test_getitem_dispatch_and_tokenizer_layout(native):
     # reference python/memb/reader.py:6-17,94-111
     from memb_amd.reader import BaseReader, tokenizer_word_list

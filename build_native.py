@@ -23,6 +23,7 @@ REFERENCE_SRC = '/root/reference/src'
 HIP_LIBRARY = os.path.join(PACKAGE_DIR, 'libmemb_hip.so')
 EXTENSION = os.path.join(PACKAGE_DIR, '_memb' + sysconfig.get_config_var('EXT_SUFFIX'))
 ORACLE_LIBRARY = os.path.join(ORACLE_DIR, 'libmemb_oracle.so')
+UNIFORM_EXPR_LIBRARY = os.path.join(ORACLE_DIR, 'libmemb_uniform_expr.so')
 REFERENCE_LIBRARY = os.path.join(ORACLE_DIR, '_ref', 'libmemb_ref.so')
 
 GPU_ARCH = 'gfx950'
@@ -95,6 +96,10 @@ def build_oracle(force=False):
             'gcc', '-O2', '-std=c11', '-fPIC', '-shared', '-pthread', '-Wall', '-ffp-contract=off',
             '-o', ORACLE_LIBRARY, source,
         ])
+    # the uniform expression as its own C++ TU, with the reference's flags (CMakeLists.txt:15)
+    expression = os.path.join(ORACLE_DIR, 'uniform_expr.cpp')
+    if os.path.exists(expression) and (force or _newer(UNIFORM_EXPR_LIBRARY, [expression])):
+        _run(['g++', '-std=c++14', '-O3', '-Wall', '-Werror', '-fPIC', '-shared', '-o', UNIFORM_EXPR_LIBRARY, expression])
     return ORACLE_LIBRARY
 
 

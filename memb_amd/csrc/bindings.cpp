@@ -82,6 +82,14 @@ struct WordPointers {
 
 py::dict contextInfo(memb::Reader& reader)
 {
+    if (reader.device() == memb::CompressedStorage::HOST_DEVICE) {
+        py::dict result;
+        result["device"] = "cpu";
+        result["dim"] = reader.dim();
+        result["n_rows"] = reader.size();
+        result["kernel"] = "host decode (" + reader.storageName() + ")";
+        return result;
+    }
     memb_hip_ctx_info info;
     if (memb_hip_ctx_get_info(reader.deviceContext(), &info) != MEMB_HIP_OK) {
         throw std::runtime_error(memb_hip_last_error());
@@ -217,6 +225,9 @@ PYBIND11_MODULE(_memb, m) {
         // ---- additions ----
         .def("size", [](memb::Reader& reader) { return reader.size(); })
         .def("device", [](memb::Reader& reader) { return reader.device(); })
+        .def("set_host_below", [](memb::Reader& reader, size_t words) { reader.setHostBelow(words); })
+        .def("host_below", [](memb::Reader& reader) { return reader.hostBelow(); })
+        .def("host_rows_decoded", [](memb::Reader& reader) { return reader.hostRowsDecoded(); })
         .def("storage_name", [](memb::Reader& reader) { return reader.storageName(); })
         .def("info", &contextInfo)
         .def("has_word_index", [](memb::Reader& reader) { return reader.hasWordIndex(); })
@@ -398,6 +409,7 @@ PYBIND11_MODULE(_memb, m) {
         py::arg("ld"),
         py::arg("stream") = 0,
         py::arg("average") = false);
+    m.attr("HOST_DEVICE") = static_cast<int>(memb::CompressedStorage::HOST_DEVICE);
     m.def("_writer_mimics_official_layout", [](bool enabled) {
         memb::wire::BufferBuilder::omitDefaults() = enabled;
     });

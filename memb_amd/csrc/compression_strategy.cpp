@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <future>
 #include <map>
 #include <stdexcept>
 #include <thread>
@@ -63,6 +64,9 @@ void CompressedStorage::setDevice(int device)
 
 memb_hip_ctx* CompressedStorage::deviceContext() const
 {
+    if (onHost()) {
+        throw std::runtime_error("this reader decodes on the host (device 'cpu'): it has no HIP device context");
+    }
     std::lock_guard<std::mutex> lock(contextMutex_);
     if (!context_) {
         context_ = createDeviceContext(device_);
@@ -70,8 +74,45 @@ memb_hip_ctx* CompressedStorage::deviceContext() const
     return context_;
 }
 
+// The reference's batch driver over host threads (src/reader.cpp:59-86): serial below
+// THREADED_DECODER_THRESHOLD words or with one thread, else jobs of ceil(n / threads) rows, each
+// writing its own slice of the output; a missing row is a zero row (src/reader.cpp:43-46).
+void CompressedStorage::decodeRowsHost(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const
+{
+    const size_t width = dim();
+    const size_t known = rowCount();
+    auto work = [=](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i) {
+            float* destination = out + i * ld + colOff;
+            if (rows[i] < known) {
+                extractRowHost(rows[i], destination);
+            } else {
+                std::fill(destination, destination + width, 0.f);
+            }
+        }
+    };
+    hostRows_.fetch_add(n, std::memory_order_relaxed);
+    if (n < THREADED_DECODER_THRESHOLD || hostThreads_ <= 1) {
+        work(0, n);
+        return;
+    }
+    const size_t jobSize = (n + hostThreads_ - 1) / hostThreads_;
+    std::vector<std::future<void>> jobs;
+    for (size_t first = jobSize; first < n; first += jobSize) {
+        jobs.push_back(std::async(std::launch::async, work, first, std::min(n, first + jobSize)));
+    }
+    work(0, std::min(n, jobSize));
+    for (auto& job : jobs) {
+        job.get();
+    }
+}
+
 void CompressedStorage::decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const
 {
+    if (onHost() || n <= hostBelow_) {
+        decodeRowsHost(rows, n, out, ld, colOff);
+        return;
+    }
     if (memb_hip_decode_rows(deviceContext(), rows, n, out, ld, colOff) != MEMB_HIP_OK) {
         throwDeviceError("HIP batch lookup failed");
     }
@@ -81,6 +122,9 @@ void CompressedStorage::decodeRowsDevice(
     const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream, bool accumulate,
     float divisor) const
 {
+    if (onHost()) {
+        throw std::runtime_error("this reader decodes on the host (device 'cpu'): device buffers need a reader on a HIP device");
+    }
     if (memb_hip_decode_rows_device_ex(
             deviceContext(), rows, n, out, ld, colOff, stream, accumulate ? MEMB_HIP_ACCUMULATE : 0u, divisor) !=
         MEMB_HIP_OK) {
@@ -291,6 +335,39 @@ public:
     }
 
 protected:
+    // Host decode of one row: the canonical-Huffman walk of the reference's extract
+    // (src/trained_compression.cpp:126-135: dim x next() -> centroid) over this project's two-level
+    // table (codec.h; results do not depend on the table width, like the reference's L). A 64-bit
+    // window is refilled bytewise, MSB first, with zeros past the end of packed_values
+    // (src/bit_stream_reader.h:16-31).
+    void extractRowHost(uint32_t row, float* destination) const override
+    {
+        const HostDecoder& decoder = hostDecoder();
+        const uint8_t* cursor = packedValues_.data + std::min<size_t>(valueOffsets_[row], packedValues_.size);
+        const uint8_t* const end = packedValues_.data + packedValues_.size;
+        const uint32_t* entries = decoder.table.entries.data();
+        const uint32_t rootBits = decoder.table.rootBits;
+        const float* centroids = decoder.centroids.data();
+        uint64_t window = 0;
+        uint32_t filled = 0;
+        for (size_t i = 0; i < dim_; ++i) {
+            while (filled <= 56) {
+                window |= static_cast<uint64_t>(cursor < end ? *cursor++ : 0) << (56 - filled);
+                filled += 8;
+            }
+            uint32_t entry = entries[window >> (64 - rootBits)];
+            if (entry & TABLE_POINTER_FLAG) {
+                const uint32_t subBits = entry & 0xff;
+                const size_t base = (entry & ~TABLE_POINTER_FLAG) >> 8;
+                entry = entries[base + ((window << rootBits) >> (64 - subBits))];
+            }
+            const uint32_t length = entry & 0xff;
+            window <<= length;
+            filled -= length;
+            destination[i] = centroids[(entry >> 8) & 0xff];
+        }
+    }
+
     memb_hip_ctx* createDeviceContext(int device) const override
     {
         memb_hip_trained_desc desc{};
@@ -314,6 +391,32 @@ protected:
     }
 
 private:
+    struct HostDecoder {
+        DecodeTable table;
+        std::vector<float> centroids;   // 256 entries, so that no symbol indexes past the codebook
+    };
+
+    // built on the first host decode (a reader on a device never needs it)
+    const HostDecoder& hostDecoder() const
+    {
+        std::call_once(hostDecoderOnce_, [this] {
+            auto lengths = codeLengthsFromSizeOffsets(keys_.data, keys_.size, sizeOffsets_.data, sizeOffsets_.size);
+            for (const auto& info : lengths) {
+                if (info.key >= centroids_.size) {
+                    throw std::runtime_error("Huffman symbol without a centroid");
+                }
+            }
+            // DEFAULT_DECODE_TABLE_BIT_LENGTH of the reference (src/trained_compression.h:11) unless told otherwise
+            const uint32_t limit = maxDirectDecodeBitLength_ ? static_cast<uint32_t>(maxDirectDecodeBitLength_) : 10;
+            hostDecoder_.table = buildDecodeTable(lengths, std::min<uint32_t>(limit, 12));
+            hostDecoder_.centroids.assign(256, 0.f);
+            std::copy(centroids_.begin(), centroids_.end(), hostDecoder_.centroids.begin());
+        });
+        return hostDecoder_;
+    }
+
+    mutable std::once_flag hostDecoderOnce_;
+    mutable HostDecoder hostDecoder_;
     size_t dim_;
     size_t maxDirectDecodeBitLength_;
     wire::VectorView<uint32_t> wordOffsets_;
@@ -571,6 +674,23 @@ public:
     }
 
 protected:
+    // reference src/uniform_compression.cpp:64-72: four separately rounded fp32 operations per weight
+    // (this file is built with -ffp-contract=off for baseline x86-64, like the reference's -O3 build);
+    // rows shorter than dim are zero padded, as the staged device copy is.
+    void extractRowHost(uint32_t row, float* destination) const override
+    {
+        const memb_hip_uniform_row& source = rows_[row];
+        const size_t count = std::min<size_t>(source.n_values, dim_);
+        const float minValue = source.min_value;
+        const float maxValue = source.max_value;
+        const uint8_t quantizationLevels = quantizationLevels_;
+        for (size_t i = 0; i < count; ++i) {
+            const float floatValue = static_cast<float>(source.values[i]);
+            destination[i] = minValue + (maxValue - minValue) * floatValue / quantizationLevels;
+        }
+        std::fill(destination + count, destination + dim_, 0.f);
+    }
+
     memb_hip_ctx* createDeviceContext(int device) const override
     {
         memb_hip_uniform_desc desc{};
@@ -671,6 +791,17 @@ public:
     }
 
 protected:
+    // reference src/full_compression.cpp:40-43
+    void extractRowHost(uint32_t row, float* destination) const override
+    {
+        const memb_hip_full_row& source = rows_[row];
+        const size_t count = std::min<size_t>(source.n_values, dim_);
+        if (count) {
+            std::memcpy(destination, source.values, count * sizeof(float));
+        }
+        std::fill(destination + count, destination + dim_, 0.f);
+    }
+
     memb_hip_ctx* createDeviceContext(int device) const override
     {
         memb_hip_full_desc desc{};

@@ -7,7 +7,12 @@
 // words to row ids on the host (`resolve`) and decodes whole batches of rows on
 // the device (`decodeRows`, through the C ABI in include/memb_hip.h);
 // `extract` is kept with the reference's signature and is a batch of one.
-// There is no CPU decode path: without a HIP device every lookup throws.
+//
+// Host decode (the reference's serial path, src/reader.cpp:61-63 and SURVEY 8b "else CPU path") exists
+// only as something a caller ASKS for: a storage placed on HOST_DEVICE (Reader(..., device = 'cpu'),
+// for hosts without a GPU: BASELINE.json configs[0]) or a `hostBelow` word count under which host
+// batches stay on the host (latency of single words). It is never taken on its own account: a storage
+// on a HIP device that cannot reach that device throws, it does not fall back.
 #pragma once
 
 #include "wire.h"
@@ -20,6 +25,8 @@
 #include <vector>
 
 namespace memb {
+
+const size_t THREADED_DECODER_THRESHOLD = 1024;  // reference src/reader.cpp:9
 
 class CompressedStorage {
 public:
@@ -53,19 +60,38 @@ public:
         const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream,
         bool accumulate = false, float divisor = 0.f) const;
 
+    // device == HOST_DEVICE: rows are decoded by extractRowHost on host threads
+    static constexpr int HOST_DEVICE = -2;
     void setDevice(int device);
     int device() const { return device_; }
+    bool onHost() const { return device_ == HOST_DEVICE; }
+    // Host batches (decodeRows) of at most `words` words are decoded on the host even though
+    // the storage lives on a device; 0 (the default) = never.
+    void setHostBelow(size_t words) { hostBelow_ = words; }
+    size_t hostBelow() const { return hostBelow_; }
+    void setHostThreads(size_t threads) { hostThreads_ = threads ? threads : 1; }
+    // rows decoded by the host path so far (tests: a device reader with default settings stays at 0)
+    uint64_t hostRowsDecoded() const { return hostRows_.load(std::memory_order_relaxed); }
     // The device context, created (payload staged to HBM) on first use.
     memb_hip_ctx* deviceContext() const;
 
 protected:
     virtual memb_hip_ctx* createDeviceContext(int device) const = 0;
+    // One row decoded on the host into destination[0 .. dim): what the reference's extract does
+    // after its word search (src/trained_compression.cpp:126-135, src/uniform_compression.cpp:58-72,
+    // src/full_compression.cpp:40-43).
+    virtual void extractRowHost(uint32_t row, float* destination) const = 0;
 
 private:
+    void decodeRowsHost(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
+
     struct WordIndex;
     const WordIndex* wordIndex() const;
 
     int device_ = 0;
+    size_t hostBelow_ = 0;
+    size_t hostThreads_ = 1;
+    mutable std::atomic<uint64_t> hostRows_{0};
     mutable std::mutex contextMutex_;
     mutable memb_hip_ctx* context_ = nullptr;
     mutable std::once_flag wordIndexOnce_;

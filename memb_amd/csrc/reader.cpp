@@ -17,12 +17,24 @@ namespace memb {
 
 namespace {
 
-const size_t THREADED_DECODER_THRESHOLD = 1024;  // reference src/reader.cpp:9
-
+// MEMB_HIP_DEVICE: a HIP device index, or "cpu" / "host" for host decode (CompressedStorage::HOST_DEVICE)
 int deviceFromEnvironment()
 {
     const char* text = std::getenv("MEMB_HIP_DEVICE");
-    return (text && *text) ? std::atoi(text) : 0;
+    if (!text || !*text) {
+        return 0;
+    }
+    if (std::strcmp(text, "cpu") == 0 || std::strcmp(text, "host") == 0) {
+        return CompressedStorage::HOST_DEVICE;
+    }
+    return std::atoi(text);
+}
+
+// MEMB_HOST_BELOW: host batches of at most this many words are decoded on the host (default 0 = never)
+size_t hostBelowFromEnvironment()
+{
+    const char* text = std::getenv("MEMB_HOST_BELOW");
+    return (text && *text) ? static_cast<size_t>(std::strtoull(text, nullptr, 10)) : 0;
 }
 
 }  // namespace
@@ -88,7 +100,25 @@ void Reader::init(std::shared_ptr<CompressionStrategy> compressionStrategy, int 
     storageName_ = compressionStrategy->storageName();
     compressedStorage_ = compressionStrategy->createCompressedStorage(
         flatIndex_.table(wire::field::Index_storage), dim_);
-    compressedStorage_->setDevice(device >= 0 ? device : deviceFromEnvironment());
+    compressedStorage_->setDevice(
+        device >= 0 || device == CompressedStorage::HOST_DEVICE ? device : deviceFromEnvironment());
+    compressedStorage_->setHostThreads(numThreads_);
+    compressedStorage_->setHostBelow(hostBelowFromEnvironment());
+}
+
+void Reader::setHostBelow(size_t words)
+{
+    compressedStorage_->setHostBelow(words);
+}
+
+size_t Reader::hostBelow() const
+{
+    return compressedStorage_->hostBelow();
+}
+
+uint64_t Reader::hostRowsDecoded() const
+{
+    return compressedStorage_->hostRowsDecoded();
 }
 
 size_t Reader::dim() const

@@ -32,7 +32,9 @@ private:
 
 class Reader {
 public:
-    // device < 0: taken from the environment variable MEMB_HIP_DEVICE, default 0.
+    // device: a HIP device index; CompressedStorage::HOST_DEVICE = decode on the host (the reference's
+    // CPU path, for hosts without a GPU); any other negative value: taken from the environment
+    // variable MEMB_HIP_DEVICE (an index, or "cpu"), default 0.
     Reader(const std::string& filename, size_t numThreads = 0, int device = -1);
     Reader(
         const std::string& filename,
@@ -53,6 +55,11 @@ public:
 
     size_t size() const;  // number of words in the file
     int device() const;
+    // Host batches of at most `words` words are decoded on the host although the reader lives on a
+    // device (single-word latency: no launch, no PCIe); 0 = never, the default (or MEMB_HOST_BELOW).
+    void setHostBelow(size_t words);
+    size_t hostBelow() const;
+    uint64_t hostRowsDecoded() const;   // rows the host path has decoded so far
     std::string storageName() const;
 
     // Sorted-order row ids of `words` (MEMB_HIP_MISSING_ROW for unknown words),

@@ -73,19 +73,28 @@ class Reader(BaseReader):
     filename     str or path-like
     num_threads  host threads for the word search of large batches, 0 = one per core
     device       HIP device index (not in the reference API); default: environment
-                 variable MEMB_HIP_DEVICE, else 0
+                 variable MEMB_HIP_DEVICE, else 0. 'cpu': decode on the host -- the reference's
+                 own serial / threaded CPU path restated, for hosts without a GPU; it is only
+                 ever used when asked for (a reader on a HIP device never falls back to it)
+    host_below   host batches (words in, numpy out) of at most this many words are decoded on
+                 the host although the reader lives on a GPU: a single word then costs no kernel
+                 launch and no PCIe round trip. 0 = never (default, or MEMB_HOST_BELOW)
     max_direct_decode_bits
                  width of the first-level decode table, 0 = library default (results
                  never depend on it; the reference's tests force 1, src/tests.cpp:76-88)
     """
 
-    def __init__(self, filename, num_threads=0, device=None, max_direct_decode_bits=0):
+    def __init__(self, filename, num_threads=0, device=None, max_direct_decode_bits=0, host_below=None):
         super().__init__()
         name = str(filename)
+        if device in ('cpu', 'host'):
+            device = _memb.HOST_DEVICE
         if device is None and not max_direct_decode_bits:
             self._impl = _memb.Reader(name, num_threads)
         else:
             self._impl = _memb.Reader(name, num_threads, -1 if device is None else int(device), max_direct_decode_bits)
+        if host_below is not None:
+            self._impl.set_host_below(int(host_below))
 
     @property
     def dim(self):
@@ -94,7 +103,14 @@ class Reader(BaseReader):
 
     @property
     def device(self):
-        return self._impl.device()
+        """HIP device index, or 'cpu' for a reader that decodes on the host"""
+        index = self._impl.device()
+        return 'cpu' if index == _memb.HOST_DEVICE else index
+
+    @property
+    def host_rows_decoded(self):
+        """rows decoded by the host path so far (0 for a GPU reader with default settings)"""
+        return self._impl.host_rows_decoded()
 
     def __len__(self):
         return self._impl.size()

@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIBRARY = os.environ.get('MEMB_ORACLE_LIBRARY', os.path.join(_HERE, 'libmemb_oracle.so'))  # override: sanitizer build
 REFERENCE_LIBRARY = os.path.join(_HERE, '_ref', 'libmemb_ref.so')
+UNIFORM_EXPR_LIBRARY = os.path.join(_HERE, 'libmemb_uniform_expr.so')
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _u16p = ctypes.POINTER(ctypes.c_uint16)
@@ -268,6 +269,27 @@ class ReferenceDecoder:
             self.decoder, view.packed_values, view.packed_values_size, view.value_offsets, view.word_count,
             view.centroids, rows.ctypes.data, len(rows), self.dim, out.ctypes.data, out.shape[1], num_threads)
         return out
+
+
+_uniform_expr_library = None
+
+
+def uniform_expression(min_value, max_value, levels, values):
+    """oracle/uniform_expr.cpp: the reference's expression over a row of bytes, as compiled with the
+    reference's flags (g++ -std=c++14 -O3, baseline x86-64). float32 array of len(values)."""
+    global _uniform_expr_library
+    if _uniform_expr_library is None:
+        if not os.path.exists(UNIFORM_EXPR_LIBRARY):
+            build()
+        _uniform_expr_library = ctypes.CDLL(UNIFORM_EXPR_LIBRARY)
+        _uniform_expr_library.memb_uniform_expr.restype = None
+        _uniform_expr_library.memb_uniform_expr.argtypes = [
+            ctypes.c_float, ctypes.c_float, ctypes.c_uint8, _u8p, ctypes.c_size_t, _f32p]
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    out = np.empty(len(values), dtype=np.float32)
+    _uniform_expr_library.memb_uniform_expr(
+        ctypes.c_float(min_value), ctypes.c_float(max_value), int(levels), _ptr(values, _u8p), len(values), _ptr(out, _f32p))
+    return out
 
 
 def uniform_value(min_value, max_value, value, levels):

@@ -215,19 +215,40 @@ def model_files():
 
 
 def uniform_expression_cases():
+    """[min bits, max bits, value, levels, result bits] from oracle/uniform_expr.cpp -- the reference's
+    expression (src/uniform_compression.cpp:70-71) compiled with the reference's flags. Covers the
+    stored-levels values of real files (2, 16, 255), an absent `quantization_levels` field (0: division
+    by zero, +-inf and NaN results), max < min, all-subnormal rows and overflowing ranges. numpy's
+    float32 arithmetic must agree (NaNs compare as NaNs: sign and payload of a generated NaN are the
+    platform's, 0xFFC00000 on x86-64)."""
     rng = np.random.default_rng(5)
     cases = []
-    specials = [(0.0, 0.0), (-1.0, 1.0), (1e-40, 3e-39), (-3.4e38, 3.4e38), (0.1, 0.1000001), (-2.5, 7.25)]
-    pairs = specials + [tuple(np.sort(rng.standard_normal(2).astype(np.float32) * 2)) for _ in range(58)]
+    f32 = np.float32
+    specials = [
+        (0.0, 0.0), (-1.0, 1.0), (-2.5, 7.25), (0.1, 0.1000001), (-3.4e38, 3.4e38),
+        # subnormal rows: everything below 2^-126
+        (1e-40, 3e-39), (1.4e-45, 1.4e-44), (-5e-41, 5e-41), (0.0, 1.4e-45), (-1.1754942e-38, 1.1754942e-38),
+        (1.1754942e-38, 1.17549435e-38),     # largest subnormal .. smallest normal
+        # max < min (a range that runs backwards)
+        (1.0, -1.0), (7.25, -2.5), (3e-39, 1e-40), (3.4e38, -3.4e38),
+        # infinities in the file
+        (0.0, float('inf')), (float('-inf'), float('inf')), (float('-inf'), 0.0),
+    ]
+    pairs = specials + [tuple(np.sort(rng.standard_normal(2).astype(np.float32) * 2)) for _ in range(46)]
     with np.errstate(all='ignore'):
         for low, high in pairs:
-            low, high = np.float32(low), np.float32(high)
-            for levels in (2, 16, 255):
-                for value in (0, 1, levels // 2, levels - 1, levels, 255):
-                    result = low + (high - low) * np.float32(value) / np.float32(levels)
-                    assert result.dtype == np.float32
+            low, high = f32(low), f32(high)
+            for levels in (0, 1, 2, 16, 255):
+                values = sorted({v for v in (0, 1, levels // 2, levels - 1, levels, 255) if 0 <= v <= 255})
+                results = oracle.uniform_expression(low, high, levels, values)
+                port = [oracle.uniform_value(low, high, v, levels) for v in values]
+                for value, result, ported in zip(values, results, port):
+                    viaNumpy = low + (high - low) * f32(value) / f32(levels)
+                    for other in (f32(viaNumpy), f32(ported)):   # numpy float32 and oracle/memb_oracle.c agree
+                        assert (np.isnan(other) and np.isnan(result)) or other.view(np.uint32) == result.view(np.uint32), \
+                            (low, high, value, levels)
                     cases.append([int(low.view(np.uint32)), int(high.view(np.uint32)), int(value), levels,
-                                  int(np.float32(result).view(np.uint32))])
+                                  int(f32(result).view(np.uint32))])
     return cases
 
 
@@ -240,6 +261,9 @@ def main():
             json.dump(payload, f, separators=(',', ':'))
             f.write('\n')
 
+    if '--only-uniform' in sys.argv:   # the other vectors stay as committed
+        dump('uniform_expr.json', uniform_expression_cases())
+        return
     dump('huffman_decode.json', decode_cases())
     dump('canonical_codes.json', canonical_cases())
     known = [(1023, 14), (33, 6), (0, 4), (1234, 11), (7, 2)]  # reference src/bit_stream_tests.cpp:35-41

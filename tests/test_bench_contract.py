@@ -1,0 +1,62 @@
+"""bench.py's output contract on small models: the single-GPU line with its per-configuration
+array, and the N > 1 path started the way the driver may start it -- `python bench.py --gpus 2`
+with no launcher -- as a rehearsal on one device (both ranks on cuda:0, gloo rendezvous)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def run_bench(arguments, tmp_path, **extra_env):
+    env = dict(os.environ, MEMB_BENCH_CACHE=str(tmp_path / 'models'), **extra_env)
+    result = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + arguments, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1, result.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_and_configuration_array(native, tmp_path):
+    line = run_bench(['--small', '--steps', '3', '--warmup', '1'], tmp_path)
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['steps'] == 3 and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['parity_vs_cpu_checker'] == 'bit-exact'
+    roofline = line['roofline']
+    assert roofline['bound'] == 'hbm' and roofline['peak'] == 8000.0 and roofline['unit'] == 'GB/s'
+    assert abs(roofline['frac'] - roofline['achieved'] / roofline['peak']) < 1e-12
+    assert roofline['kernel'].startswith('decode_trained')
+    assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['cpu_baseline']['cores'] >= 1
+    workloads = [entry['workload'] for entry in line['configs']]
+    for index in range(5):
+        assert any('configs[{}]'.format(index) in name for name in workloads), (index, workloads)
+    for entry in line['configs']:
+        assert entry['parity'].startswith('bit-exact'), entry
+        assert entry['kernel_ms'] > 0 and entry['algorithmic_bytes'] > 0
+
+
+def test_two_ranks_started_without_a_launcher(native, tmp_path):
+    line = run_bench(['--gpus', '2', '--small', '--steps', '2', '--warmup', '1'], tmp_path, MEMB_BENCH_REHEARSAL='1')
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and len(line['per_rank']) == 2
+    assert line['parity_vs_cpu_checker'].startswith('bit-exact')
+    strong = line['strong_scaling']
+    assert strong['scaling'] == 'strong' and strong['ranks_seen'] == 2
+    first, second = strong['per_rank']
+    assert first['rows'][0] == 0 and first['rows'][1] == second['rows'][0] and second['rows'][1] == 50000
+    assert all(entry['parity'].startswith('bit-exact') for entry in strong['per_rank'])
+    assert strong['kernel_only']['value'] > strong['with_d2h']['value'] > 0
+
+    strong_main = run_bench(['--gpus', '2', '--small', '--steps', '2', '--warmup', '1', '--scaling', 'strong'],
+                            tmp_path, MEMB_BENCH_REHEARSAL='1')
+    assert strong_main['scaling'] == 'strong' and strong_main['config']['workload'] == 'glove840b-300d-2bit-fullvocab'
+    assert sum(entry['batch'] for entry in strong_main['per_rank']) == 50000

@@ -117,3 +117,90 @@ def test_large_batches_from_several_threads(native, full_model):
     assert not errors, errors
     for (first, last), rows in zip(spans, results):
         assert bits_equal(rows, expected[first:last]), (first, last)
+
+
+# ---- the other BASELINE.json configurations at their full sizes ----
+
+def _dump_against_checker(native, path, centroid_limit):
+    """Full dump in key order: every slice bit-equal to the checker, values are centroids, and a second
+    dump of the rows in reverse order gives the same rows (a different tile -> wave assignment)."""
+    import torch
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    count = len(reader)
+    rows = torch.arange(count, dtype=torch.int32, device='cuda')
+    out = reader.rows_embedding_device(rows)
+    torch.cuda.synchronize()
+    step = 200000
+    for start in range(0, count, step):
+        stop = min(count, start + step)
+        expected = checker.rows_embedding(np.arange(start, stop, dtype=np.uint32))
+        assert bits_equal(out[start:stop].cpu().numpy(), expected), (start, stop)
+    assert torch.unique(out).numel() <= centroid_limit
+    backwards = reader.rows_embedding_device(torch.flip(rows, dims=(0,)).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.flip(backwards, dims=(0,)).view(torch.int32), out.view(torch.int32))
+    return reader, out
+
+
+def test_fasttext_shaped_6bit_full_dump(native):
+    # BASELINE.json configs[2]: 1,999,995 words, trained 6-bit (byte keys, up to 64 centroids)
+    from memb_amd import synthetic
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', 1999995))
+    path, _ = synthetic.cached_model(count, 300, 'trained', 6)
+    reader, _ = _dump_against_checker(native, path, 64)
+    assert reader.info()['kernel'].startswith('decode_trained_persistent<') and reader.info()['kernel'].endswith('false>')
+
+
+def test_glove_shaped_2bit_full_dump_and_its_eight_way_split(native):
+    # BASELINE.json configs[3]: the 2,196,017-word 2-bit dump, whole and as the eight slices
+    # memb_amd.sharding.shard_range hands to eight GPUs (decoded one after the other on this one)
+    import torch
+    from memb_amd import synthetic
+    from memb_amd.sharding import shard_range
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    path, _ = synthetic.cached_model(count, 300, 'trained', 2)
+    reader, out = _dump_against_checker(native, path, 4)
+    for rank in range(8):
+        start, stop = shard_range(count, rank, 8)
+        rows = torch.arange(start, stop, dtype=torch.int32, device='cuda')
+        piece = reader.rows_embedding_device(rows)
+        torch.cuda.synchronize()
+        assert torch.equal(piece.view(torch.int32), out[start:stop].view(torch.int32)), rank
+
+
+def test_union_of_two_full_size_models_500k_words(native):
+    # BASELINE.json configs[4]: ReadersUnion concatenate of a GloVe-shaped and a fastText-shaped 4-bit
+    # model, 500 000 words of which a quarter is unknown to each model, (n, 600) output merged on the device
+    import torch
+    from memb_amd import synthetic
+    glove = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    fasttext = int(os.environ.get('MEMB_TEST_FULL_VOCAB', 1999995))
+    path_a, _ = synthetic.cached_model(glove, 300, 'trained', 4)
+    path_b, _ = synthetic.cached_model(fasttext, 300, 'trained', 4, seed=4321)
+    reader_a, reader_b = native.Reader(path_a), native.Reader(path_b)
+    n = min(500000, glove)
+    rng = np.random.default_rng(17)
+    rows_a = rng.integers(0, len(reader_a), size=n).astype(np.uint32)
+    rows_a[rng.random(n) < 0.25] = 0xFFFFFFFF
+    rows_b = rng.integers(0, len(reader_b), size=n).astype(np.uint32)
+    rows_b[rng.random(n) < 0.25] = 0xFFFFFFFF
+    ids = [torch.from_numpy(rows_a.view(np.int32)).cuda(), torch.from_numpy(rows_b.view(np.int32)).cuda()]
+    merged = torch.full((n, 600), -1.0, dtype=torch.float32, device='cuda')
+    fused = native._memb.union_rows_to_device(
+        [reader_a._impl, reader_b._impl], [ids[0].data_ptr(), ids[1].data_ptr()], [0, 300], n,
+        merged.data_ptr(), merged.stride(0), torch.cuda.current_stream().cuda_stream, False)
+    assert fused, 'two 4-bit models of one geometry share the union kernel'
+    torch.cuda.synchronize()
+    got = merged.cpu().numpy()
+    expected = np.concatenate([oracle.OracleReader(path_a).rows_embedding(rows_a),
+                               oracle.OracleReader(path_b).rows_embedding(rows_b)], axis=-1)
+    assert bits_equal(got, expected)
+    both_missing = (rows_a == 0xFFFFFFFF) & (rows_b == 0xFFFFFFFF)
+    assert both_missing.any() and not got[both_missing].any()
+    # the same through one launch per reader (column blocks of the one matrix)
+    again = torch.full((n, 600), -1.0, dtype=torch.float32, device='cuda')
+    reader_a.rows_embedding_device(ids[0], out=again, col_off=0)
+    reader_b.rows_embedding_device(ids[1], out=again, col_off=300)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int32), merged.view(torch.int32))

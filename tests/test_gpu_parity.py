@@ -471,7 +471,9 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
     # one hand-made uniform file per `levels`, rows = the (min, max) pairs
     from memb_amd import _memb
     cases = golden_json('uniform_expr.json')
-    for levels in (2, 16, 255):
+    # (levels 0 = a file without the quantization_levels field: division by zero, +-inf and NaN rows;
+    #  the vectors also hold max < min and all-subnormal rows)
+    for levels in (0, 1, 2, 16, 255):
         subset = [c for c in cases if c[3] == levels]
         pairs = sorted({(c[0], c[1]) for c in subset})
         values = sorted({c[2] for c in subset})

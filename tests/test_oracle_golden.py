@@ -89,17 +89,33 @@ def test_missing_and_invalid_files(tmp_path):
 
 
 def test_uniform_expression_is_ieee_fp32():
-    # reference src/uniform_compression.cpp:70-71; vectors: numpy float32 evaluation
+    # reference src/uniform_compression.cpp:70-71. The vectors come from oracle/uniform_expr.cpp (the
+    # expression as a C++ translation unit built with the reference's flags); the C restatement, that
+    # translation unit as built here, and numpy's float32 arithmetic must all reproduce them -- levels 0
+    # (absent field: +-inf, NaN), max < min and subnormal rows included. NaNs compare as NaNs.
+    cases = golden_json('uniform_expr.json')
+    assert {c[3] for c in cases} == {0, 1, 2, 16, 255}
+    assert any(np.uint32(c[0]).view(np.float32) > np.uint32(c[1]).view(np.float32) for c in cases)   # max < min
+    subnormal = [c for c in cases if 0 < (c[0] & 0x7fffffff) < 0x00800000 and 0 < (c[1] & 0x7fffffff) < 0x00800000]
+    assert len(subnormal) > 50 and any(0 < (c[4] & 0x7fffffff) < 0x00800000 for c in subnormal)
+    assert any(np.isinf(np.uint32(c[4]).view(np.float32)) for c in cases if c[3] == 0)
+    assert any(np.isnan(np.uint32(c[4]).view(np.float32)) for c in cases if c[3] == 0)
     mismatches = 0
-    for low, high, value, levels, expected in golden_json('uniform_expr.json'):
-        low = np.uint32(low).view(np.float32)
-        high = np.uint32(high).view(np.float32)
-        got = np.float32(oracle.uniform_value(low, high, value, levels))
-        want = np.uint32(expected).view(np.float32)
-        if np.isnan(want):
-            mismatches += not np.isnan(got)
-        else:
-            mismatches += got.view(np.uint32) != np.uint32(expected)
+    with np.errstate(all='ignore'):
+        for low, high, value, levels, expected in cases:
+            low = np.uint32(low).view(np.float32)
+            high = np.uint32(high).view(np.float32)
+            want = np.uint32(expected).view(np.float32)
+            candidates = (
+                np.float32(oracle.uniform_value(low, high, value, levels)),
+                oracle.uniform_expression(low, high, levels, [value])[0],
+                np.float32(low + (high - low) * np.float32(value) / np.float32(levels)),
+            )
+            for got in candidates:
+                if np.isnan(want):
+                    mismatches += not np.isnan(got)
+                else:
+                    mismatches += got.view(np.uint32) != np.uint32(expected)
     assert mismatches == 0
 
 

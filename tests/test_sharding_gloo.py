@@ -1,7 +1,10 @@
-"""The N > 1 path on CPU: two processes (gloo), each takes its slice of the
-batch, slices are gathered on the host and must equal the unsharded result.
-The per-slice lookup uses the CPU checker here (no GPU in this suite); the
-GPU suite runs the same split through the HIP path in one process."""
+"""The N > 1 path: two processes (gloo), each takes its slice of the batch, slices
+are gathered on the host and must equal the unsharded result. Without a GPU (the
+CPU suite) the per-slice lookup is the CPU checker's -- what is under test there is
+the split, the rendezvous and the gather; the GPU suite runs the same two-process
+worker with every rank's slice decoded by the HIP path (each rank a Reader of its
+own on the device LOCAL_RANK picks, cuda:0 for both on a one-GPU box) and checked
+against the checker."""
 import os
 import subprocess
 import sys
@@ -36,14 +39,21 @@ WORKER = textwrap.dedent('''
 
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
-    reader = oracle.OracleReader({model!r}, 1)
-    keys = reader.keys()
-    batch = [keys[(7 * i) % len(keys)] if i % 9 else 'missing-%d' % i for i in range(1001)]
+    checker = oracle.OracleReader({model!r}, 1)
+    reader = checker
+    if {use_hip!r}:
+        import memb_amd
+        devices = memb_amd.hip_device_count()
+        assert devices >= 1
+        reader = memb_amd.Reader({model!r}, device=int(os.environ['LOCAL_RANK']) % devices)
+    keys = checker.keys()
+    batch = [keys[(7 * i) % len(keys)] if i % 9 else 'missing-%d' % i for i in range({count})]
     mine = shard_of(batch, rank, world)
     local = reader.batch_embedding(mine)
+    assert np.array_equal(local.view(np.uint32), checker.batch_embedding(mine).view(np.uint32))
     full = gather_rows(local, len(batch), dst=0)
     if rank == 0:
-        assert np.array_equal(full.view(np.uint32), reader.batch_embedding(batch).view(np.uint32))
+        assert np.array_equal(full.view(np.uint32), checker.batch_embedding(batch).view(np.uint32))
         np.save({out!r}, full)
     else:
         assert full is None
@@ -52,17 +62,28 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_shard_and_host_gather(native, tmp_path):
+def run_two_ranks(tmp_path, use_hip, count, port):
     model = os.path.join(GOLDEN, 'synthetic_4bit.bin')
     out = str(tmp_path / 'gathered.npy')
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER.format(repo=REPO, model=model, out=out))
+    script.write_text(WORKER.format(repo=REPO, model=model, out=out, use_hip=use_hip, count=count))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     result = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-         '--master-addr', '127.0.0.1', '--master-port', '29571', str(script)],
-        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert result.returncode == 0, result.stdout[-3000:]
     gathered = np.load(out)
-    assert gathered.shape == (1001, 300)
+    assert gathered.shape == (count, 300)
     assert (gathered[0] == 0).all()  # entry 0 is a missing word
+
+
+def test_two_rank_shard_and_host_gather(native, tmp_path):
+    run_two_ranks(tmp_path, use_hip=False, count=1001, port=29571)
+
+
+@pytest.mark.gpu
+def test_two_rank_shard_through_the_hip_path(native, tmp_path):
+    # two processes, each decoding its slice on the GPU (above the 512-word small-batch path and below it)
+    run_two_ranks(tmp_path, use_hip=True, count=3001, port=29573)
+    run_two_ranks(tmp_path, use_hip=True, count=301, port=29575)

@@ -134,8 +134,13 @@ struct memb_hip_ctx {
     uint32_t* table = nullptr;
     float* codebook = nullptr;
     bool fast = false;                   // <= 16 centroids, codes <= 8 bits, one-level table
-    memb::DecodeTable hostTable;
+    memb::DecodeTable hostTable;         // 8-byte device entries: nibble keys, the index pass, the union kernel
     uint32_t tableDwords = 0;
+    // byte keys (!fast): the table of the PACKED kernels -- 4-byte entries, a first level that covers
+    // the longest code where 32 KiB hold it (hip_trained_kernels.h: decodeSegment)
+    memb::DecodeTable byteTable;
+    std::vector<memb::CodeInfo> codeLengths;   // kept to rebuild byteTable narrower when LDS is short
+    uint32_t* table32 = nullptr;
     uint32_t maxStreamBytes = 0;
     uint32_t slotDwords = 0;
     uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
@@ -201,9 +206,19 @@ uint32_t codebookDwords(const memb_hip_ctx* ctx)
     return ctx->fast ? 512u : 256u;
 }
 
+// LDS dwords of the PACKED kernels' table (4-byte entries, padded to 16 bytes)
+uint32_t packedTableDwords(const memb_hip_ctx* ctx)
+{
+    return roundUp4(static_cast<uint32_t>(ctx->byteTable.entries.size()));
+}
+
+// withKeys: a lookup kernel (symbol tiles; byte-key models then use the PACKED layout); without: the index pass
 uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys)
 {
     uint32_t perWave = wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
+    if (withKeys && !ctx->fast) {
+        return 4u * (packedTableDwords(ctx) + codebookDwords(ctx) + waves * perWave);
+    }
     return 4u * (ctx->tableDwords + codebookDwords(ctx) + waves * perWave);
 }
 
@@ -307,7 +322,7 @@ hipError_t launchPersistentMode(
     if (ctx->fast) {
         return launchPersistentVariant<false, MODE, true>(ctx, params, blocks, threads, ldsBytes, stream);
     }
-    return ctx->hostTable.hasSubTables
+    return ctx->byteTable.hasSubTables
         ? launchPersistentVariant<true, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream)
         : launchPersistentVariant<false, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream);
 }
@@ -319,8 +334,10 @@ hipError_t launchTrainedMode(
     if (ctx->fast) {
         return launchTrainedVariant<false, MODE, true>(params, blocks, threads, ldsBytes, stream);
     }
-    return ctx->hostTable.hasSubTables ? launchTrainedVariant<true, MODE, false>(params, blocks, threads, ldsBytes, stream)
-                                       : launchTrainedVariant<false, MODE, false>(params, blocks, threads, ldsBytes, stream);
+    // (the index pass reads the 8-byte table, every other byte-key kernel the packed one)
+    const bool hasSub = MODE == OUT_INDEX ? ctx->hostTable.hasSubTables : ctx->byteTable.hasSubTables;
+    return hasSub ? launchTrainedVariant<true, MODE, false>(params, blocks, threads, ldsBytes, stream)
+                  : launchTrainedVariant<false, MODE, false>(params, blocks, threads, ldsBytes, stream);
 }
 
 TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
@@ -377,6 +394,12 @@ int launchTrained(
     params.keyRowBytes = keyRowBytes(ctx);
     params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
     params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
+    if (!ctx->fast) {
+        // byte keys: the PACKED kernels' table (4-byte entries, tableDwords of them incl. padding)
+        params.table = ctx->table32;
+        params.rootBits = ctx->byteTable.rootBits;
+        params.tableDwords = packedTableDwords(ctx);
+    }
 
     // The kernels index LDS and the symbol tile from these numbers without further checks.
     {
@@ -389,6 +412,7 @@ int launchTrained(
             uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
             (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
             geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
+            (ctx->fast || (params.table != nullptr && params.tableDwords >= (1u << params.rootBits))) &&
             geometry.ldsBytes <= ctx->ldsLimit && ld >= colOff + params.dim;
         if (!consistent) {
             return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
@@ -933,6 +957,23 @@ int buildHostTable(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             }
             ++limit;
         }
+        // The byte-key kernels' table. What costs there is the second-level lookup, not the size of
+        // the first level: a branch and a second dependent LDS round trip per symbol as soon as one
+        // lane of the wavefront needs it (6-bit GloVe-shaped model, codes up to 10 bits: 0.71 ms with
+        // an 8-bit first level, 0.61 ms with a 10-bit one; 8-bit model, codes up to 13 bits: 0.74 /
+        // 0.72 / 0.68 ms with 11 / 12 / 13 bits). So the first level covers the longest code
+        // whenever 32 KiB of 4-byte entries hold it (13 bits); a given max_direct_bits is still
+        // honoured (tests force the two-level path with it), raised only while the tables would not fit.
+        ctx->codeLengths = lengths;
+        uint32_t byteLimit = desc->max_direct_bits ? desc->max_direct_bits : envUint("MEMB_HIP_BYTE_ROOT_BITS", 13);
+        byteLimit = std::max<uint32_t>(1, std::min<uint32_t>(byteLimit, 13));
+        for (;;) {
+            ctx->byteTable = memb::buildDecodeTable(lengths, byteLimit);
+            if (ctx->byteTable.entries.size() * 4 <= 48 * 1024 || byteLimit >= 13) {
+                break;
+            }
+            ++byteLimit;
+        }
     } catch (const std::exception& error) {
         return fail(MEMB_HIP_ERR_INVALID, error.what());
     }
@@ -1090,13 +1131,27 @@ void chooseLanes(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         lanes = 1;
     }
     const uint32_t group = ctx->fast ? 8 : 4;
+    // (byte keys: a first level wider than 11 bits is a luxury -- it goes first when LDS is short)
+    auto narrowTable = [ctx] {
+        if (ctx->fast || ctx->byteTable.rootBits <= 11) {
+            return false;
+        }
+        ctx->byteTable = memb::buildDecodeTable(ctx->codeLengths, ctx->byteTable.rootBits - 1);
+        return true;
+    };
     for (;;) {
         ctx->segmentSymbols = std::max<uint32_t>(group, ((desc->dim + lanes - 1) / lanes + group - 1) / group * group);
         ctx->lanesPerWord = (desc->dim + ctx->segmentSymbols - 1) / ctx->segmentSymbols;
         if (lanes >= WAVE || trainedLdsBytes(ctx, 1, WAVE / ctx->lanesPerWord, true) <= ctx->ldsLimit) {
             break;
         }
+        if (narrowTable()) {
+            continue;
+        }
         lanes = std::min<uint32_t>(WAVE, lanes < 8 ? 8 : 2 * lanes);
+    }
+    // a forced block size (MEMB_HIP_WAVES, tests) may still need the room
+    while (!chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr).waves && narrowTable()) {
     }
     ctx->indexWide = uint64_t(ctx->maxStreamBytes) * 8 + 64 >= 65536;
 }
@@ -1122,6 +1177,12 @@ int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             }
         }
         code = copyToDevice(ctx->table, expanded.data(), expanded.size() * 4);
+    }
+    if (code == MEMB_HIP_OK && !ctx->fast) {
+        code = deviceAlloc(ctx, &ctx->table32, ctx->byteTable.entries.size() * 4);
+        if (code == MEMB_HIP_OK) {
+            code = copyToDevice(ctx->table32, ctx->byteTable.entries.data(), ctx->byteTable.entries.size() * 4);
+        }
     }
     if (code == MEMB_HIP_OK) {
         code = deviceAlloc(ctx, &ctx->codebook, 512 * 4);
@@ -1353,9 +1414,10 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
     info->n_rows = ctx->nRows;
     info->device_bytes = ctx->deviceBytes;
     if (ctx->storage == memb::wire::Storage_Trained) {
-        info->root_bits = ctx->hostTable.rootBits;
-        info->max_code_bits = ctx->hostTable.maxCodeBits;
-        info->table_entries = static_cast<uint32_t>(ctx->hostTable.entries.size());
+        const memb::DecodeTable& table = ctx->fast ? ctx->hostTable : ctx->byteTable;   // the lookup kernels' table
+        info->root_bits = table.rootBits;
+        info->max_code_bits = table.maxCodeBits;
+        info->table_entries = static_cast<uint32_t>(table.entries.size());
         info->max_stream_bytes = ctx->maxStreamBytes;
         TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
         info->waves_per_block = geometry.waves;
@@ -1368,7 +1430,8 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", persistent ? "decode_trained_persistent" : "decode_trained",
-            ctx->hostTable.hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT), ctx->fast ? "true" : "false");
+            (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
+            ctx->fast ? "true" : "false");
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
         std::snprintf(

@@ -594,7 +594,12 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
-    if (tile >= tiles) {
+    // Measurement (debugFlags bit 3): the wavefronts of a block meet at a barrier before every
+    // output phase, so that the block's adjacent tiles reach memory together; every wavefront of
+    // the block then makes the same number of rounds (idle ones past the end of the batch).
+    const bool syncOutput = (p.debugFlags & 8) != 0;
+    unsigned long long blockTile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE);
+    if (syncOutput ? blockTile >= tiles : tile >= tiles) {
         return;
     }
     const LaneRole role = laneRole(p, lane);
@@ -620,12 +625,13 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     // decode (which gave them a whole decode to land) and before this round's
     // stores are issued, so that the wait there is only for loads; the new
     // loads are the last memory instructions of the round.
-    for (; tile < tiles; tile += stride) {
+    for (; syncOutput ? blockTile < tiles : tile < tiles; tile += stride, blockTile += stride) {
+        const bool live = tile < tiles;
         const unsigned long long tileBase = tile * p.wordsPerWave;
         const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+            live ? static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase)) : 0u;
 
-        if (!(p.debugFlags & 1)) {
+        if (live && !(p.debugFlags & 1)) {
             decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta0);
         }
         waveLdsFence();
@@ -645,7 +651,10 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
         unpackMeta(p, role, meta2);
         __builtin_amdgcn_sched_barrier(0);
 
-        if (!(p.debugFlags & 2)) {
+        if (syncOutput) {
+            __syncthreads();
+        }
+        if (live && !(p.debugFlags & 2)) {
             // rows of the tile consecutive (a dump in key order, or a run of one)?
             const uint32_t firstRow = __shfl(meta0.row, 0);
             const bool sequentialTile = __all(role.spare || meta0.row == firstRow + role.word);

@@ -584,6 +584,11 @@ def main():
         elapsed = float(slowest.item())
     kernel_ms = sorted(starts[i].elapsed_time(stops[i]) for i in range(args.steps))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    # This box's write rate into the very same buffer (outside the timed region): torch's fill_ kernel,
+    # as a yardstick for what the memory system of this particular GPU gives a write-only stream
+    fill_ms = timer.launches(lambda: out.fill_(0.0), 10)
+    step()   # the output again, for the parity check below
+    torch.cuda.synchronize()
     rank_summary = {'rank': rank, 'device': local_rank, 'batch': n, 'kernel_avg_ms': kernel_avg_ms, 'kernel_min_ms': kernel_ms[0]}
     if distributed:
         per_rank = [None] * world_size
@@ -684,6 +689,12 @@ def main():
             'algorithmic_bytes_per_launch': nbytes,
             'algorithmic_bytes_per_word': nbytes / max(n, 1),
             'frac_of_copy_ceiling': achieved_gbps / HBM_COPY_CEILING_GBPS,
+            'box_fill': {
+                'what': 'torch fill_ of the same output buffer on this GPU, median of 10 (write-only yardstick, not a bound: boxes differ by ~10 %)',
+                'ms': fill_ms[len(fill_ms) // 2],
+                'GBps': 4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3) / 1e9,
+                'kernel_hbm_bytes_rate_vs_fill': ((traffic or nbytes) / (kernel_avg_ms * 1e-3)) / (4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3)),
+            },
             'rank': 0,
         },
         'cpu_baseline': baseline,

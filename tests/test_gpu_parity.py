@@ -120,6 +120,21 @@ def test_small_batches_through_the_pinned_buffer(native, make_model, storage, bi
         reader.batch_embedding_into([keys[r] if r < len(keys) else '?' for r in rows], wide, 5)
         assert bits_equal(wide[:, 5:305], expected), count
         assert (wide[:, :5] == 7.0).all() and (wide[:, 305:] == 7.0).all()
+        # a reader on a device never decodes on the host unless asked to (host_below / device='cpu')
+        assert reader.device == 0 and reader.host_rows_decoded == 0
+
+
+def test_host_below_and_the_device_agree(native, make_model):
+    # the opt-in host path for small host batches next to the HIP path of the same reader: same bits
+    path, words = make_model(3000, 300, 'trained', 4)
+    keys = sorted(words)
+    on_device = native.Reader(path)
+    mixed = native.Reader(path, host_below=64)
+    for count in (1, 64, 65, 600):
+        batch = keys[7:7 + count] + ['not-a-word']
+        assert bits_equal(mixed[batch[:count]], on_device[batch[:count]])
+    assert mixed.host_rows_decoded == 1 + 64 and on_device.host_rows_decoded == 0
+    assert bits_equal(mixed[keys[5]], on_device[keys[5]])
 
 
 def test_host_copy_ring_chunks_threads_and_slices(native, make_model, monkeypatch):

@@ -146,6 +146,10 @@ public:
         view.position = target + 4;
         blob_.require(view.position, view.size * sizeof(T));
         view.data = reinterpret_cast<const T*>(blob_.data + view.position);
+        // elements are read through typed pointers: a crafted offset must not make them misaligned
+        if (reinterpret_cast<uintptr_t>(view.data) % alignof(T) != 0) {
+            throw std::runtime_error(VERIFICATION_FAILED);
+        }
         return view;
     }
 
@@ -154,6 +158,10 @@ public:
     {
         VectorView<char> view = vector<char>(id);
         blob_.require(view.position, view.size + 1);
+        // storages keep raw char pointers into the mapping and run strcmp / strlen on them
+        if (blob_.data[view.position + view.size] != 0) {
+            throw std::runtime_error(VERIFICATION_FAILED);
+        }
         return view;
     }
 
@@ -217,6 +225,7 @@ inline TableView getIndexChecked(const Blob& blob)
 class BufferBuilder {
 public:
     typedef uint32_t Ref;  // distance from buffer end to the start of an object
+    static constexpr size_t MAX_BUFFER_SIZE = (size_t(1) << 31) - 1;
 
     explicit BufferBuilder(size_t initialCapacity = 1024):
         storage_(std::max<size_t>(initialCapacity, 64)),
@@ -356,6 +365,11 @@ private:
 
     void ensure(size_t extra)
     {
+        // offsets are 32 bits; like FlatBufferBuilder (FLATBUFFERS_MAX_BUFFER_SIZE) refuse to grow past
+        // 2 GiB - 1 instead of writing wrapped offsets
+        if (extra > MAX_BUFFER_SIZE || used_ > MAX_BUFFER_SIZE - extra) {
+            throw std::runtime_error("memb file would exceed 2 GiB: the format's offsets are 32 bits");
+        }
         if (used_ + extra <= storage_.size()) {
             return;
         }

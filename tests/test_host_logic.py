@@ -185,6 +185,29 @@ def test_lookup_without_device_fails_loudly(native):
         reader[['the', 'of']]
 
 
+def test_strings_without_their_terminator_are_refused(native, tmp_path):
+    # storages keep raw char pointers into the mapping and strcmp them: a word whose NUL has been
+    # overwritten must be refused when the file is opened, not read past
+    for name, word in (('six_words_uniform.bin', b'tho'), ('six_words_full.bin', b'abc')):
+        data = bytearray(open(os.path.join(GOLDEN, name), 'rb').read())
+        at = data.find(len(word).to_bytes(4, 'little') + word + b'\0')
+        assert at >= 0
+        data[at + 4 + len(word)] = ord('x')
+        broken = tmp_path / name
+        broken.write_bytes(bytes(data))
+        with pytest.raises(RuntimeError, match='File format verification failed'):
+            native.Reader(str(broken))
+    data = bytearray(open(os.path.join(GOLDEN, 'six_words_trained.bin'), 'rb').read())
+    packed = b'a\0abc\0of\0th\0the\0tho\0'   # every word with its NUL; the string's own terminator follows
+    at = data.find(len(packed).to_bytes(4, 'little') + packed + b'\0')
+    assert at >= 0
+    data[at + 4 + len(packed)] = ord('x')
+    broken = tmp_path / 'trained.bin'
+    broken.write_bytes(bytes(data))
+    with pytest.raises(RuntimeError, match='File format verification failed'):
+        native.Reader(str(broken))
+
+
 def test_into_calls_refuse_arrays_they_could_not_fill_in_place(native):
     # pybind11 would convert a float64 / float16 / non-contiguous array into a temporary copy, fill
     # that, and leave the caller's matrix untouched: such arrays are refused before any lookup

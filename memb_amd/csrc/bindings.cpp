@@ -173,8 +173,10 @@ PYBIND11_MODULE(_memb, m) {
                 if (buffer.ndim != 2 || static_cast<size_t>(buffer.shape[0]) != words.size()) {
                     throw std::runtime_error("Expected a matrix with one row per word");
                 }
-                builder.addWords(
-                    words, reinterpret_cast<const float*>(buffer.ptr), static_cast<size_t>(buffer.shape[1]));
+                const float* values = reinterpret_cast<const float*>(buffer.ptr);
+                const size_t dim = static_cast<size_t>(buffer.shape[1]);
+                py::gil_scoped_release release;   // copies rows: other Python threads may run meanwhile
+                builder.addWords(words, values, dim);
             })
         .def(
             "save",

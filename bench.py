@@ -43,6 +43,7 @@ HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy on MI355X (same guide)
 GLOVE_WORDS = 2196017
 FASTTEXT_WORDS = 1999995
 MISSING = 0xFFFFFFFF
+FILL_LAUNCHES = 40
 
 WORKLOADS = {
     # name: (words, bits, batch) ; batch None = every key (full dump)
@@ -112,12 +113,21 @@ class Timer:
     def __init__(self, torch):
         self.torch = torch
 
-    def launches(self, call, count, warmup=3):
+    def launches(self, call, count, run_in_ms=20.0):
+        """Sorted per-launch times of `count` launches that follow ~run_in_ms of the same launches without a
+        gap (the part's power state needs that long to settle after an idle gap: tools/perf/ramp.py)."""
         torch = self.torch
-        for _ in range(warmup):
-            call()
+        call()
         torch.cuda.synchronize()
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        begin.record()
+        call()
+        end.record()
+        torch.cuda.synchronize()
+        one = max(begin.elapsed_time(end), 1e-3)
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+        for _ in range(max(3, min(2000, int(run_in_ms / one) + 1))):
+            call()
         for begin, end in events:
             begin.record()
             call()
@@ -428,9 +438,14 @@ def strong_scaling(args, memb_amd, synthetic, rank, world_size, local_rank, dist
     steps = args.steps
 
     def timed(call):
-        for _ in range(3):
-            call()
+        call()
         torch.cuda.synchronize()
+        probe = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - probe, 1e-6)
+        for _ in range(max(3, min(2000, int(0.02 / one) + 1))):   # ~20 ms without a gap: the power state settles
+            call()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -557,14 +572,26 @@ def main():
     def step():
         reader.rows_embedding_device(rows, out=out)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-
-    # the timed region: exactly `steps` steps between barrier + synchronize on both sides; per-launch
-    # kernel durations from HIP events on the stream the kernel runs on
+    # Events first, so that nothing but launches lies between the phases below.
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    fills = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(FILL_LAUNCHES)]
+    torch.cuda.synchronize()
+
+    # (1) The box's yardstick: torch's fill_ of the very same output buffer, FILL_LAUNCHES times (~20 ms),
+    # enqueued directly in front of the warmup. It doubles as the run-in of the GPU's power state: after
+    # any idle gap of a few milliseconds this part runs launches 3..25 of a burst ~10 % slower than
+    # launch 26 onwards (tools/perf/ramp.py: 0.65 ms against 0.59 ms, whether the gap was 0, 3 or 10 s),
+    # and with W = 5, K = 20 the timed region would sit exactly inside that transient.
+    for begin, end in fills:
+        begin.record()
+        out.fill_(0.0)
+        end.record()
+    # (2) W untimed warmup steps
+    for _ in range(args.warmup):
+        step()
+    # (3) the timed region: exactly `steps` steps between barrier + synchronize on both sides; per-launch
+    # kernel durations from HIP events on the stream the kernel runs on
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -584,11 +611,7 @@ def main():
         elapsed = float(slowest.item())
     kernel_ms = sorted(starts[i].elapsed_time(stops[i]) for i in range(args.steps))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
-    # This box's write rate into the very same buffer (outside the timed region): torch's fill_ kernel,
-    # as a yardstick for what the memory system of this particular GPU gives a write-only stream
-    fill_ms = timer.launches(lambda: out.fill_(0.0), 10)
-    step()   # the output again, for the parity check below
-    torch.cuda.synchronize()
+    fill_ms = sorted(begin.elapsed_time(end) for begin, end in fills[FILL_LAUNCHES // 2:])   # the settled half
     rank_summary = {'rank': rank, 'device': local_rank, 'batch': n, 'kernel_avg_ms': kernel_avg_ms, 'kernel_min_ms': kernel_ms[0]}
     if distributed:
         per_rank = [None] * world_size
@@ -690,7 +713,7 @@ def main():
             'algorithmic_bytes_per_word': nbytes / max(n, 1),
             'frac_of_copy_ceiling': achieved_gbps / HBM_COPY_CEILING_GBPS,
             'box_fill': {
-                'what': 'torch fill_ of the same output buffer on this GPU, median of 10 (write-only yardstick, not a bound: boxes differ by ~10 %)',
+                'what': 'torch fill_ of the same output buffer on this GPU, {} launches enqueued in front of the warmup steps, median of the second half (write-only yardstick, not a bound: boxes differ by ~10 %; also the run-in of the power state, see DESIGN.md section 6)'.format(FILL_LAUNCHES),
                 'ms': fill_ms[len(fill_ms) // 2],
                 'GBps': 4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3) / 1e9,
                 'kernel_hbm_bytes_rate_vs_fill': ((traffic or nbytes) / (kernel_avg_ms * 1e-3)) / (4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3)),

@@ -11,7 +11,7 @@ print(json.dumps(d['host_api'], indent=1))
 echo "== N=2 rehearsal (both ranks on cuda:0, gloo), self-launched"
 MEMB_BENCH_REHEARSAL=1 timeout -k 10 600 python3 bench.py --gpus 2 --small --steps 3 --warmup 1 > gpurun_out/r2_bench_n2_rehearsal.json 2> gpurun_out/r2_bench_n2_rehearsal.err || { tail -30 gpurun_out/r2_bench_n2_rehearsal.err; exit 1; }
 python3 -c "
-import json; d=json.load(open('gpurun_out/r2_bench_n2_rehearsal.json'))
+import json; d=json.loads([l for l in open('gpurun_out/r2_bench_n2_rehearsal.json') if l.startswith('{')][-1])
 print('n_gpus', d['n_gpus'], 'ranks_seen', d['ranks_seen'], 'value %.4g' % d['value'], d['parity_vs_cpu_checker'])
 print(json.dumps(d['strong_scaling'], indent=1)[:1500])
 "

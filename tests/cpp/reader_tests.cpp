@@ -191,6 +191,35 @@ void codecKnownAnswers()
     CHECK(clusters == expectedClusters);
 }
 
+// Descriptions of prefix codes that cannot exist must be refused by the table builder, never indexed
+// with (the CPU suite runs this file under AddressSanitizer: an over-subscribed set of lengths used to
+// write past the first-level table).
+void malformedCodes()
+{
+    std::printf("malformed code descriptions\n");
+    auto lengths = [](std::initializer_list<uint32_t> values) {
+        std::vector<memb::CodeInfo> result;
+        uint8_t key = 0;
+        for (uint32_t length : values) {
+            result.push_back({key++, length});
+        }
+        return result;
+    };
+    for (uint32_t limit : {1u, 4u, 10u, 12u}) {
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable(lengths({1, 1, 1}), limit); }));
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable(lengths({1, 1, 1, 13}), limit); }));
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable(lengths({1, 2, 3, 3, 3}), limit); }));
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable(lengths({2, 1}), limit); }));        // not sorted
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable(lengths({1, 17}), limit); }));       // too long
+        CHECK(throws<std::runtime_error>([&] { memb::buildDecodeTable({}, limit); }));
+        // complete and incomplete codes are fine: 1 + 2 + 3 + 3 bits, and a lone 16-bit code beside a 1-bit one
+        const memb::DecodeTable complete = memb::buildDecodeTable(lengths({1, 2, 3, 3}), limit);
+        CHECK(complete.maxCodeBits == 3 && complete.entries.size() >= (size_t(1) << complete.rootBits));
+        const memb::DecodeTable sparse = memb::buildDecodeTable(lengths({1, 16}), limit);
+        CHECK(sparse.maxCodeBits == 16 && sparse.hasSubTables);
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -199,6 +228,7 @@ int main(int argc, char** argv)
     try {
         refusals();
         codecKnownAnswers();
+        malformedCodes();
         if (!hostOnly) {
             roundTrip("full storage round trip", memb::wire::Storage_Full,
                       memb::createCompressionStrategy(memb::wire::Storage_Full));

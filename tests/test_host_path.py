@@ -119,6 +119,31 @@ def test_host_below_keeps_small_host_batches_on_the_host(native, monkeypatch):
     assert native.Reader(path).device == 'cpu'
 
 
+def build_reader_tests(native, tmp_path, extra_flags):
+    binary = str(tmp_path / 'reader_tests')
+    library_dir = os.path.dirname(native.HIP_LIBRARY_PATH)
+    command = ['g++', '-std=c++17', '-Wall', '-Werror', '-ffp-contract=off'] + extra_flags
+    command += ['-I', os.path.join(REPO, 'include'), os.path.join(REPO, 'tests', 'cpp', 'reader_tests.cpp')]
+    command += [os.path.join(REPO, 'memb_amd', 'csrc', name) for name in ('reader.cpp', 'builder.cpp', 'compression_strategy.cpp')]
+    command += ['-L', library_dir, '-lmemb_hip', '-Wl,-rpath,' + library_dir, '-pthread', '-o', binary]
+    build = subprocess.run(command, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    return binary
+
+
+def test_cpp_cases_under_address_sanitizer(native, tmp_path):
+    # wire parser, table construction (incl. descriptions of impossible codes), writer and host decode
+    # of the product, instrumented: AddressSanitizer + UBSan, CPU only (the GPU pool has no sanitizer runs)
+    binary = build_reader_tests(native, tmp_path, ['-O1', '-g', '-fsanitize=address,undefined',
+                                                   '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer'])
+    env = dict(os.environ, MEMB_HIP_DEVICE='cpu', ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    run = subprocess.run([binary], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stdout[-4000:]
+    assert 'malformed code descriptions' in run.stdout and run.stdout.strip().endswith('ok (0 failed checks)')
+    assert 'runtime error' not in run.stdout and 'AddressSanitizer' not in run.stdout
+
+
 def test_reference_cpp_cases_on_the_host_path(native, tmp_path):
     # the reference's own test cases (tests/cpp/reader_tests.cpp restates src/tests.cpp) with the
     # host path selected through the environment: six words x three storages, the forced two-level

@@ -21,6 +21,12 @@ struct TrainedParams {
     const uint16_t* segmentIndex;   // [nRows][lanesPerWord - 1] bit offsets of segments 1.. from the stream start
     const uint32_t* rowMeta;        // or null: one 16-byte record per row, {start, offsets of segments 1..7 in 13 bits
                                     // each}: what streamStarts and segmentIndex hold, fetched by ONE load per lane
+    uint32_t recordPieces;          // non-zero: ROW RECORDS -- `streams` holds one fixed-size region of this many
+                                    // 16-byte pieces per row, row r at piece r * recordPieces: piece 0 = the record
+                                    // {stream bytes, 7 x 13-bit segment offsets}, the bitstream from piece 1 on. A
+                                    // row's address needs no lookup, its offsets arrive with its stream: a random
+                                    // word costs two line requests (index entry + straddling stream: 3.2)
+    uint32_t loadPieces;            // pieces copied to LDS per word (recordPieces, or the whole slot: slotDwords / 4)
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
                                     // (both hold 32-bit entries when indexWide: rows longer than 65535 bits)
     const uint32_t* table;          // 8-byte entries, see TableEntry
@@ -31,7 +37,7 @@ struct TrainedParams {
     uint32_t rootBits;
     uint32_t dim;
     uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
-    uint32_t slotMagic;       // fastDivide magic for slotDwords / 4
+    uint32_t slotMagic;       // fastDivide magic for loadPieces
     uint32_t lanesPerWord;    // G
     uint32_t laneMagic;       // fastDivide magic for G
     uint32_t wordsPerWave;    // 64 / G
@@ -115,6 +121,10 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     if (p.debugFlags & 4) {
         return meta;
     }
+    if (p.recordPieces) {   // row records: the address is arithmetic, the offsets come with the stream
+        meta.start = row < p.nRows ? row * p.recordPieces : 0u;
+        return meta;
+    }
     if (row < p.nRows && p.rowMeta) {
         const u32x4* source = reinterpret_cast<const u32x4*>(p.rowMeta) + row;
         const u32x4 record = (p.debugFlags & 0x100) ? *source : __builtin_nontemporal_load(source);
@@ -132,24 +142,30 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     return meta;
 }
 
-// rowMeta: picks the lane's 13-bit field out of the record's 96 offset bits (field s - 1 of
-// segment s at bit 13 (s - 1)); no-op for the two-array layout.
-__device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRole& role, WordMeta& meta)
+// The lane's 13-bit field out of a record's 96 offset bits (field s - 1 of segment s at bit 13 (s - 1)).
+__device__ __forceinline__ uint32_t segmentField(uint32_t segment, uint32_t bits0, uint32_t bits1, uint32_t bits2)
 {
-    if (!p.rowMeta) {
-        return;
-    }
     // (two conditional moves per step, spelled out: a three-way select by index is turned into
     // a table in scratch memory)
-    const uint32_t bit = role.segment ? ROW_META_BITS * (role.segment - 1) : 0u;
+    const uint32_t bit = segment ? ROW_META_BITS * (segment - 1) : 0u;
     const bool second = bit >= 32;
     const bool third = bit >= 64;
-    uint32_t low = second ? meta.packed2 : meta.segmentBits;
-    uint32_t high = second ? meta.packed3 : meta.packed2;
-    low = third ? meta.packed3 : low;
+    uint32_t low = second ? bits1 : bits0;
+    uint32_t high = second ? bits2 : bits1;
+    low = third ? bits2 : low;
     high = third ? 0u : high;
     const uint32_t field = __builtin_amdgcn_alignbit(high, low, bit & 31) & ((1u << ROW_META_BITS) - 1);
-    meta.segmentBits = role.segment ? field : 0u;
+    return segment ? field : 0u;
+}
+
+// rowMeta: the lane's segment offset out of the record just loaded; no-op for the other layouts
+// (two arrays: already in segmentBits; row records: read from LDS by decodeSegment).
+__device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRole& role, WordMeta& meta)
+{
+    if (!p.rowMeta || p.recordPieces) {
+        return;
+    }
+    meta.segmentBits = segmentField(role.segment, meta.segmentBits, meta.packed2, meta.packed3);
 }
 
 constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
@@ -169,7 +185,7 @@ struct StreamRegisters {
 __device__ __forceinline__ void issueStreamLoad(
     const TrainedParams& p, uint32_t sourceStart, uint32_t lane, uint32_t round, u32x4& destination)
 {
-    const uint32_t piecesPerWord = p.slotDwords / 4;
+    const uint32_t piecesPerWord = p.loadPieces;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
     if (round * WAVE < totalPieces && !(p.debugFlags & 4)) {   // wave-uniform
         const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
@@ -198,7 +214,7 @@ __device__ __forceinline__ void issueStreamLoads(
 __device__ __forceinline__ void writeStream(
     const TrainedParams& p, uint32_t* slots, uint32_t lane, uint32_t round, const u32x4& value)
 {
-    const uint32_t piecesPerWord = p.slotDwords / 4;
+    const uint32_t piecesPerWord = p.loadPieces;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
     const uint32_t q = round * WAVE + lane;
     if (q < totalPieces) {
@@ -215,6 +231,17 @@ __device__ __forceinline__ void writeStreams(
     writeStream(p, slots, lane, firstRound + 1, v.r1);
     writeStream(p, slots, lane, firstRound + 2, v.r2);
     writeStream(p, slots, lane, firstRound + 3, v.r3);
+}
+
+// Row records: the lane's segment offset out of the record at the head of its word's LDS slot, once
+// the slot has been written (and fenced). No-op for the other layouts.
+__device__ __forceinline__ void recordSegmentBits(
+    const TrainedParams& p, const uint32_t* slots, const LaneRole& role, WordMeta& meta)
+{
+    if (p.recordPieces) {
+        const uint32_t* slot = slots + role.word * p.slotDwords;
+        meta.segmentBits = segmentField(role.segment, slot[1], slot[2], slot[3]);
+    }
 }
 
 // FAST: codebook of at most 16 centroids and no code longer than 8 bits (2- and
@@ -247,9 +274,14 @@ __device__ __forceinline__ void decodeSegment(
     const bool present = meta.row < p.nRows;
     const uint32_t* slot = slots + role.word * p.slotDwords;
     uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
-    const uint32_t lastWindow = p.slotDwords - 3;
+    uint32_t lastWindow = p.slotDwords - 3;
     const uint32_t rootShift = 32 - p.rootBits;
     uint32_t bitPos = meta.segmentBits;   // streams start on a slot boundary
+    if (p.recordPieces) {
+        // row records: the slot begins with the row's record (read by recordSegmentBits), the bitstream follows it
+        slot += 4;
+        lastWindow -= 4;
+    }
     // byte position of this lane's first group inside the symbol tile
     uint32_t keyOffset = role.word * p.keyRowBytes + role.segment * (p.segmentSymbols * KEY_BITS / 8);
     const uint32_t keyRowEnd = role.spare ? 0 : (role.word + 1) * p.keyRowBytes;
@@ -557,7 +589,7 @@ __global__ void decode_trained(TrainedParams p)
     WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
     unpackMeta(p, role, meta);
 
-    const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
+    const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
         StreamRegisters v;
         issueStreamLoads(p, meta, lane, round, v);
@@ -565,6 +597,7 @@ __global__ void decode_trained(TrainedParams p)
     }
     waveLdsFence();
 
+    recordSegmentBits(p, mem.slots, role, meta);
     decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
     if (MODE == OUT_INDEX) {
         return;
@@ -619,6 +652,7 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     writeStreams(p, mem.slots, lane, 0, streams);
     issueStreamLoads(p, meta1, lane, 0, streams);
     waveLdsFence();
+    recordSegmentBits(p, mem.slots, role, meta0);
 
     // Invariant at the top, for the current tile t:
     //   LDS slots hold the bitstreams of t;
@@ -673,6 +707,7 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
         meta0 = meta1;
         meta1 = meta2;
         waveLdsFence();
+        recordSegmentBits(p, mem.slots, role, meta0);   // the slots hold the next tile since the consume point
     }
 }
 
@@ -752,7 +787,7 @@ __global__ void decode_trained_union(UnionParams u)
         const TrainedParams& p = u.model[m];
         unpackMeta(p, role, meta[m]);
         uint32_t* slots = waveLds + m * u.perModelDwords;
-        const uint32_t rounds = (p.wordsPerWave * (p.slotDwords / 4) + WAVE - 1) / WAVE;
+        const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
         for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
             StreamRegisters v;
             issueStreamLoads(p, meta[m], lane, round, v);
@@ -767,6 +802,7 @@ __global__ void decode_trained_union(UnionParams u)
         const TrainedParams& p = u.model[m];
         uint32_t* slots = waveLds + m * u.perModelDwords;
         uint32_t* keyTile = slots + u.keyTileOffsetDwords[m];
+        recordSegmentBits(p, slots, role, meta[m]);
         decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
             p, reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots, keyTile, role, meta[m]);
         // nibble keys have no code for "absent": remember which words of the tile are
@@ -924,9 +960,11 @@ __global__ void decode_trained_union(UnionParams u)
 }
 
 // Staging: streamStarts + segmentIndex -> rowMeta records (see TrainedParams::rowMeta). One thread per row.
+// With recordPieces != 0 the record goes to piece row * recordPieces of `rowMeta` (= the row-record
+// array) and its first dword holds the row's stream length in bytes instead of a start.
 __global__ void pack_row_meta(
     const uint32_t* streamStarts, const uint16_t* segmentIndex, uint32_t lanesPerWord, unsigned long long nRows,
-    uint32_t* rowMeta)
+    uint32_t* rowMeta, uint32_t recordPieces, const uint32_t* streamBytes)
 {
     const unsigned long long row = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (row >= nRows) {
@@ -942,7 +980,11 @@ __global__ void pack_row_meta(
             offsets[(bit >> 5) + 1] |= static_cast<uint32_t>(shifted >> 32);
         }
     }
-    reinterpret_cast<uint4*>(rowMeta)[row] = make_uint4(streamStarts[row], offsets[0], offsets[1], offsets[2]);
+    if (recordPieces) {
+        reinterpret_cast<uint4*>(rowMeta)[row * recordPieces] = make_uint4(streamBytes[row], offsets[0], offsets[1], offsets[2]);
+    } else {
+        reinterpret_cast<uint4*>(rowMeta)[row] = make_uint4(streamStarts[row], offsets[0], offsets[1], offsets[2]);
+    }
 }
 
 // Staging-time re-pack of the file's bitstreams (byte aligned, insertion order,
@@ -951,7 +993,7 @@ __global__ void pack_row_meta(
 // row (= sorted key) order, stored as big-endian dwords. One wavefront per row.
 __global__ void repack_streams(
     const uint8_t* packed, unsigned long long packedBytes, const uint32_t* valueOffsets, const uint32_t* streamStarts,
-    unsigned long long nRows, uint4* streams)
+    unsigned long long nRows, uint4* streams, uint32_t recordPieces)
 {
     const unsigned long long row = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) / WAVE;
     if (row >= nRows) {
@@ -959,7 +1001,8 @@ __global__ void repack_streams(
     }
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t first = streamStarts[row];
-    const uint32_t pieces = streamStarts[row + 1] - first;
+    // (row records: every row owns recordPieces pieces, the first of them its record)
+    const uint32_t pieces = recordPieces ? recordPieces - 1 : streamStarts[row + 1] - first;
     const unsigned long long source = valueOffsets[row];
     for (uint32_t piece = lane; piece < pieces; piece += WAVE) {
         uint32_t dwords[4];

@@ -146,6 +146,7 @@ struct memb_hip_ctx {
     uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
     bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
+    uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
@@ -348,6 +349,8 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.segmentIndex = ctx->segmentIndex;
     params.indexWide = ctx->indexWide ? 1u : 0u;
     params.rowMeta = ctx->rowMeta;
+    params.recordPieces = ctx->recordPieces;
+    params.loadPieces = ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4;
     params.table = ctx->table;
     params.codebook = ctx->codebook;
     params.nRows = ctx->nRows;
@@ -356,7 +359,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.rootBits = ctx->hostTable.rootBits;
     params.dim = ctx->dim;
     params.slotDwords = ctx->slotDwords;
-    params.slotMagic = magicFor(ctx->slotDwords / 4, 64ull * (ctx->slotDwords / 4) * 5);
+    params.slotMagic = magicFor(params.loadPieces, 64ull * params.loadPieces * 5);
     params.debugFlags = ctx->switches.debugFlags;
     return params;
 }
@@ -406,6 +409,8 @@ int launchTrained(
         const uint32_t group = ctx->fast ? 8 : 4;
         const bool consistent = wordsPerWave >= 1 && wordsPerWave * params.lanesPerWord <= WAVE &&
             params.slotDwords >= 4 && params.slotDwords % 4 == 0 && params.segmentSymbols % group == 0 &&
+            params.loadPieces >= 1 && params.loadPieces * 4 <= params.slotDwords &&
+            (!params.recordPieces || (params.lanesPerWord <= ROW_META_MAX_LANES && params.slotDwords >= 4 * params.recordPieces + 3)) &&
             uint64_t(params.lanesPerWord) * params.segmentSymbols >= params.dim &&
             uint64_t(params.lanesPerWord - 1) * params.segmentSymbols < params.dim &&
             params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
@@ -423,7 +428,7 @@ int launchTrained(
     const uint32_t threads = geometry.waves * WAVE;
     // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
     // (long streams with few lanes per word) take the one-shot kernel.
-    const uint32_t streamRounds = (wordsPerWave * (ctx->slotDwords / 4) + WAVE - 1) / WAVE;
+    const uint32_t streamRounds = (wordsPerWave * params.loadPieces + WAVE - 1) / WAVE;
     const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
     hipError_t status;
     switch (geometry.mode) {
@@ -1051,13 +1056,37 @@ int measureStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
 // Re-packed layout on the device: streamStarts, then the bitstreams themselves (repack_streams).
 int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
 {
-    // Re-packed layout: row r's stream occupies ceil(bytes / 16) pieces from streamStarts[r].
+    // Row records (TrainedParams::recordPieces) where the model allows: at most 8 lanes per word and
+    // streams below 1 KiB (the record's 13-bit offsets), and rows of similar length -- every row then
+    // owns 16 + the longest stream bytes, rounded up to 32 so that a row never touches a third line.
+    // Otherwise (or with MEMB_HIP_ROW_RECORDS=0) the compact layout: row r's stream occupies
+    // ceil(bytes / 16) pieces from streamStarts[r], offsets in rowMeta or the two arrays.
     std::vector<uint32_t> streamStarts(desc->n_rows + 1, 0);
+    uint64_t compactPieces = 0;
+    for (uint64_t r = 0; r < desc->n_rows; ++r) {
+        compactPieces += (ctx->streamBytes[r] + 15) / 16;
+    }
+    const uint32_t recordPieces = ((16 + ctx->maxStreamBytes + 31) / 32) * 2;
+    ctx->recordPieces = 0;
+    if (desc->n_rows && ctx->lanesPerWord > 1 && ctx->lanesPerWord <= ROW_META_MAX_LANES &&
+        uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && envUint("MEMB_HIP_ROW_RECORDS", 1) &&
+        envUint("MEMB_HIP_ROW_META", 1) && ctx->slotDwords >= 4 * recordPieces + 3 &&
+        uint64_t(recordPieces) * desc->n_rows <= (compactPieces + desc->n_rows) * 5 / 4 &&   // at most 25 % padding
+        uint64_t(recordPieces) * (desc->n_rows + 2) < (1ull << 32)) {
+        ctx->recordPieces = recordPieces;
+    }
     {
         uint64_t next = 0;
         for (uint64_t r = 0; r < desc->n_rows; ++r) {
+            if (ctx->recordPieces) {
+                streamStarts[r] = static_cast<uint32_t>(r * ctx->recordPieces + 1);   // the stream follows the record
+                continue;
+            }
             streamStarts[r] = static_cast<uint32_t>(next);
             next += (ctx->streamBytes[r] + 15) / 16;
+        }
+        if (ctx->recordPieces) {
+            next = uint64_t(ctx->recordPieces) * desc->n_rows;
         }
         if (next + ctx->slotDwords / 4 + 1 >= (1ull << 32)) {
                 return fail(MEMB_HIP_ERR_INVALID, "bitstreams too large");
@@ -1100,7 +1129,7 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             const uint64_t blocks = (desc->n_rows * WAVE + threads - 1) / threads;
             hipLaunchKernelGGL(
                 repack_streams, dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, ctx->stream, filePacked,
-                desc->packed_values_bytes, fileOffsets, ctx->streamStarts, desc->n_rows, ctx->streams);
+                desc->packed_values_bytes, fileOffsets, ctx->streamStarts, desc->n_rows, ctx->streams, ctx->recordPieces);
             hipError_t launched = hipGetLastError();
             if (launched == hipSuccess) {
                 launched = hipStreamSynchronize(ctx->stream);
@@ -1227,15 +1256,28 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
     }
     // Lookups read a row's stream start and segment offsets as one 16-byte record with one load
     // per lane: one request per word of a random batch (the two arrays cost two or three), one
-    // per tile of a key-order dump.
+    // per tile of a key-order dump. With row records the same record sits in front of the row's
+    // stream instead and costs no request of its own.
+    const bool records = ctx->recordPieces != 0;
     if (code == MEMB_HIP_OK && desc->n_rows && ctx->lanesPerWord > 1 && ctx->lanesPerWord <= ROW_META_MAX_LANES &&
-        uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && envUint("MEMB_HIP_ROW_META", 1)) {
-        code = deviceAlloc(ctx, &ctx->rowMeta, size_t(desc->n_rows) * 16 + 16);
+        uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && (records || envUint("MEMB_HIP_ROW_META", 1))) {
+        uint32_t* lengths = nullptr;   // per-row stream bytes, staging only
+        if (records) {
+            hipError_t status = hipMalloc(reinterpret_cast<void**>(&lengths), desc->n_rows * 4);
+            if (status != hipSuccess) {
+                code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(status));
+            } else {
+                code = copyToDevice(lengths, ctx->streamBytes.data(), desc->n_rows * 4);
+            }
+        } else {
+            code = deviceAlloc(ctx, &ctx->rowMeta, size_t(desc->n_rows) * 16 + 16);
+        }
         if (code == MEMB_HIP_OK) {
             const uint32_t threads = 256;
             hipLaunchKernelGGL(
                 pack_row_meta, dim3(static_cast<uint32_t>((desc->n_rows + threads - 1) / threads)), dim3(threads), 0,
-                ctx->stream, ctx->streamStarts, ctx->segmentIndex, ctx->lanesPerWord, desc->n_rows, ctx->rowMeta);
+                ctx->stream, ctx->streamStarts, ctx->segmentIndex, ctx->lanesPerWord, desc->n_rows,
+                records ? reinterpret_cast<uint32_t*>(ctx->streams) : ctx->rowMeta, ctx->recordPieces, lengths);
             hipError_t status = hipGetLastError();
             if (status == hipSuccess) {
                 status = hipStreamSynchronize(ctx->stream);
@@ -1243,6 +1285,9 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             if (status != hipSuccess) {
                 code = fail(MEMB_HIP_ERR_DEVICE, std::string("pack_row_meta: ") + hipGetErrorString(status));
             }
+        }
+        if (lengths) {
+            (void)hipFree(lengths);
         }
     }
     return code;
@@ -1281,7 +1326,8 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     // Slot: stream plus the 12-byte window the decoder reads at its last
     // position; whole 16-byte pieces, an odd number of them so that equal
     // positions in consecutive slots fall into different LDS banks.
-    ctx->slotDwords = (((ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
+    // (+ 16 bytes in front for the row's record where the row-record layout is used: stageStreams)
+    ctx->slotDwords = (((16 + ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
     ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
         !envUint("MEMB_HIP_NO_FAST", 0);
     ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
@@ -1289,11 +1335,11 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
 
     code = openDevice(ctx, device);
     if (code == MEMB_HIP_OK) {
+        chooseLanes(ctx, desc);   // before the streams: the layout depends on the lanes per word
         code = stageStreams(ctx, desc);
     }
     const double tRepacked = now();
     if (code == MEMB_HIP_OK) {
-        chooseLanes(ctx, desc);
         code = stageTables(ctx, desc);
     }
     if (code == MEMB_HIP_OK) {
@@ -1426,7 +1472,8 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->lds_bytes_per_block = geometry.ldsBytes;
         // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys>
         const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-        const uint32_t streamRounds = (wordsPerWave * (ctx->slotDwords / 4) + WAVE - 1) / WAVE;
+        const uint32_t loadPieces = ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4;
+        const uint32_t streamRounds = (wordsPerWave * loadPieces + WAVE - 1) / WAVE;
         const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", persistent ? "decode_trained_persistent" : "decode_trained",

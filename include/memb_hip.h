@@ -117,6 +117,9 @@ typedef struct memb_hip_ctx_info {
     uint32_t segment_symbols;    /* trained: symbols decoded by each of those lanes */
     uint32_t lds_bytes_per_block;
     char kernel[96];             /* the kernel a dense device-resident batch runs, spelled as rocprofv3 prints it */
+    uint32_t row_layout;         /* trained: 2 = row records (fixed-size row regions, record in front of the stream),
+                                    1 = compact streams + one 16-byte index record per row, 0 = compact streams + index arrays */
+    uint32_t row_bytes;          /* trained, row records: bytes every row owns */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);

@@ -109,6 +109,8 @@ py::dict contextInfo(memb::Reader& reader)
     result["segment_symbols"] = info.segment_symbols;
     result["lds_bytes_per_block"] = info.lds_bytes_per_block;
     result["kernel"] = std::string(info.kernel);
+    result["row_layout"] = info.row_layout;
+    result["row_bytes"] = info.row_bytes;
     return result;
 }
 

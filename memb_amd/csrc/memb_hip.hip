@@ -1470,6 +1470,8 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->lanes_per_word = ctx->lanesPerWord;
         info->segment_symbols = ctx->segmentSymbols;
         info->lds_bytes_per_block = geometry.ldsBytes;
+        info->row_layout = ctx->recordPieces ? 2u : (ctx->rowMeta ? 1u : 0u);
+        info->row_bytes = ctx->recordPieces * 16;
         // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys>
         const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
         const uint32_t loadPieces = ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4;

@@ -741,6 +741,35 @@ def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
             assert info['lanes_per_word'] == -(-300 // info['segment_symbols'])
 
 
+def test_row_layouts_give_identical_rows(native, make_model, monkeypatch):
+    # row records (fixed-size regions, record in front of the stream), compact streams + rowMeta records,
+    # compact streams + the two index arrays: same bits, host and device buffers, dumps and random rows
+    import torch
+    for bits, distribution in ((2, 'normal'), (4, 'normal'), (6, 'student'), (8, 'student')):
+        path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
+        checker = oracle.OracleReader(path)
+        rng = np.random.default_rng(bits)
+        rows = rng.integers(0, 20000, size=9000).astype(np.uint32)
+        rows[::53] = 0xFFFFFFFF
+        expected = checker.rows_embedding(rows)
+        dump = np.arange(20000, dtype=np.uint32)
+        expected_dump = checker.rows_embedding(dump)
+        sizes = {}
+        for name, env in (('records', {}), ('rowmeta', {'MEMB_HIP_ROW_RECORDS': '0'}), ('arrays', {'MEMB_HIP_ROW_META': '0'})):
+            for key in ('MEMB_HIP_ROW_RECORDS', 'MEMB_HIP_ROW_META'):
+                monkeypatch.delenv(key, raising=False)
+            for key, value in env.items():
+                monkeypatch.setenv(key, value)
+            for persistent in ('1', '0'):
+                monkeypatch.setenv('MEMB_HIP_PERSISTENT', persistent)
+                reader = native.Reader(path)
+                assert bits_equal(reader.rows_embedding(rows), expected), (bits, name, persistent)
+                device_rows = torch.from_numpy(dump.view(np.int32)).cuda()
+                assert bits_equal(reader.rows_embedding_device(device_rows).cpu().numpy(), expected_dump), (bits, name, persistent)
+                sizes[name] = reader.info()['row_layout']
+        assert sizes == {'records': 2, 'rowmeta': 1, 'arrays': 0}, sizes   # the three layouts were really staged
+
+
 def test_generic_path_on_a_small_codebook(native, make_model, monkeypatch):
     # <= 16 centroids normally take the nibble / pair-table variant; the byte-key variant must agree
     path, words = make_model(20000, 300, 'trained', 4)

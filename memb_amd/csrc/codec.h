@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace memb {
@@ -327,16 +328,22 @@ public:
         predict(data, count, result->data());
     }
 
+    // every value on its own: large inputs are split over threads (the result does not depend on it)
     void predict(const float* data, size_t count, uint8_t* result) const
     {
         if (centroids_.empty()) {
             throw std::runtime_error("Attempt to use KMeansClusterizer before fitting");
         }
-        const float* first = splits_.data();
-        const float* last = first + splits_.size();
-        for (size_t i = 0; i < count; ++i) {
-            result[i] = static_cast<uint8_t>(std::lower_bound(first, last, data[i]) - first);
-        }
+        const size_t threads = threadsFor(count);
+        const size_t chunk = (count + threads - 1) / threads;
+        runThreads(threads, [&](size_t t) {
+            const float* first = splits_.data();
+            const float* last = first + splits_.size();
+            const size_t end = std::min(count, (t + 1) * chunk);
+            for (size_t i = std::min(count, t * chunk); i < end; ++i) {
+                result[i] = static_cast<uint8_t>(std::lower_bound(first, last, data[i]) - first);
+            }
+        });
     }
 
     const std::vector<float>& centroids() const { return centroids_; }
@@ -345,18 +352,49 @@ private:
     static constexpr size_t MAX_ITERATIONS = 30;
     static constexpr double SMALL_CLUSTER_FACTOR = 128;
 
+    // Running means in data order (reference src/kmeans.cpp:92-98): a cluster's mean depends on the
+    // order of its own members only, so threads take whole clusters (cluster a -> thread a mod T) and
+    // every mean is the very sequence of fp32 operations the single loop performs.
     void updateCentroids(const std::vector<float>& data, const std::vector<uint8_t>& assignments)
     {
         std::vector<size_t> counts(centroids_.size(), 0);
         std::vector<float> centroids(centroids_.size(), 0);
-        for (size_t i = 0; i < data.size(); ++i) {
-            auto a = assignments[i];
-            float n = static_cast<float>(counts[a]);
-            centroids[a] = n / (n + 1) * centroids[a] + 1 / (n + 1) * data[i];
-            counts[a] += 1;
-        }
+        const size_t threads = std::min(threadsFor(data.size()), std::max<size_t>(centroids_.size(), 1));
+        runThreads(threads, [&](size_t t) {
+            for (size_t i = 0; i < data.size(); ++i) {
+                const size_t a = assignments[i];
+                if (a % threads != t) {
+                    continue;
+                }
+                float n = static_cast<float>(counts[a]);
+                centroids[a] = n / (n + 1) * centroids[a] + 1 / (n + 1) * data[i];
+                counts[a] += 1;
+            }
+        });
         std::sort(centroids.begin(), centroids.end());
         setCentroids(centroids);
+    }
+
+    static size_t threadsFor(size_t count)
+    {
+        return std::max<size_t>(1, std::min<size_t>({std::thread::hardware_concurrency(), size_t(64), count / 65536 + 1}));
+    }
+
+    template <typename F>
+    static void runThreads(size_t threads, F body)
+    {
+        if (threads <= 1) {
+            body(0);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads; ++t) {
+            pool.emplace_back(body, t);
+        }
+        body(0);
+        for (auto& thread : pool) {
+            thread.join();
+        }
     }
 
     void setCentroids(const std::vector<float>& centroids)

@@ -461,10 +461,10 @@ public:
         const size_t threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), wordCount / 4096 + 1));
         const size_t wordsPerThread = (wordCount + threads - 1) / threads;
         std::vector<std::vector<uint64_t>> partialCounts(threads, std::vector<uint64_t>(256, 0));
+        clusterizer.predict(values_.data(), values_.size(), quantized.data());   // threaded inside
         runParallel(threads, [&](size_t t) {
             size_t first = std::min(wordCount, t * wordsPerThread) * dim_;
             size_t last = std::min(wordCount, (t + 1) * wordsPerThread) * dim_;
-            clusterizer.predict(values_.data() + first, last - first, quantized.data() + first);
             for (size_t i = first; i < last; ++i) {
                 partialCounts[t][quantized[i]] += 1;
             }

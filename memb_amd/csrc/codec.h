@@ -361,14 +361,21 @@ private:
         std::vector<float> centroids(centroids_.size(), 0);
         const size_t threads = std::min(threadsFor(data.size()), std::max<size_t>(centroids_.size(), 1));
         runThreads(threads, [&](size_t t) {
+            // (accumulators of its own: neighbouring clusters share cache lines in the common arrays)
+            std::vector<size_t> ownCounts(centroids_.size() + 16, 0);
+            std::vector<float> ownCentroids(centroids_.size() + 32, 0);
             for (size_t i = 0; i < data.size(); ++i) {
                 const size_t a = assignments[i];
                 if (a % threads != t) {
                     continue;
                 }
-                float n = static_cast<float>(counts[a]);
-                centroids[a] = n / (n + 1) * centroids[a] + 1 / (n + 1) * data[i];
-                counts[a] += 1;
+                float n = static_cast<float>(ownCounts[a]);
+                ownCentroids[a] = n / (n + 1) * ownCentroids[a] + 1 / (n + 1) * data[i];
+                ownCounts[a] += 1;
+            }
+            for (size_t a = t; a < centroids_.size(); a += threads) {
+                centroids[a] = ownCentroids[a];
+                counts[a] = ownCounts[a];
             }
         });
         std::sort(centroids.begin(), centroids.end());

@@ -465,17 +465,20 @@ __device__ __forceinline__ void outputTile(
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = tileWords * piecesPerWord;
         float* tileOut = p.out + tileBase * p.ld + p.colOff;
+        const bool noGather = (p.debugFlags & 0x2000) != 0;   // measurement: store constants, no LDS reads
         for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
             uint32_t k[BURST];
             float4 f[BURST];
 #pragma unroll
             for (int u = 0; u < BURST; ++u) {
                 const uint32_t q = min(q0 + WAVE * u, pieces - 1);
-                k[u] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[q] : keyTile[q];
+                k[u] = noGather ? 0u : (FAST ? reinterpret_cast<const uint16_t*>(keyTile)[q] : keyTile[q]);
             }
 #pragma unroll
             for (int u = 0; u < BURST; ++u) {
-                if (FAST) {
+                if (noGather) {
+                    f[u] = make_float4(1.f, 2.f, 3.f, 4.f);
+                } else if (FAST) {
                     const float2 a = pairLds[k[u] & 0xff];
                     const float2 b = pairLds[k[u] >> 8];
                     f[u] = make_float4(a.x, a.y, b.x, b.y);

@@ -1057,7 +1057,9 @@ int measureStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
 int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
 {
     // Row records (TrainedParams::recordPieces) where the model allows: at most 8 lanes per word and
-    // streams below 1 KiB (the record's 13-bit offsets), and rows of similar length -- every row then
+    // streams below 1 KiB (the record's 13-bit offsets), and rows of similar length (the regions may take
+    // 35 % more than the compact layout; the 2-bit model, rows of 1..3 bits per weight, needs 33 % and
+    // still gains 1 % on the key-order dump and 3 % on shuffled rows) -- every row then
     // owns 16 + the longest stream bytes, rounded up to 32 so that a row never touches a third line.
     // Otherwise (or with MEMB_HIP_ROW_RECORDS=0) the compact layout: row r's stream occupies
     // ceil(bytes / 16) pieces from streamStarts[r], offsets in rowMeta or the two arrays.
@@ -1071,7 +1073,8 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
     if (desc->n_rows && ctx->lanesPerWord > 1 && ctx->lanesPerWord <= ROW_META_MAX_LANES &&
         uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && envUint("MEMB_HIP_ROW_RECORDS", 1) &&
         envUint("MEMB_HIP_ROW_META", 1) && ctx->slotDwords >= 4 * recordPieces + 3 &&
-        uint64_t(recordPieces) * desc->n_rows <= (compactPieces + desc->n_rows) * 5 / 4 &&   // at most 25 % padding
+        uint64_t(recordPieces) * desc->n_rows * 100 <=
+            (compactPieces + desc->n_rows) * (100 + envUint("MEMB_HIP_RECORD_PADDING_PERCENT", 35)) &&   // at most 35 % padding
         uint64_t(recordPieces) * (desc->n_rows + 2) < (1ull << 32)) {
         ctx->recordPieces = recordPieces;
     }

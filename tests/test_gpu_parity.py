@@ -768,9 +768,9 @@ def test_row_layouts_give_identical_rows(native, make_model, monkeypatch):
                 assert bits_equal(reader.rows_embedding_device(device_rows).cpu().numpy(), expected_dump), (bits, name, persistent)
                 sizes[name] = reader.info()['row_layout']
         # the layouts were really staged; models whose longest row is far above the average row (heavy
-        # tails, or 2-bit codes of 1..3 bits) keep the compact layout by the 25 % padding rule
+        # tails) keep the compact layout by the 35 % padding rule
         assert sizes['rowmeta'] == 1 and sizes['arrays'] == 0, sizes
-        assert sizes['records'] == 2 if bits == 4 else sizes['records'] in (1, 2), (bits, sizes)
+        assert sizes['records'] == 2 if distribution == 'normal' else sizes['records'] in (1, 2), (bits, sizes)
 
 
 def test_generic_path_on_a_small_codebook(native, make_model, monkeypatch):

@@ -21,8 +21,9 @@
  *
  * Every function returns 0 on success and a non-zero code on failure;
  * memb_hip_last_error() returns the message for the calling thread.
- * There is no CPU fallback: without a usable HIP device every decode entry
- * point fails.
+ * There is no CPU fallback in this library: without a usable HIP device every
+ * decode entry point fails. (The C++ classes above it can decode on the host when
+ * a caller asks them to -- see INTEGRATION.md section 4 -- and then never call in here.)
  */
 #ifndef MEMB_HIP_H
 #define MEMB_HIP_H

@@ -2,8 +2,10 @@
 
 Same Python surface as the reference package (python/memb/__init__.py:1-4):
 Reader, ReadersUnion, Builder, available_compression_strategies. Lookups run as
-HIP kernels; there is no CPU decode path, so the native extension must be
-built (`python build_native.py`) and a HIP device must be present.
+HIP kernels: the native extension must be built (`python build_native.py`) and a
+HIP device must be present -- a reader never falls back to the CPU on its own.
+The reference's host path exists only on request: Reader(path, device='cpu')
+for hosts without a GPU, host_below=N to keep tiny host batches off the GPU.
 """
 import os as _os
 

@@ -1329,8 +1329,9 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     // Slot: stream plus the 12-byte window the decoder reads at its last
     // position; whole 16-byte pieces, an odd number of them so that equal
     // positions in consecutive slots fall into different LDS banks.
-    // (+ 16 bytes in front for the row's record where the row-record layout is used: stageStreams)
-    ctx->slotDwords = (((16 + ctx->maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
+    // (a row-record region -- 16 bytes of record + the longest stream, rounded up to 32: stageStreams --
+    // must fit in front of that window as well)
+    ctx->slotDwords = (((((16 + ctx->maxStreamBytes + 31) / 32) * 32 + 12 + 15) / 16) | 1u) * 4;
     ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
         !envUint("MEMB_HIP_NO_FAST", 0);
     ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, SIX_WORDS, golden_json
+from conftest import REPO, GOLDEN, SIX_WORDS, golden_json
 
 
 def test_strategies_listed_like_reference(native):
@@ -237,6 +237,19 @@ def test_into_calls_refuse_arrays_they_could_not_fill_in_place(native):
         reader.rows_embedding_into(rows, np.zeros((3, 6), dtype=np.float32), 0)
     with pytest.raises(RuntimeError, match='Output must be'):
         reader.batch_embedding_into(words, np.zeros((2, 6), dtype=np.float32), 4)
+
+
+def test_bench_refuses_more_ranks_than_devices_without_touching_a_gpu(native):
+    # `python bench.py --gpus N` with no launcher starts its own ranks; on a host with fewer devices it
+    # says so instead (the parent counts devices, it never initialises one)
+    import subprocess
+    import sys
+    if native.hip_device_count() >= 2:
+        pytest.skip('this host has the devices')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MEMB_BENCH_REHEARSAL')}
+    run = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--small'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert run.returncode != 0 and '--gpus 2: this node has' in run.stderr and not run.stdout.strip()
 
 
 def test_getitem_dispatch_and_tokenizer_layout(native):

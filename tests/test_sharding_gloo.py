@@ -1,10 +1,8 @@
 """The N > 1 path: two processes (gloo), each takes its slice of the batch, slices
-are gathered on the host and must equal the unsharded result. Without a GPU (the
-CPU suite) the per-slice lookup is the CPU checker's -- what is under test there is
-the split, the rendezvous and the gather; the GPU suite runs the same two-process
-worker with every rank's slice decoded by the HIP path (each rank a Reader of its
-own on the device LOCAL_RANK picks, cuda:0 for both on a one-GPU box) and checked
-against the checker."""
+are gathered on the host and must equal the unsharded result. Every rank looks its
+slice up with the product's own Reader and checks it against the CPU checker: in
+the CPU suite a Reader on the host path (device='cpu'), in the GPU suite a Reader
+on the device LOCAL_RANK picks (cuda:0 for both ranks on a one-GPU box)."""
 import os
 import subprocess
 import sys
@@ -40,12 +38,13 @@ WORKER = textwrap.dedent('''
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     checker = oracle.OracleReader({model!r}, 1)
-    reader = checker
+    import memb_amd
     if {use_hip!r}:
-        import memb_amd
         devices = memb_amd.hip_device_count()
         assert devices >= 1
         reader = memb_amd.Reader({model!r}, device=int(os.environ['LOCAL_RANK']) % devices)
+    else:
+        reader = memb_amd.Reader({model!r}, device='cpu')
     keys = checker.keys()
     batch = [keys[(7 * i) % len(keys)] if i % 9 else 'missing-%d' % i for i in range({count})]
     mine = shard_of(batch, rank, world)

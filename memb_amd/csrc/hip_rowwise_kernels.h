@@ -70,8 +70,11 @@ __global__ void dequant_uniform(UniformParams p)
                 const uint32_t row = rowLds[word[u]];
                 packed[u] = 0;
                 if (row < p.nRows) {
-                    packed[u] = *reinterpret_cast<const uint32_t*>(
+                    const uint32_t* source = reinterpret_cast<const uint32_t*>(
                         p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
+                    // non-temporal: a row's bytes are read once per lookup (500 k random rows 0.167 vs 0.178 ms,
+                    // the key-order dump 0.164 vs 0.162)
+                    packed[u] = __builtin_nontemporal_load(source);
                 }
             }
 #pragma unroll
@@ -156,6 +159,7 @@ __global__ void gather_full(FullParams p)
                 const uint32_t row = rowLds[word[u]];
                 f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < p.nRows) {
+                    // (non-temporal loads bought nothing here: 0.246 ms either way on 500 k random rows)
                     f[u] = *reinterpret_cast<const float4*>(
                         p.values + static_cast<unsigned long long>(row) * p.dim + 4 * column[u]);
                 }

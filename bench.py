@@ -473,6 +473,16 @@ def strong_scaling(args, memb_amd, synthetic, rank, world_size, local_rank, dist
     elapsed_kernel = timed(kernel_only)
     kernel_ms = Timer(torch).launches(kernel_only, steps)
     elapsed_d2h = timed(with_d2h)
+
+    # the product's own host-side gather: every rank decodes its slice straight into its rows of a host
+    # matrix (memb_hip_decode_rows: centroid indices over PCIe, expanded by host threads)
+    host_rows = np.zeros((len(mine), reader.dim), dtype=np.float32)
+
+    def host_gather():
+        reader.rows_embedding_into(mine, host_rows)
+
+    elapsed_host = timed(host_gather)
+    host_parity = sampled_parity(path, mine, lambda picks: host_rows[picks], sample=5000)
     nbytes = algorithmic_bytes(library, reader, mine)
     parity = sampled_parity(path, mine, lambda picks: host[torch.from_numpy(picks)].numpy(), sample=5000)
     mine_summary = {
@@ -496,6 +506,9 @@ def strong_scaling(args, memb_amd, synthetic, rank, world_size, local_rank, dist
         'kernel_only': {'value': count * steps / elapsed_kernel, 'unit': 'embeddings/s', 'ms_per_step': elapsed_kernel / steps * 1e3},
         'with_d2h': {'value': count * steps / elapsed_d2h, 'unit': 'embeddings/s', 'ms_per_step': elapsed_d2h / steps * 1e3,
                      'note': 'each rank also copies its slice of the fp32 result into its own pinned host buffer (PCIe-bound); the disjoint slices of those buffers are the host-side gather'},
+        'host_gather': {'value': count * steps / elapsed_host, 'unit': 'embeddings/s', 'ms_per_step': elapsed_host / steps * 1e3,
+                        'parity_rank0': host_parity,
+                        'note': 'Reader.rows_embedding_into per rank: its slice decoded into its rows of a host matrix through the product\'s host-buffer path (centroid indices over PCIe, host threads expand them)'},
         'per_rank': gathered,
     }, build_seconds
 

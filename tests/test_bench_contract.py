@@ -55,6 +55,7 @@ def test_two_ranks_started_without_a_launcher(native, tmp_path):
     assert first['rows'][0] == 0 and first['rows'][1] == second['rows'][0] and second['rows'][1] == 50000
     assert all(entry['parity'].startswith('bit-exact') for entry in strong['per_rank'])
     assert strong['kernel_only']['value'] > strong['with_d2h']['value'] > 0
+    assert strong['host_gather']['value'] > 0 and strong['host_gather']['parity_rank0'].startswith('bit-exact')
 
     strong_main = run_bench(['--gpus', '2', '--small', '--steps', '2', '--warmup', '1', '--scaling', 'strong'],
                             tmp_path, MEMB_BENCH_REHEARSAL='1')

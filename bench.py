@@ -69,6 +69,8 @@ def parse_args():
     parser.add_argument('--no-configs', action='store_true',
                         help='skip the per-configuration array and the strong-scaling leg (profiling runs: only the timed kernel)')
     parser.add_argument('--small', action='store_true', help='shrink every model to 50 000 words (plumbing rehearsal)')
+    parser.add_argument('--dry-launch', action='store_true',
+                        help='--gpus N without a launcher: build, check, print the launch command and what the parent saw; start nothing')
     return parser.parse_args()
 
 
@@ -76,29 +78,64 @@ def parse_args():
 # launching the ranks
 # --------------------------------------------------------------------------------------------
 
+def kfd_gpu_count(topology='/sys/class/kfd/kfd/topology/nodes'):
+    """GPUs of this node as the kernel driver lists them: topology nodes with SIMDs (CPU nodes have
+    simd_count 0). Reads sysfs only -- no HIP, no torch. None when the driver's tree is not there."""
+    try:
+        nodes = os.listdir(topology)
+    except OSError:
+        return None
+    count = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(topology, node, 'properties')) as f:
+                for line in f:
+                    fields = line.split()
+                    if len(fields) == 2 and fields[0] == 'simd_count' and int(fields[1]) > 0:
+                        count += 1
+        except (OSError, ValueError):
+            continue   # a node this user may not read is not a GPU this user can run on
+    return count
+
+
+def hip_runtime_mapped():
+    """Has this process mapped a HIP / HSA runtime library (the first step of touching the GPU)?"""
+    with open('/proc/self/maps') as f:
+        return any('libamdhip64' in line or 'libhsa-runtime64' in line for line in f)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process.
 
-    This parent makes no GPU call (it builds the native code, which needs none, and counts devices,
-    which does not initialise the runtime), so nothing that has touched the GPU is ever replaced by
-    another program; the ranks are ordinary child processes and their output passes through."""
+    This parent never touches the GPU: it imports neither torch nor memb_amd (both map libamdhip64),
+    builds the native code with hipcc (a compiler run, no device) and counts GPUs from the kernel
+    driver's sysfs tree. It checks /proc/self/maps for a HIP runtime before it starts the children and
+    hands what it saw to rank 0 (`launcher` in the JSON line), so nothing that has initialised the
+    GPU is ever the parent of, or replaced by, another GPU program. The ranks are ordinary child
+    processes; their output passes through."""
     import socket
     import build_native
     build_native.build_all()
     rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
-    if not rehearsal:
-        import torch
-        available = torch.cuda.device_count()
-        if available < args.gpus:
-            raise SystemExit('--gpus {}: this node has {} HIP device(s)'.format(args.gpus, available))
+    available = kfd_gpu_count()
+    if not rehearsal and available is not None and available < args.gpus:
+        raise SystemExit('--gpus {}: this node has {} GPU(s) (kfd topology)'.format(args.gpus, available))
     with socket.socket() as probe:
         probe.bind(('127.0.0.1', 0))
         port = probe.getsockname()[1]
     command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MEMB_BENCH_PREBUILT='1')
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + \
+        [argument for argument in sys.argv[1:] if argument != '--dry-launch']
+    launcher = {'started_by': 'bench.py (child processes)', 'parent_mapped_hip_runtime': hip_runtime_mapped(),
+                'gpus_in_kfd_topology': available, 'parent_imported_torch': 'torch' in sys.modules}
+    if launcher['parent_mapped_hip_runtime']:
+        raise SystemExit('bench.py: the launching process has a HIP runtime mapped; refusing to start GPU ranks from it')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MEMB_BENCH_PREBUILT='1', MEMB_BENCH_LAUNCHER=json.dumps(launcher))
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '8')
+    if args.dry_launch:
+        print(json.dumps({'launcher': launcher, 'command': command}))
+        return 0
     return subprocess.run(command, env=env).returncode
 
 
@@ -736,6 +773,8 @@ def main():
         'cpu_baseline': baseline,
         'parity_vs_cpu_checker': parity,
         'ranks_seen': len(per_rank),
+        'launcher': json.loads(os.environ['MEMB_BENCH_LAUNCHER']) if os.environ.get('MEMB_BENCH_LAUNCHER') else
+                    {'started_by': 'torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'python bench.py'},
         'per_rank': per_rank,
         'strong_scaling': strong,
         'configs': configs,

@@ -50,7 +50,7 @@ def _hipcc():
     raise RuntimeError('hipcc not found: the HIP library cannot be built')
 
 
-def build_hip_library(force=False):
+def build_hip_library(force=False, extra_flags=()):
     sources = [os.path.join(CSRC, name) for name in
                ('memb_hip.hip', 'hip_device_common.h', 'hip_trained_kernels.h', 'hip_rowwise_kernels.h',
                 'hip_host_path.h', 'worker_pool.h', 'codec.h', 'wire.h')]
@@ -60,7 +60,7 @@ def build_hip_library(force=False):
             _hipcc(), '--offload-arch=' + GPU_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
             # uniform dequantisation must stay four separately rounded IEEE operations
             '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt',
-            '-Wno-unused-value', '-Wno-align-mismatch', '-Wno-pass-failed',
+            '-Wno-unused-value', '-Wno-align-mismatch', '-Wno-pass-failed', *extra_flags,
             '-o', HIP_LIBRARY, os.path.join(CSRC, 'memb_hip.hip'),
         ])
     return HIP_LIBRARY

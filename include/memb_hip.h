@@ -102,8 +102,22 @@ typedef struct memb_hip_full_desc {
     const memb_hip_full_row* rows;
 } memb_hip_full_desc;
 
-/* Facts about a context, for reporting (bench.py) and tests. */
+/*
+ * Version of this interface: bumped whenever a struct of this header changes size or layout,
+ * or an entry point changes meaning. 3 = round 3 (memb_hip_ctx_info gained struct_size;
+ * memb_hip_ctx_set_option and the builder entry points were added).
+ */
+#define MEMB_HIP_ABI_VERSION 3
+int memb_hip_abi_version(void);
+
+/*
+ * Facts about a context, for reporting (bench.py) and tests. The caller sets struct_size to
+ * sizeof(memb_hip_ctx_info) as ITS header declares it; the library fills at most that many
+ * bytes, so a client built against an older (shorter) declaration is never written past its
+ * struct, and writes back the number of bytes it filled.
+ */
 typedef struct memb_hip_ctx_info {
+    uint32_t struct_size;
     int32_t device;
     uint32_t storage;            /* 1 full, 2 uniform, 3 trained (wire::Storage tags) */
     uint32_t dim;
@@ -135,6 +149,20 @@ int memb_hip_ctx_create_full(memb_hip_ctx** ctx, int device, const memb_hip_full
 void memb_hip_ctx_destroy(memb_hip_ctx* ctx);
 
 int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
+
+/*
+ * Tuning knobs of a live context (results never depend on them). Unknown names and values
+ * out of range return MEMB_HIP_ERR_INVALID and change nothing.
+ *   "nt_loads"        0 / 1   non-temporal loads of bitstreams and index records (persistent kernel)
+ *   "waves_per_block" 0 = choose, or 1, 2, 4, 8
+ *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
+ *   "persistent"      0 / 1   one tile per wavefront instead of the persistent pipeline
+ *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)
+ * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug",
+ * the measurement switches of hip_trained_kernels.h; the shipped library refuses it.
+ * Not thread-safe against lookups running on the same context.
+ */
+int memb_hip_ctx_set_option(memb_hip_ctx* ctx, const char* name, uint64_t value);
 
 /*
  * Batch lookup, host buffers (the reference's calling convention: caller-owned

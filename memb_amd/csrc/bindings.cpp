@@ -90,7 +90,8 @@ py::dict contextInfo(memb::Reader& reader)
         result["kernel"] = "host decode (" + reader.storageName() + ")";
         return result;
     }
-    memb_hip_ctx_info info;
+    memb_hip_ctx_info info{};
+    info.struct_size = sizeof(info);
     if (memb_hip_ctx_get_info(reader.deviceContext(), &info) != MEMB_HIP_OK) {
         throw std::runtime_error(memb_hip_last_error());
     }
@@ -234,6 +235,14 @@ PYBIND11_MODULE(_memb, m) {
         .def("host_rows_decoded", [](memb::Reader& reader) { return reader.hostRowsDecoded(); })
         .def("storage_name", [](memb::Reader& reader) { return reader.storageName(); })
         .def("info", &contextInfo)
+        .def(
+            "set_option",
+            [](memb::Reader& reader, const std::string& name, uint64_t value) {
+                if (memb_hip_ctx_set_option(reader.deviceContext(), name.c_str(), value) != MEMB_HIP_OK) {
+                    throw std::runtime_error(memb_hip_last_error());
+                }
+            },
+            "tuning knob of the device context (include/memb_hip.h: memb_hip_ctx_set_option)")
         .def("has_word_index", [](memb::Reader& reader) { return reader.hasWordIndex(); })
         .def(
             "context_handle",

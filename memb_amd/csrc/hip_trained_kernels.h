@@ -48,10 +48,38 @@ struct TrainedParams {
     uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
     uint32_t indexSegmentSymbols;
     uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
-    uint32_t debugFlags;      // measurement only (MEMB_HIP_DEBUG): 1 = skip decode, 2 = skip output
+    uint32_t debugFlags;      // measurement builds only (MEMB_HIP_MEASURE; see measureFlags below)
     uint32_t accumulate;      // epilogue: add to what the output already holds ...
     float divisor;            // ... and / or divide by this (0 = no division)
 };
+
+// Measurement switches (skip the decode, skip the output, store policies ...; the list is in front of
+// storeOutput16). They exist in builds with -DMEMB_HIP_MEASURE only (tools/perf/build_measure.py): the
+// shipped library folds every one of these branches away, so no environment variable or option can make
+// it write anything but the decoded rows.
+__device__ __forceinline__ uint32_t measureFlags(const TrainedParams& p)
+{
+#ifdef MEMB_HIP_MEASURE
+    return p.debugFlags;
+#else
+    (void)p;
+    return 0u;
+#endif
+}
+
+// One 16-byte piece of a row's bitstream (or an index record). NT: non-temporal (`global_load_dwordx4 ... nt`).
+// A template argument, not a run-time select: `flag ? *p : __builtin_nontemporal_load(p)` is merged by
+// LLVM into ONE plain load (round 2 shipped exactly that and believed it was measuring nt loads);
+// tests/test_isa.py counts the nt loads in the compiled kernels.
+template <bool NT>
+__device__ __forceinline__ u32x4 loadPiece(const u32x4* source)
+{
+    if constexpr (NT) {
+        return __builtin_nontemporal_load(source);
+    } else {
+        return *source;
+    }
+}
 
 // OUT_KEYS: no codebook gather -- `out` receives the symbol tile itself, dense rows of
 // keyRowBytes (one centroid index per byte, or per nibble when FAST), for the host-buffer
@@ -95,7 +123,7 @@ __device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned
     if (role.spare || index >= p.n) {
         return MISSING;
     }
-    return p.rows && !(p.debugFlags & 4) ? p.rows[index] : static_cast<uint32_t>(index);
+    return p.rows && !(measureFlags(p) & 4) ? p.rows[index] : static_cast<uint32_t>(index);
 }
 
 constexpr uint32_t ROW_META_BITS = 13;        // a segment offset inside a rowMeta record: streams below 1 KiB
@@ -110,6 +138,7 @@ struct WordMeta {
 };
 
 // Issues the loads only; the values may be used after unpackMeta.
+template <bool NT>
 __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_t row, const LaneRole& role)
 {
     WordMeta meta;
@@ -118,7 +147,7 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     meta.segmentBits = 0;
     meta.packed2 = 0;
     meta.packed3 = 0;
-    if (p.debugFlags & 4) {
+    if (measureFlags(p) & 4) {
         return meta;
     }
     if (p.recordPieces) {   // row records: the address is arithmetic, the offsets come with the stream
@@ -127,7 +156,7 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     }
     if (row < p.nRows && p.rowMeta) {
         const u32x4* source = reinterpret_cast<const u32x4*>(p.rowMeta) + row;
-        const u32x4 record = (p.debugFlags & 0x100) ? *source : __builtin_nontemporal_load(source);
+        const u32x4 record = loadPiece<NT>(source);
         meta.start = record.x;
         meta.segmentBits = record.y;
         meta.packed2 = record.z;
@@ -182,32 +211,31 @@ struct StreamRegisters {
 // rows' streams, which is harmless; the array ends with a guard of one slot).
 // Absent words read the start of the array and never emit what they decode;
 // lanes past the tile's last piece re-read its last piece.
+template <bool NT>
 __device__ __forceinline__ void issueStreamLoad(
     const TrainedParams& p, uint32_t sourceStart, uint32_t lane, uint32_t round, u32x4& destination)
 {
     const uint32_t piecesPerWord = p.loadPieces;
     const uint32_t totalPieces = p.wordsPerWave * piecesPerWord;
-    if (round * WAVE < totalPieces && !(p.debugFlags & 4)) {   // wave-uniform
+    if (round * WAVE < totalPieces && !(measureFlags(p) & 4)) {   // wave-uniform
         const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
         const uint32_t w = fastDivide(q, p.slotMagic, piecesPerWord);
         const uint32_t piece = q - w * piecesPerWord;
         const uint32_t wordStart = __shfl(sourceStart, w * p.lanesPerWord);
-        // non-temporal: a row's bitstream is read once per lookup, and a batch streams through far more
-        // of them than the caches hold; without the hint they push each other and the output lines around
-        // (-2 % on the key-order dump, -4 % on shuffled rows, in steady state and with cold caches alike)
         const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
-        destination = (p.debugFlags & 0x100) ? *source : __builtin_nontemporal_load(source);
+        destination = loadPiece<NT>(source);
     }
 }
 
+template <bool NT>
 __device__ __forceinline__ void issueStreamLoads(
     const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, StreamRegisters& v)
 {
     const uint32_t sourceStart = meta.row < p.nRows ? meta.start : 0u;
-    issueStreamLoad(p, sourceStart, lane, firstRound + 0, v.r0);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 1, v.r1);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 2, v.r2);
-    issueStreamLoad(p, sourceStart, lane, firstRound + 3, v.r3);
+    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 0, v.r0);
+    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 1, v.r1);
+    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 2, v.r2);
+    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 3, v.r3);
 }
 
 // Into the LDS slots (already big-endian dwords, so the decoder extracts bits with plain shifts).
@@ -450,9 +478,9 @@ __device__ __forceinline__ void outputTile(
         absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
     }
     const bool checkWords = FAST && absent != 0;
-    uint32_t storePolicy = (p.debugFlags >> 4) & 7;   // wave-uniform
-    if (p.debugFlags & 0x80) {
-        storePolicy = sequentialTile ? storePolicy : (p.debugFlags >> 10) & 7;
+    uint32_t storePolicy = (measureFlags(p) >> 4) & 7;   // wave-uniform
+    if (measureFlags(p) & 0x80) {
+        storePolicy = sequentialTile ? storePolicy : (measureFlags(p) >> 10) & 7;
     }
 
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
@@ -465,7 +493,7 @@ __device__ __forceinline__ void outputTile(
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = tileWords * piecesPerWord;
         float* tileOut = p.out + tileBase * p.ld + p.colOff;
-        const bool noGather = (p.debugFlags & 0x2000) != 0;   // measurement: store constants, no LDS reads
+        const bool noGather = (measureFlags(p) & 0x2000) != 0;   // measurement: store constants, no LDS reads
         for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
             uint32_t k[BURST];
             float4 f[BURST];
@@ -569,6 +597,10 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
     return result;
 }
 
+// Stream loads of the kernels that process one tile per wavefront (decode_trained, decode_trained_union):
+// plain. (The persistent kernel has both forms, chosen per launch: memb_hip_ctx_set_option "nt_loads".)
+constexpr bool ONE_TILE_NT_LOADS = false;
+
 // One-shot kernel: one tile per wavefront. Used to build the segment index
 // (OUT_INDEX) and for tiles too wide for the persistent kernel's registers.
 template <bool HAS_SUB, int MODE, bool FAST>
@@ -589,13 +621,13 @@ __global__ void decode_trained(TrainedParams p)
         static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
 
     const LaneRole role = laneRole(p, lane);
-    WordMeta meta = loadWordMeta(p, loadTileRow(p, tile, role), role);
+    WordMeta meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, loadTileRow(p, tile, role), role);
     unpackMeta(p, role, meta);
 
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
         StreamRegisters v;
-        issueStreamLoads(p, meta, lane, round, v);
+        issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, round, v);
         writeStreams(p, mem.slots, lane, round, v);
     }
     waveLdsFence();
@@ -622,7 +654,7 @@ __global__ void decode_trained(TrainedParams p)
 #define MEMB_HIP_PERSISTENT_BOUNDS
 #endif
 
-template <bool HAS_SUB, int MODE, bool FAST>
+template <bool HAS_SUB, int MODE, bool FAST, bool NT>
 __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -636,7 +668,7 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     // Measurement (debugFlags bit 3): the wavefronts of a block meet at a barrier before every
     // output phase, so that the block's adjacent tiles reach memory together; every wavefront of
     // the block then makes the same number of rounds (idle ones past the end of the batch).
-    const bool syncOutput = (p.debugFlags & 8) != 0;
+    const bool syncOutput = (measureFlags(p) & 8) != 0;
     unsigned long long blockTile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE);
     if (syncOutput ? blockTile >= tiles : tile >= tiles) {
         return;
@@ -645,15 +677,15 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
 
     // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
     uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
-    WordMeta meta0 = loadWordMeta(p, loadTileRow(p, tile, role), role);
-    WordMeta meta1 = loadWordMeta(p, loadTileRow(p, tile + stride, role), role);
-    WordMeta metaLoading = loadWordMeta(p, loadTileRow(p, tile + 2 * stride, role), role);
+    WordMeta meta0 = loadWordMeta<NT>(p, loadTileRow(p, tile, role), role);
+    WordMeta meta1 = loadWordMeta<NT>(p, loadTileRow(p, tile + stride, role), role);
+    WordMeta metaLoading = loadWordMeta<NT>(p, loadTileRow(p, tile + 2 * stride, role), role);
     unpackMeta(p, role, meta0);
     unpackMeta(p, role, meta1);
     StreamRegisters streams;
-    issueStreamLoads(p, meta0, lane, 0, streams);
+    issueStreamLoads<NT>(p, meta0, lane, 0, streams);
     writeStreams(p, mem.slots, lane, 0, streams);
-    issueStreamLoads(p, meta1, lane, 0, streams);
+    issueStreamLoads<NT>(p, meta1, lane, 0, streams);
     waveLdsFence();
     recordSegmentBits(p, mem.slots, role, meta0);
 
@@ -671,7 +703,7 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
         const uint32_t tileWords =
             live ? static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase)) : 0u;
 
-        if (live && !(p.debugFlags & 1)) {
+        if (live && !(measureFlags(p) & 1)) {
             decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta0);
         }
         waveLdsFence();
@@ -694,7 +726,7 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
         if (syncOutput) {
             __syncthreads();
         }
-        if (live && !(p.debugFlags & 2)) {
+        if (live && !(measureFlags(p) & 2)) {
             // rows of the tile consecutive (a dump in key order, or a run of one)?
             const uint32_t firstRow = __shfl(meta0.row, 0);
             const bool sequentialTile = __all(role.spare || meta0.row == firstRow + role.word);
@@ -704,8 +736,8 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
         __builtin_amdgcn_sched_barrier(0);
 
         // next round of loads; each uses what the previous round fetched
-        issueStreamLoads(p, meta2, lane, 0, streams);          // stream bytes of t + 2
-        metaLoading = loadWordMeta(p, row3, role);              // offsets of t + 3
+        issueStreamLoads<NT>(p, meta2, lane, 0, streams);          // stream bytes of t + 2
+        metaLoading = loadWordMeta<NT>(p, row3, role);              // offsets of t + 3
         rowLoading = loadTileRow(p, tile + 4 * stride, role);   // row ids of t + 4
         meta0 = meta1;
         meta1 = meta2;
@@ -783,7 +815,7 @@ __global__ void decode_trained_union(UnionParams u)
     }
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
-        meta[m] = loadWordMeta(u.model[m], rows[m], role);
+        meta[m] = loadWordMeta<ONE_TILE_NT_LOADS>(u.model[m], rows[m], role);
     }
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
@@ -793,7 +825,7 @@ __global__ void decode_trained_union(UnionParams u)
         const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
         for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
             StreamRegisters v;
-            issueStreamLoads(p, meta[m], lane, round, v);
+            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta[m], lane, round, v);
             writeStreams(p, slots, lane, round, v);
         }
     }

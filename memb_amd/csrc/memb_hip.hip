@@ -109,8 +109,10 @@ uint32_t envUint(const char* name, uint32_t fallback)
 // when a context is created.
 struct Switches {
     uint32_t waves = 0;            // MEMB_HIP_WAVES: force the wavefronts per block (0 = choose)
-    uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG: 1 = skip decode, 2 = skip output
+    uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
     bool persistent = true;        // MEMB_HIP_PERSISTENT
+    bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
+    uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -189,6 +191,21 @@ struct TrainedGeometry {
 uint32_t roundUp4(uint32_t v)
 {
     return (v + 3) / 4 * 4;
+}
+
+// LDS dwords of one word's bitstream slot: the stream plus the 12-byte window the decoder reads
+// at its last position, whole 16-byte pieces, an odd number of them so that equal positions in
+// consecutive slots fall into different LDS banks.
+uint32_t compactSlotDwords(uint32_t maxStreamBytes)
+{
+    return (((maxStreamBytes + 12 + 15) / 16) | 1u) * 4;
+}
+
+// Same with a row record in front (16 bytes of record + the longest stream, rounded up to 32:
+// stageStreams), which must fit in front of that window as well.
+uint32_t recordSlotDwords(uint32_t maxStreamBytes)
+{
+    return (((((16 + maxStreamBytes + 31) / 32) * 32 + 12 + 15) / 16) | 1u) * 4;
 }
 
 // symbol tile of one wave: rows of dim bytes (dword aligned) or dim / 2 bytes (FAST)
@@ -282,7 +299,7 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
     return hipGetLastError();
 }
 
-template <bool HAS_SUB, int MODE, bool FAST>
+template <bool HAS_SUB, int MODE, bool FAST, bool NT>
 hipError_t launchPersistentVariant(
     const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
@@ -292,14 +309,14 @@ hipError_t launchPersistentVariant(
     static thread_local uint32_t configuredLds = 0;
     int device = 0;
     (void)hipGetDevice(&device);
-    const void* kernel = reinterpret_cast<const void*>(&decode_trained_persistent<HAS_SUB, MODE, FAST>);
+    const void* kernel = reinterpret_cast<const void*>(&decode_trained_persistent<HAS_SUB, MODE, FAST, NT>);
     if (configuredDevice != device || configuredThreads != threads || configuredLds != ldsBytes) {
         hipError_t status = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (status != hipSuccess) {
             return status;
         }
         status = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &blocksPerCu, decode_trained_persistent<HAS_SUB, MODE, FAST>, static_cast<int>(threads), ldsBytes);
+            &blocksPerCu, decode_trained_persistent<HAS_SUB, MODE, FAST, NT>, static_cast<int>(threads), ldsBytes);
         if (status != hipSuccess) {
             return status;
         }
@@ -309,11 +326,24 @@ hipError_t launchPersistentVariant(
         configuredLds = ldsBytes;
     }
     // as many blocks as are resident at once; each wavefront strides over the tiles
-    const uint32_t resident = static_cast<uint32_t>(blocksPerCu) * ctx->cuCount;
+    uint32_t perCu = static_cast<uint32_t>(blocksPerCu);
+    if (ctx->switches.blocksPerCu) {
+        perCu = std::min(perCu, ctx->switches.blocksPerCu);
+    }
+    const uint32_t resident = perCu * ctx->cuCount;
     const uint32_t blocks = std::min(tileBlocks, resident);
     hipLaunchKernelGGL(
-        (decode_trained_persistent<HAS_SUB, MODE, FAST>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+        (decode_trained_persistent<HAS_SUB, MODE, FAST, NT>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
+}
+
+template <bool HAS_SUB, int MODE, bool FAST>
+hipError_t launchPersistentLoads(
+    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    return ctx->switches.ntLoads
+        ? launchPersistentVariant<HAS_SUB, MODE, FAST, true>(ctx, params, tileBlocks, threads, ldsBytes, stream)
+        : launchPersistentVariant<HAS_SUB, MODE, FAST, false>(ctx, params, tileBlocks, threads, ldsBytes, stream);
 }
 
 template <int MODE>
@@ -321,11 +351,11 @@ hipError_t launchPersistentMode(
     const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
 {
     if (ctx->fast) {
-        return launchPersistentVariant<false, MODE, true>(ctx, params, blocks, threads, ldsBytes, stream);
+        return launchPersistentLoads<false, MODE, true>(ctx, params, blocks, threads, ldsBytes, stream);
     }
     return ctx->byteTable.hasSubTables
-        ? launchPersistentVariant<true, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream)
-        : launchPersistentVariant<false, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream);
+        ? launchPersistentLoads<true, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream)
+        : launchPersistentLoads<false, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream);
 }
 
 template <int MODE>
@@ -849,8 +879,12 @@ Switches readSwitches()
 {
     Switches switches;
     switches.waves = envUint("MEMB_HIP_WAVES", 0);
+#ifdef MEMB_HIP_MEASURE
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
+#endif
     switches.persistent = envUint("MEMB_HIP_PERSISTENT", 1) != 0;
+    switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
+    switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1077,6 +1111,10 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             (compactPieces + desc->n_rows) * (100 + envUint("MEMB_HIP_RECORD_PADDING_PERCENT", 35)) &&   // at most 35 % padding
         uint64_t(recordPieces) * (desc->n_rows + 2) < (1ull << 32)) {
         ctx->recordPieces = recordPieces;
+    } else {
+        // compact layout: the slot holds the stream and the decoder's last window only (no record, no
+        // rounding to 32), so lookups copy two pieces per word less and the wavefronts need less LDS
+        ctx->slotDwords = compactSlotDwords(ctx->maxStreamBytes);
     }
     {
         uint64_t next = 0;
@@ -1098,7 +1136,28 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
     }
     const size_t streamPieces = size_t(streamStarts[desc->n_rows]) + ctx->slotDwords / 4 + 1;   // + guard of one slot
 
-    int code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
+    // Placement experiments (tools/perf/ab3.py): MEMB_HIP_STREAM_ALIGN = power of two the array's first
+    // byte is aligned to (hipMalloc gives 2 MiB for large blocks), MEMB_HIP_STREAM_OFFSET = bytes added
+    // to that (multiple of 256).
+    const size_t align = envUint("MEMB_HIP_STREAM_ALIGN", 0);
+    const size_t offset = envUint("MEMB_HIP_STREAM_OFFSET", 0) / 256 * 256;
+    int code;
+    if ((align & (align - 1)) == 0 && (align || offset)) {
+        uint8_t* raw = nullptr;
+        code = deviceAlloc(ctx, &raw, streamPieces * 16 + align + offset);
+        if (code == MEMB_HIP_OK) {
+            uintptr_t first = reinterpret_cast<uintptr_t>(raw);
+            if (align) {
+                first = (first + align - 1) / align * align;
+            }
+            ctx->streams = reinterpret_cast<uint4*>(first + offset);
+        }
+    } else {
+        code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
+    }
+    if (ctx->switches.verbose) {
+        std::fprintf(stderr, "memb_hip: stream array at %p, %zu bytes\n", static_cast<void*>(ctx->streams), streamPieces * 16);
+    }
     uint8_t* filePacked = nullptr;      // temporary device copies of the file's arrays
     uint32_t* fileOffsets = nullptr;
     if (code == MEMB_HIP_OK) {
@@ -1211,9 +1270,12 @@ int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         code = copyToDevice(ctx->table, expanded.data(), expanded.size() * 4);
     }
     if (code == MEMB_HIP_OK && !ctx->fast) {
-        code = deviceAlloc(ctx, &ctx->table32, ctx->byteTable.entries.size() * 4);
+        // (setUpLds copies whole 16-byte pieces: the device copy is padded to packedTableDwords like the LDS image)
+        std::vector<uint32_t> padded(ctx->byteTable.entries);
+        padded.resize(packedTableDwords(ctx), 0);
+        code = deviceAlloc(ctx, &ctx->table32, padded.size() * 4);
         if (code == MEMB_HIP_OK) {
-            code = copyToDevice(ctx->table32, ctx->byteTable.entries.data(), ctx->byteTable.entries.size() * 4);
+            code = copyToDevice(ctx->table32, padded.data(), padded.size() * 4);
         }
     }
     if (code == MEMB_HIP_OK) {
@@ -1326,12 +1388,8 @@ int ctx_create_trained_checked(memb_hip_ctx** out, int device, const memb_hip_tr
     if (code != MEMB_HIP_OK) {
         return code;
     }
-    // Slot: stream plus the 12-byte window the decoder reads at its last
-    // position; whole 16-byte pieces, an odd number of them so that equal
-    // positions in consecutive slots fall into different LDS banks.
-    // (a row-record region -- 16 bytes of record + the longest stream, rounded up to 32: stageStreams --
-    // must fit in front of that window as well)
-    ctx->slotDwords = (((((16 + ctx->maxStreamBytes + 31) / 32) * 32 + 12 + 15) / 16) | 1u) * 4;
+    // (sized for row records first: stageStreams shrinks it when the model stays on the compact layout)
+    ctx->slotDwords = recordSlotDwords(ctx->maxStreamBytes);
     ctx->fast = desc->n_centroids <= 16 && ctx->hostTable.maxCodeBits <= 8 && !ctx->hostTable.hasSubTables &&
         !envUint("MEMB_HIP_NO_FAST", 0);
     ctx->tableDwords = static_cast<uint32_t>((2 * ctx->hostTable.entries.size() + 3) / 4 * 4);
@@ -1452,11 +1510,58 @@ int ctx_create_full_checked(memb_hip_ctx** out, int device, const memb_hip_full_
 }
 
 
+int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
+
 int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
 {
     if (!ctx || !info) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
+    // the caller's declaration of the struct may be shorter (or longer) than this library's
+    const uint32_t callerSize = info->struct_size;
+    if (callerSize < sizeof(uint32_t) || callerSize > 4096) {
+        return fail(MEMB_HIP_ERR_INVALID, "memb_hip_ctx_info.struct_size must be set to sizeof(memb_hip_ctx_info)");
+    }
+    memb_hip_ctx_info filled;
+    const int code = fillInfo(ctx, &filled);
+    if (code != MEMB_HIP_OK) {
+        return code;
+    }
+    const uint32_t bytes = std::min<uint32_t>(callerSize, sizeof(filled));
+    filled.struct_size = bytes;
+    std::memcpy(info, &filled, bytes);
+    return MEMB_HIP_OK;
+}
+
+int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
+{
+    if (!ctx || !name) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    const std::string key(name);
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (key == "nt_loads" && value <= 1) {
+        ctx->switches.ntLoads = value != 0;
+    } else if (key == "waves_per_block" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) {
+        ctx->switches.waves = static_cast<uint32_t>(value);
+    } else if (key == "blocks_per_cu" && value <= 32) {
+        ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
+    } else if (key == "persistent" && value <= 1) {
+        ctx->switches.persistent = value != 0;
+    } else if (key == "host_expand" && value <= 1) {
+        ctx->switches.hostExpand = value != 0;
+#ifdef MEMB_HIP_MEASURE
+    } else if (key == "debug" && value <= 0xFFFFFFFFull) {
+        ctx->switches.debugFlags = static_cast<uint32_t>(value);
+#endif
+    } else {
+        return fail(MEMB_HIP_ERR_INVALID, "unknown option or value out of range: " + key);
+    }
+    return MEMB_HIP_OK;
+}
+
+int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
+{
     std::memset(info, 0, sizeof(*info));
     info->device = ctx->device;
     info->storage = ctx->storage;
@@ -1482,9 +1587,9 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         const uint32_t streamRounds = (wordsPerWave * loadPieces + WAVE - 1) / WAVE;
         const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
         std::snprintf(
-            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", persistent ? "decode_trained_persistent" : "decode_trained",
+            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s%s>", persistent ? "decode_trained_persistent" : "decode_trained",
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
-            ctx->fast ? "true" : "false");
+            ctx->fast ? "true" : "false", !persistent ? "" : (ctx->switches.ntLoads ? ", true" : ", false"));
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
         std::snprintf(
@@ -1770,6 +1875,16 @@ int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full
 int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
 {
     return guarded([&] { return ctx_get_info_checked(ctx, info); });
+}
+
+int memb_hip_abi_version(void)
+{
+    return MEMB_HIP_ABI_VERSION;
+}
+
+int memb_hip_ctx_set_option(memb_hip_ctx* ctx, const char* name, uint64_t value)
+{
+    return guarded([&] { return option_set_checked(ctx, name, value); });
 }
 
 int memb_hip_decode_rows_device(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream)

@@ -193,3 +193,8 @@ class Reader(BaseReader):
     def info(self):
         '''Facts about the device context (stages the model on first call)'''
         return self._impl.info()
+
+    def set_option(self, name, value):
+        '''Tuning knob of the device context ('nt_loads', 'waves_per_block', 'blocks_per_cu', 'persistent',
+        'host_expand': include/memb_hip.h, memb_hip_ctx_set_option); results never depend on them'''
+        self._impl.set_option(str(name), int(value))

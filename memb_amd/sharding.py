@@ -34,9 +34,26 @@ def lookup_shard(reader, words, rank, world_size):
     return reader.batch_embedding(list(shard_of(words, rank, world_size)))
 
 
+_host_groups = {}
+
+
+def host_group(group=None, force_new=False):
+    '''A gloo (host memory, TCP / shared memory) group with the ranks of `group`: the lookup path has no
+    exchange step, so nothing of it may enter RCCL -- also when the job's default group is `nccl`.
+    Creating the group is collective: every rank of `group` must make its first gather_rows call.'''
+    import torch.distributed as dist
+    if dist.get_backend(group) == 'gloo' and not force_new:
+        return group
+    key = id(group) if group is not None else None
+    if key not in _host_groups:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _host_groups[key] = dist.new_group(ranks=ranks, backend='gloo')
+    return _host_groups[key]
+
+
 def gather_rows(local_rows, count, group=None, dst=0):
-    '''Host-side gather of the per-rank slices into one (count, dim) array on rank `dst`
-    (None elsewhere). Uses the process group only to move host buffers.'''
+    '''Host-side gather of the per-rank slices into one (count, dim) array on rank `dst` (a rank of
+    `group`; None is returned elsewhere). Host buffers over a gloo group: no device memory, no RCCL.'''
     import torch
     import torch.distributed as dist
 
@@ -45,17 +62,18 @@ def gather_rows(local_rows, count, group=None, dst=0):
     local_rows = np.ascontiguousarray(local_rows, dtype=np.float32)
     dim = local_rows.shape[1]
     job_size = (count + world_size - 1) // world_size
-    device = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
-    padded = torch.zeros((job_size, dim), dtype=torch.float32, device=device)
-    padded[:local_rows.shape[0]] = torch.from_numpy(local_rows).to(device)
+    padded = torch.zeros((job_size, dim), dtype=torch.float32)
+    padded[:local_rows.shape[0]] = torch.from_numpy(local_rows)
     pieces = [torch.empty_like(padded) for _ in range(world_size)] if rank == dst else None
-    dist.gather(padded, pieces, dst=dst, group=group)
+    hosts = host_group(group)
+    global_dst = dist.get_global_rank(group, dst) if group is not None else dst
+    dist.gather(padded, pieces, dst=global_dst, group=hosts)
     if rank != dst:
         return None
     out = np.empty((count, dim), dtype=np.float32)
     for r, piece in enumerate(pieces):
         start, stop = shard_range(count, r, world_size)
-        out[start:stop] = piece[:stop - start].cpu().numpy()
+        out[start:stop] = piece[:stop - start].numpy()
     return out
 
 

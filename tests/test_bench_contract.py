@@ -10,7 +10,7 @@ import pytest
 
 from conftest import REPO
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                  'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
@@ -26,6 +26,34 @@ def run_bench(arguments, tmp_path, **extra_env):
     return json.loads(lines[0])
 
 
+def test_launcher_parent_never_touches_the_gpu(native, tmp_path):
+    """`python bench.py --gpus 8` as the driver may start it: the parent that spawns the ranks must not have
+    mapped a HIP runtime (it imports neither torch nor memb_amd; devices are counted from sysfs)."""
+    result = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--small', '--dry-launch'],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                            env=dict(os.environ, MEMB_BENCH_REHEARSAL='1'))
+    assert result.returncode == 0, result.stderr[-2000:]
+    plan = json.loads(result.stdout.strip().splitlines()[-1])
+    assert plan['launcher']['parent_mapped_hip_runtime'] is False
+    assert plan['launcher']['parent_imported_torch'] is False
+    command = plan['command']
+    assert command[command.index('--nproc-per-node') + 1] == '8' and '--dry-launch' not in command
+    assert command[command.index('--master-addr') + 1] == '127.0.0.1'
+
+
+def test_gpus_are_counted_from_the_kfd_topology(tmp_path):
+    sys.path.insert(0, REPO)
+    import bench
+    for node, simds in enumerate((0, 0, 1024, 1024, 1024)):
+        directory = tmp_path / 'nodes' / str(node)
+        directory.mkdir(parents=True)
+        (directory / 'properties').write_text('cpu_cores_count {}\nsimd_count {}\nmem_banks_count 1\n'.format(64 if not simds else 0, simds))
+    assert bench.kfd_gpu_count(str(tmp_path / 'nodes')) == 3
+    assert bench.kfd_gpu_count(str(tmp_path / 'absent')) is None
+    assert bench.hip_runtime_mapped() in (False, True)
+
+
+@gpu
 def test_single_gpu_line_and_configuration_array(native, tmp_path):
     line = run_bench(['--small', '--steps', '3', '--warmup', '1'], tmp_path)
     for key in CONTRACT_KEYS:
@@ -45,9 +73,11 @@ def test_single_gpu_line_and_configuration_array(native, tmp_path):
         assert entry['kernel_ms'] > 0 and entry['algorithmic_bytes'] > 0
 
 
+@gpu
 def test_two_ranks_started_without_a_launcher(native, tmp_path):
     line = run_bench(['--gpus', '2', '--small', '--steps', '2', '--warmup', '1'], tmp_path, MEMB_BENCH_REHEARSAL='1')
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and len(line['per_rank']) == 2
+    assert line['launcher']['parent_mapped_hip_runtime'] is False and line['launcher']['parent_imported_torch'] is False
     assert line['parity_vs_cpu_checker'].startswith('bit-exact')
     strong = line['strong_scaling']
     assert strong['scaling'] == 'strong' and strong['ranks_seen'] == 2
@@ -61,3 +91,15 @@ def test_two_ranks_started_without_a_launcher(native, tmp_path):
                             tmp_path, MEMB_BENCH_REHEARSAL='1')
     assert strong_main['scaling'] == 'strong' and strong_main['config']['workload'] == 'glove840b-300d-2bit-fullvocab'
     assert sum(entry['batch'] for entry in strong_main['per_rank']) == 50000
+
+
+@gpu
+def test_four_rank_rehearsal(native, tmp_path):
+    # as many ranks as a one-GPU box allows next to the test process (at most 6 processes may use the card);
+    # the 8-way split itself is covered on the CPU: tests/test_sharding_gloo.py, tests/test_gpu_full_size.py
+    line = run_bench(['--gpus', '4', '--small', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], tmp_path,
+                     MEMB_BENCH_REHEARSAL='1')
+    assert line['n_gpus'] == 4 and line['ranks_seen'] == 4
+    strong = line['strong_scaling']
+    assert [entry['rows'] for entry in strong['per_rank']] == [[0, 12500], [12500, 25000], [25000, 37500], [37500, 50000]]
+    assert all(entry['parity'].startswith('bit-exact') for entry in strong['per_rank'])

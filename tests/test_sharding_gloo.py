@@ -50,6 +50,13 @@ WORKER = textwrap.dedent('''
     mine = shard_of(batch, rank, world)
     local = reader.batch_embedding(mine)
     assert np.array_equal(local.view(np.uint32), checker.batch_embedding(mine).view(np.uint32))
+    if {force_host_group!r}:
+        # what gather_rows does under an `nccl` default group: a gloo group of its own for the host buffers
+        import memb_amd.sharding as sharding
+        sharding._host_groups[None] = sharding.host_group(None, force_new=True)
+        assert dist.get_backend(sharding._host_groups[None]) == 'gloo'
+        original = sharding.host_group
+        sharding.host_group = lambda group=None, force_new=False: sharding._host_groups[None]
     full = gather_rows(local, len(batch), dst=0)
     if rank == 0:
         assert np.array_equal(full.view(np.uint32), checker.batch_embedding(batch).view(np.uint32))
@@ -61,14 +68,15 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def run_two_ranks(tmp_path, use_hip, count, port):
+def run_two_ranks(tmp_path, use_hip, count, port, ranks=2, force_host_group=False):
     model = os.path.join(GOLDEN, 'synthetic_4bit.bin')
     out = str(tmp_path / 'gathered.npy')
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER.format(repo=REPO, model=model, out=out, use_hip=use_hip, count=count))
+    script.write_text(WORKER.format(repo=REPO, model=model, out=out, use_hip=use_hip, count=count,
+                                    force_host_group=force_host_group))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     result = subprocess.run(
-        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node={}'.format(ranks),
          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert result.returncode == 0, result.stdout[-3000:]
@@ -79,6 +87,12 @@ def run_two_ranks(tmp_path, use_hip, count, port):
 
 def test_two_rank_shard_and_host_gather(native, tmp_path):
     run_two_ranks(tmp_path, use_hip=False, count=1001, port=29571)
+
+
+def test_eight_rank_shard_and_gather_over_a_separate_gloo_group(native, tmp_path):
+    # the N = 8 split the driver's scaling run uses (host path, CPU only), gathered through a gloo group made
+    # for the purpose -- what gather_rows does when the job's default group is nccl: the data never enters RCCL
+    run_two_ranks(tmp_path, use_hip=False, count=1003, port=29577, ranks=8, force_host_group=True)
 
 
 @pytest.mark.gpu

@@ -52,7 +52,11 @@ WORKLOADS = {
     'fasttext2m-300d-6bit-fullvocab': (FASTTEXT_WORDS, 6, None),  # BASELINE.json configs[2]
     'glove840b-300d-2bit-fullvocab': (GLOVE_WORDS, 2, None),     # BASELINE.json configs[3]
     'small-4bit': (50000, 4, None),                              # quick functional run
+    # the two below are not single trained models: main() takes their step from special_workload()
+    'union-concat-500k': (GLOVE_WORDS, 4, 500000),               # BASELINE.json configs[4] as the timed step (profiling runs)
+    'uniform-8bit-500k': (500000, 8, None),                      # uniform storage dump as the timed step (profiling runs)
 }
+SPECIAL_WORKLOADS = ('union-concat-500k', 'uniform-8bit-500k')
 STRONG_WORKLOAD = 'glove840b-300d-2bit-fullvocab'
 
 
@@ -452,6 +456,73 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     return results, build_seconds
 
 
+def special_workload(name, args, memb_amd, synthetic, library, torch, np, glove, fasttext):
+    """The two configurations that are not one trained model, as the timed step of the main line (so that
+    `rocprofv3 ... -- python3 bench.py --workload <name> --no-configs` profiles exactly that kernel):
+    returns step(), the output tensor, batch size, algorithmic bytes, a parity callable, a description."""
+    import oracle
+    from memb_amd import _memb
+    cores = os.cpu_count() or 1
+    build_seconds = 0.0
+    if name == 'uniform-8bit-500k':
+        count = min(500000, glove)
+        path, spent = synthetic.cached_model(count, 300, 'uniform', 8)
+        build_seconds += spent
+        reader = memb_amd.Reader(path, device=0)
+        info = reader.info()
+        rows_host = np.arange(len(reader), dtype=np.uint32)
+        rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
+        out = torch.empty((len(rows_host), reader.dim), dtype=torch.float32, device='cuda')
+        return {
+            'step': lambda: reader.rows_embedding_device(rows, out=out), 'out': out, 'n': len(rows_host),
+            'nbytes': algorithmic_bytes(library, reader, rows_host), 'kernel': info['kernel'], 'info': info, 'keep': (reader, rows),
+            'parity': lambda: sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy()),
+            'config': {'vocabulary': len(reader), 'dim': reader.dim, 'storage': 'uniform', 'bits_per_weight': 8,
+                       'batch': 'keys() full dump'},
+            'build_seconds': build_seconds,
+        }
+    path_a, spent = synthetic.cached_model(glove, 300, 'trained', 4)
+    build_seconds += spent
+    path_b, spent = synthetic.cached_model(fasttext, 300, 'trained', 4, seed=4321)
+    build_seconds += spent
+    reader_a = memb_amd.Reader(path_a, device=0)
+    reader_b = memb_amd.Reader(path_b, device=0)
+    info = reader_a.info()
+    reader_b.info()
+    batch = min(500000, len(reader_a))
+    rng = np.random.default_rng(17)   # the batch of measure_union
+    rows_a = rng.integers(0, len(reader_a), size=batch).astype(np.uint32)
+    rows_a[rng.random(batch) < 0.25] = MISSING
+    rows_b = rng.integers(0, len(reader_b), size=batch).astype(np.uint32)
+    rows_b[rng.random(batch) < 0.25] = MISSING
+    ids = [torch.from_numpy(rows_a.view(np.int32)).cuda(), torch.from_numpy(rows_b.view(np.int32)).cuda()]
+    merged = torch.empty((batch, reader_a.dim + reader_b.dim), dtype=torch.float32, device='cuda')
+
+    def step():
+        done = _memb.union_rows_to_device(
+            [reader_a._impl, reader_b._impl], [ids[0].data_ptr(), ids[1].data_ptr()], [0, reader_a.dim], batch,
+            merged.data_ptr(), merged.stride(0), torch.cuda.current_stream().cuda_stream, False)
+        if not done:
+            raise SystemExit('the two models cannot share decode_trained_union')
+
+    def parity():
+        picks = np.sort(np.random.default_rng(5).choice(batch, size=min(20000, batch), replace=False))
+        expected = np.concatenate([
+            oracle.OracleReader(path_a, cores).rows_embedding(np.ascontiguousarray(rows_a[picks])),
+            oracle.OracleReader(path_b, cores).rows_embedding(np.ascontiguousarray(rows_b[picks]))], axis=-1)
+        got = merged[torch.from_numpy(picks).cuda()].cpu().numpy()
+        return 'bit-exact ({} sampled rows)'.format(len(picks)) if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
+
+    return {
+        'step': step, 'out': merged, 'n': batch,
+        'nbytes': algorithmic_bytes(library, reader_a, rows_a) + algorithmic_bytes(library, reader_b, rows_b) - 4 * batch,
+        'kernel': 'decode_trained_union', 'info': info, 'keep': (reader_a, reader_b, ids), 'parity': parity,
+        'config': {'vocabulary': [len(reader_a), len(reader_b)], 'dim': reader_a.dim + reader_b.dim, 'storage': 'trained + trained',
+                   'bits_per_weight': 4, 'batch': '500 000 random words, 25 % missing per model, ReadersUnion concatenate in one launch'},
+        'build_seconds': build_seconds,
+    }
+
+
 # --------------------------------------------------------------------------------------------
 # strong scaling: ONE dump split over the ranks
 # --------------------------------------------------------------------------------------------
@@ -596,31 +667,42 @@ def main():
         words, glove, fasttext = min(words, 50000), 50000, 49999
     os.environ['MEMB_BENCH_CACHE'] = args.cache_dir
     build_seconds = 0.0
-    if rank == 0:
-        path, build_seconds = synthetic.cached_model(words, 300, 'trained', bits)   # written once per box
-    if distributed:
-        dist.barrier()
-    path, _ = synthetic.cached_model(words, 300, 'trained', bits)
-
-    reader, info, open_seconds = open_reader(memb_amd, path, local_rank)
-    dim = reader.dim
-    count = len(reader)
     library = ctypes.CDLL(memb_amd.HIP_LIBRARY_PATH)
     timer = Timer(torch)
-
-    rows_all = batch_rows(count, batch, np)
-    if strong_main:
-        start, stop = shard_range(len(rows_all), rank, world_size)
-        rows_host = np.ascontiguousarray(rows_all[start:stop])
+    special = None
+    if workload in SPECIAL_WORKLOADS:
+        if distributed or strong_main:
+            raise SystemExit('--workload {} is a one-GPU profiling run'.format(workload))
+        args.no_configs = True
+        args.no_cpu_baseline = True
+        special = special_workload(workload, args, memb_amd, synthetic, library, torch, np, glove, fasttext)
+        build_seconds = special['build_seconds']
+        info, open_seconds, out, n, nbytes, step = special['info'], 0.0, special['out'], special['n'], special['nbytes'], special['step']
+        dim, count, rows_host, reader, path = out.shape[1], special['n'], None, None, None
     else:
-        rows_host = rows_all
-    n = len(rows_host)
-    nbytes = algorithmic_bytes(library, reader, rows_host)
-    rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
-    out = torch.empty((n, dim), dtype=torch.float32, device='cuda')
+        if rank == 0:
+            path, build_seconds = synthetic.cached_model(words, 300, 'trained', bits)   # written once per box
+        if distributed:
+            dist.barrier()
+        path, _ = synthetic.cached_model(words, 300, 'trained', bits)
 
-    def step():
-        reader.rows_embedding_device(rows, out=out)
+        reader, info, open_seconds = open_reader(memb_amd, path, local_rank)
+        dim = reader.dim
+        count = len(reader)
+
+        rows_all = batch_rows(count, batch, np)
+        if strong_main:
+            start, stop = shard_range(len(rows_all), rank, world_size)
+            rows_host = np.ascontiguousarray(rows_all[start:stop])
+        else:
+            rows_host = rows_all
+        n = len(rows_host)
+        nbytes = algorithmic_bytes(library, reader, rows_host)
+        rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
+        out = torch.empty((n, dim), dtype=torch.float32, device='cuda')
+
+        def step():
+            reader.rows_embedding_device(rows, out=out)
 
     # Events first, so that nothing but launches lies between the phases below.
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -693,6 +775,8 @@ def main():
         got = out.cpu().numpy()
         parity = 'bit-exact' if np.array_equal(got.view(np.uint32), expected.view(np.uint32)) else 'MISMATCH'
         del expected, got
+    elif special is not None:
+        parity = special['parity']()
     elif not args.no_cpu_baseline:
         # N > 1: no timed CPU leg, but rank 0's output is still checked on a sample of its batch
         parity = sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy())
@@ -734,7 +818,7 @@ def main():
         'vs_baseline': None,
         'dtype': 'u32',
         'data': 'synthetic',
-        'config': {
+        'config': dict({
             'workload': workload,
             'vocabulary': count,
             'dim': dim,
@@ -745,7 +829,7 @@ def main():
                      (', ONE batch split over the ranks as sharding.shard_range does' if strong_main else ''),
             'vectors': 'N(0, 0.4^2) seed 1234, written by memb_amd.Builder',
             'parallelism': 'batch shards, model replicated per GPU, no collective',
-        },
+        }, **(special['config'] if special else {})),
         'roofline': {
             'bound': 'hbm',
             'achieved': achieved_gbps,
@@ -754,7 +838,7 @@ def main():
             'frac': achieved_gbps / HBM_PEAK_GBPS,
             'traffic': traffic,
             'traffic_source': traffic_source,
-            'kernel': info.get('kernel', 'decode_trained_persistent'),
+            'kernel': special['kernel'] if special else info.get('kernel', 'decode_trained_persistent'),
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_min_ms': kernel_ms[0],
             'kernel_median_ms': kernel_ms[len(kernel_ms) // 2],
@@ -780,8 +864,8 @@ def main():
         'configs': configs,
         'host_api': host_api,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
-        'geometry': {k: info[k] for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
-                                          'max_code_bits', 'max_stream_bytes', 'device_bytes')},
+        'geometry': {k: info.get(k) for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
+                                              'max_code_bits', 'max_stream_bytes', 'device_bytes', 'row_layout', 'row_bytes')},
         'model_build_s': build_seconds,
         'reader_open_s': open_seconds,
     }

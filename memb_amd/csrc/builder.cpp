@@ -27,6 +27,12 @@ Builder::Builder(size_t dim, const std::string& storageName, size_t bitsPerWeigh
 // its tests match on them (src/tests.cpp:115-136).
 void Builder::addWord(const std::string& word, const float* embedding, size_t size)
 {
+    std::lock_guard<std::mutex> lock(mutex_);
+    addWordLocked(word, embedding, size);
+}
+
+void Builder::addWordLocked(const std::string& word, const float* embedding, size_t size)
+{
     if (size != dim_) {
         std::ostringstream message;
         message << "Vector dimension (" << size << ") for word " << word << " doesn't match builder dimension ("
@@ -46,9 +52,10 @@ void Builder::addWord(const std::string& word, const std::vector<float>& embeddi
 
 void Builder::addWords(const std::vector<std::string>& words, const float* matrix, size_t rowLength)
 {
+    std::lock_guard<std::mutex> lock(mutex_);
     seen_.reserve(seen_.size() + words.size());
     for (size_t row = 0; row < words.size(); ++row) {
-        addWord(words[row], matrix + row * rowLength, rowLength);
+        addWordLocked(words[row], matrix + row * rowLength, rowLength);
     }
 }
 
@@ -56,6 +63,7 @@ void Builder::addWords(const std::vector<std::string>& words, const float* matri
 // (reference src/flatbuffers/embeddings.fbs:7-19, src/builder.cpp:50-61).
 void Builder::dump(std::ostream& sink)
 {
+    std::lock_guard<std::mutex> lock(mutex_);
     const wire::BufferBuilder::Ref storage = compressor_->finalize();
     buffer_.startTable();
     buffer_.addScalar<uint32_t>(wire::field::Index_dim, static_cast<uint32_t>(dim_));

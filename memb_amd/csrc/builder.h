@@ -7,6 +7,7 @@
 
 #include <iosfwd>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -23,6 +24,8 @@ public:
     void addWord(const std::string& word, const std::vector<float>& embedding);
     // Row i of the row-major matrix (rowLength floats per row) belongs to words[i]; the
     // same checks, word by word, so a failure leaves the words before it added.
+    // (Adding and dumping take a lock: the Python binding releases the GIL around addWords, so calls
+    // from several Python threads are serialised here; the order of words is then the order of calls.)
     void addWords(const std::vector<std::string>& words, const float* matrix, size_t rowLength);
 
     size_t dim() const { return dim_; }
@@ -32,6 +35,7 @@ public:
     void save(const std::string& filename);
 
 private:
+    void addWordLocked(const std::string& word, const float* embedding, size_t size);
     void attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight);
 
     const size_t dim_;
@@ -39,6 +43,7 @@ private:
     wire::BufferBuilder buffer_;
     std::shared_ptr<Compressor> compressor_;
     std::unordered_set<std::string> seen_;
+    std::mutex mutex_;
 };
 
 }  // namespace memb

@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <map>
@@ -450,11 +453,23 @@ public:
         if (wordCount == 0) {
             throw std::runtime_error("Nothing to encode");
         }
+        // MEMB_BUILDER_VERBOSE=1: where the time of a save goes, step by step, on stderr
+        const bool verbose = std::getenv("MEMB_BUILDER_VERBOSE") && std::getenv("MEMB_BUILDER_VERBOSE")[0] == '1';
+        auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double stamp = clock();
+        auto lap = [&](const char* what) {
+            const double now = clock();
+            if (verbose) {
+                std::fprintf(stderr, "memb builder: %-34s %.3f s\n", what, now - stamp);
+            }
+            stamp = now;
+        };
         const size_t sampleWords = std::min(CLUSTER_SAMPLE_SIZE, wordCount);
         std::vector<float> sample(values_.begin(), values_.begin() + sampleWords * dim_);
 
         KMeansClusterizer clusterizer(quantizationLevels_);
         clusterizer.fit(sample);
+        lap("k-means fit (10 000-word sample)");
 
         // quantise everything, count symbol frequencies
         std::vector<uint8_t> quantized(values_.size());
@@ -462,6 +477,7 @@ public:
         const size_t wordsPerThread = (wordCount + threads - 1) / threads;
         std::vector<std::vector<uint64_t>> partialCounts(threads, std::vector<uint64_t>(256, 0));
         clusterizer.predict(values_.data(), values_.size(), quantized.data());   // threaded inside
+        lap("predict (every scalar)");
         runParallel(threads, [&](size_t t) {
             size_t first = std::min(wordCount, t * wordsPerThread) * dim_;
             size_t last = std::min(wordCount, (t + 1) * wordsPerThread) * dim_;
@@ -477,6 +493,7 @@ public:
             }
         }
 
+        lap("symbol histogram + free fp32");
         auto codeLengths = huffmanCodeLengths(counts);
         auto codes = canonicalCodes(codeLengths);
         std::vector<PrefixCode> codebook(256, PrefixCode{0, 0});
@@ -508,6 +525,7 @@ public:
             partialStreams[t].swap(writer.bytes());
         });
         std::vector<uint8_t>().swap(quantized);
+        lap("Huffman code + bit packing");
 
         size_t totalBytes = 0;
         for (const auto& part : partialStreams) {
@@ -532,6 +550,7 @@ public:
             }
         }
 
+        lap("concatenate streams");
         // sort words with std::string::operator< (reference :73-79)
         std::vector<uint32_t> order(wordCount);
         for (size_t w = 0; w < wordCount; ++w) {
@@ -550,6 +569,7 @@ public:
             packedWords.append(words_[w].c_str(), std::strlen(words_[w].c_str()) + 1);
         }
 
+        lap("sort words + offsets");
         std::vector<uint8_t> decoderKeys;
         std::vector<uint32_t> sizeOffsets;
         decoderDescription(codeLengths, &decoderKeys, &sizeOffsets);
@@ -579,7 +599,9 @@ public:
         builder_.addOffset(wire::field::Trained_packed_values, packedValuesRef);
         builder_.addOffset(wire::field::Trained_decoder, decoderRef);
         builder_.addOffset(wire::field::Trained_clusterizer, clusterizerRef);
-        return builder_.endTable();
+        auto result = builder_.endTable();
+        lap("flatbuffer assembly");
+        return result;
     }
 
 private:

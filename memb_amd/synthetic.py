@@ -97,7 +97,9 @@ def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed
     '''Path of a synthetic model in the per-box cache, written on first use.
     Returns (path, seconds spent building; 0.0 when it was already there)'''
     import time
-    name = 'synthetic_{}w_{}d_{}{}bit_{}_{}.bin'.format(count, dim, storage_type, bits_per_weight, distribution, seed)
+    # g2: generator version -- build_file draws blocks >= 1 from generators of their own since round 2, so a
+    # model of more than 200 000 words written by an older tree has other contents under the old name
+    name = 'synthetic_g2_{}w_{}d_{}{}bit_{}_{}.bin'.format(count, dim, storage_type, bits_per_weight, distribution, seed)
     path = os.path.join(cache_dir(), name)
     if os.path.exists(path):
         return path, 0.0

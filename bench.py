@@ -122,8 +122,9 @@ def spawn_ranks(args):
     build_native.build_all()
     rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
     available = kfd_gpu_count()
-    if not rehearsal and available is not None and available < args.gpus:
-        raise SystemExit('--gpus {}: this node has {} GPU(s) (kfd topology)'.format(args.gpus, available))
+    if not rehearsal and (available or 0) < args.gpus:
+        raise SystemExit('--gpus {}: this node has {} GPU(s) ({})'.format(
+            args.gpus, available or 0, 'kfd topology' if available is not None else 'no /sys/class/kfd: no amdgpu compute driver'))
     with socket.socket() as probe:
         probe.bind(('127.0.0.1', 0))
         port = probe.getsockname()[1]

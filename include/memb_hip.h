@@ -156,6 +156,8 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "nt_loads"        0 / 1   non-temporal loads of bitstreams and index records (persistent kernel)
  *   "waves_per_block" 0 = choose, or 1, 2, 4, 8
  *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
+ *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
+ *                     that make the same number of rounds (equal tiles per wavefront)
  *   "persistent"      0 / 1   one tile per wavefront instead of the persistent pipeline
  *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)
  * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug",

@@ -660,11 +660,19 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr bool PACKED = !FAST;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const WaveLds mem = setUpLds<MODE>(p, lds);
 
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
+    const LaneRole role = laneRole(p, lane);
+    // The row ids of the first four tiles before anything else: they depend on nothing, and the copy of
+    // table and codebook into LDS then hides the first of the pipeline's dependent hops (a batch of a few
+    // tiles per wavefront -- 100 000 words -- is mostly prologue).
+    const uint32_t row0 = loadTileRow(p, tile, role);
+    const uint32_t row1 = loadTileRow(p, tile + stride, role);
+    const uint32_t row2 = loadTileRow(p, tile + 2 * stride, role);
+    uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
+    const WaveLds mem = setUpLds<MODE>(p, lds);
     // Measurement (debugFlags bit 3): the wavefronts of a block meet at a barrier before every
     // output phase, so that the block's adjacent tiles reach memory together; every wavefront of
     // the block then makes the same number of rounds (idle ones past the end of the batch).
@@ -673,13 +681,11 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     if (syncOutput ? blockTile >= tiles : tile >= tiles) {
         return;
     }
-    const LaneRole role = laneRole(p, lane);
 
     // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
-    uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
-    WordMeta meta0 = loadWordMeta<NT>(p, loadTileRow(p, tile, role), role);
-    WordMeta meta1 = loadWordMeta<NT>(p, loadTileRow(p, tile + stride, role), role);
-    WordMeta metaLoading = loadWordMeta<NT>(p, loadTileRow(p, tile + 2 * stride, role), role);
+    WordMeta meta0 = loadWordMeta<NT>(p, row0, role);
+    WordMeta meta1 = loadWordMeta<NT>(p, row1, role);
+    WordMeta metaLoading = loadWordMeta<NT>(p, row2, role);
     unpackMeta(p, role, meta0);
     unpackMeta(p, role, meta1);
     StreamRegisters streams;
@@ -765,23 +771,22 @@ constexpr int UNION_MAX_MODELS = 4;
 struct UnionParams {
     TrainedParams model[UNION_MAX_MODELS];   // out / ld shared, colOff per model; n, wordsPerWave etc. equal
     uint32_t tableOffsetDwords[UNION_MAX_MODELS];
-    uint32_t keyTileOffsetDwords[UNION_MAX_MODELS];   // symbol tile inside a model's per-wave area (after its slots)
+    // inside one wavefront's LDS area: where model m's bitstream slots and symbol tile live. The one-tile
+    // kernel gives every model slots of its own; the persistent kernel decodes the models one after the
+    // other out of ONE set of slots (the largest model's), so only the symbol tiles are per model.
+    uint32_t slotOffsetDwords[UNION_MAX_MODELS];
+    uint32_t keyTileOffsetDwords[UNION_MAX_MODELS];
     uint32_t codebookOffsetDwords;   // model m's codebook at this + m * 512 dwords
     uint32_t sharedDwords;           // tables + codebooks
-    uint32_t perModelDwords;         // one model's slots + symbol tile of one wave
+    uint32_t perWaveDwords;          // one wavefront's area
     uint32_t rowPieces;              // 16-byte pieces of a merged row: COUNT * dim / 4, or dim / 4 when averaging
     uint32_t rowMagic;               // fastDivide magic for rowPieces
 };
 
-template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE>
-__global__ void decode_trained_union(UnionParams u)
+// Tables and codebooks of all models into LDS; ends with a block barrier.
+template <int COUNT>
+__device__ __forceinline__ void setUpUnionLds(const UnionParams& u, uint32_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const TrainedParams& first = u.model[0];
-
-    // tables and codebooks of all models
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
         const TrainedParams& p = u.model[m];
@@ -795,118 +800,44 @@ __global__ void decode_trained_union(UnionParams u)
         }
     }
     __syncthreads();
+}
 
-    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
-    const unsigned long long tileBase = tile * first.wordsPerWave;
-    if (tileBase >= first.n) {
-        return;
-    }
-    const uint32_t tileWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
-    const LaneRole role = laneRole(first, lane);
-    uint32_t* waveLds = lds + u.sharedDwords + wave * (COUNT * u.perModelDwords);
+// Per model, the ballot of a tile's words the model does not know. Named members and compile-time
+// selection: an array indexed through a reference ended up in scratch memory.
+struct AbsentMasks {
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
 
-    // the dependent hops of all models side by side: row ids, then offsets, then bitstreams
-    uint32_t rows[COUNT];
-    WordMeta meta[COUNT];
-#pragma unroll
-    for (int m = 0; m < COUNT; ++m) {
-        rows[m] = loadTileRow(u.model[m], tile, role);
+    // (called from unrolled loops: `model` is a constant by then)
+    __device__ __forceinline__ void set(int model, unsigned long long value)
+    {
+        if (model == 0) m0 = value;
+        if (model == 1) m1 = value;
+        if (model == 2) m2 = value;
+        if (model == 3) m3 = value;
     }
-#pragma unroll
-    for (int m = 0; m < COUNT; ++m) {
-        meta[m] = loadWordMeta<ONE_TILE_NT_LOADS>(u.model[m], rows[m], role);
-    }
-#pragma unroll
-    for (int m = 0; m < COUNT; ++m) {
-        const TrainedParams& p = u.model[m];
-        unpackMeta(p, role, meta[m]);
-        uint32_t* slots = waveLds + m * u.perModelDwords;
-        const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
-        for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
-            StreamRegisters v;
-            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta[m], lane, round, v);
-            writeStreams(p, slots, lane, round, v);
-        }
-    }
-    waveLdsFence();
 
-    unsigned long long absent[COUNT];
-#pragma unroll
-    for (int m = 0; m < COUNT; ++m) {
-        const TrainedParams& p = u.model[m];
-        uint32_t* slots = waveLds + m * u.perModelDwords;
-        uint32_t* keyTile = slots + u.keyTileOffsetDwords[m];
-        recordSegmentBits(p, slots, role, meta[m]);
-        decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
-            p, reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots, keyTile, role, meta[m]);
-        // nibble keys have no code for "absent": remember which words of the tile are
-        absent[m] = __ballot(!(meta[m].row < p.nRows) && !role.spare && role.segment == 0 && role.word < tileWords);
+    // Does model `model` lack the word whose first lane is `firstLane`? (Arithmetic, not a chain of
+    // selects on `model`: LLVM turns such a chain into a table in scratch memory.)
+    template <int COUNT>
+    __device__ __forceinline__ bool lacks(uint32_t model, uint32_t firstLane) const
+    {
+        uint32_t perModel = static_cast<uint32_t>(m0 >> firstLane) & 1u;
+        if (COUNT > 1) perModel |= (static_cast<uint32_t>(m1 >> firstLane) & 1u) << 1;
+        if (COUNT > 2) perModel |= (static_cast<uint32_t>(m2 >> firstLane) & 1u) << 2;
+        if (COUNT > 3) perModel |= (static_cast<uint32_t>(m3 >> firstLane) & 1u) << 3;
+        return (perModel >> model) & 1u;
     }
-    waveLdsFence();
+};
 
-    if (!AVERAGE) {
-        // merged rows, 16 bytes per lane, row contiguous when the column blocks are adjacent
-        const uint32_t piecesPerWord = first.dim / 4;
-        const uint32_t pieces = tileWords * u.rowPieces;
-        constexpr int BURST = 4;
-        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
-            uint32_t k[BURST];
-            uint32_t w[BURST];
-            uint32_t m[BURST];
-            uint32_t c[BURST];
-#pragma unroll
-            for (int b = 0; b < BURST; ++b) {
-                const uint32_t q = min(q0 + WAVE * b, pieces - 1);
-                w[b] = fastDivide(q, u.rowMagic, u.rowPieces);
-                const uint32_t inRow = q - w[b] * u.rowPieces;
-                m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
-                c[b] = inRow - m[b] * piecesPerWord;
-                uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
-#pragma unroll
-                for (int i = 1; i < COUNT; ++i) {
-                    keyTileOffset = m[b] == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
-                }
-                const uint32_t* keyTile = waveLds + m[b] * u.perModelDwords + keyTileOffset;
-                const uint32_t at = w[b] * (first.keyRowBytes / (FAST ? 2 : 4)) + c[b];
-                k[b] = FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
-            }
-#pragma unroll
-            for (int b = 0; b < BURST; ++b) {
-                const uint32_t* codebook = lds + u.codebookOffsetDwords + m[b] * 512;
-                float4 f;
-                if (FAST) {
-                    const float2 lo = reinterpret_cast<const float2*>(codebook)[k[b] & 0xff];
-                    const float2 hi = reinterpret_cast<const float2*>(codebook)[k[b] >> 8];
-                    f = make_float4(lo.x, lo.y, hi.x, hi.y);
-                    unsigned long long mask = absent[0];
-#pragma unroll
-                    for (int i = 1; i < COUNT; ++i) {
-                        mask = m[b] == static_cast<uint32_t>(i) ? absent[i] : mask;
-                    }
-                    if ((mask >> (w[b] * first.lanesPerWord)) & 1) {
-                        f = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                } else {
-                    const float* centroids = reinterpret_cast<const float*>(codebook);
-                    f.x = centroids[k[b] & 0xff];
-                    f.y = centroids[(k[b] >> 8) & 0xff];
-                    f.z = centroids[(k[b] >> 16) & 0xff];
-                    f.w = centroids[k[b] >> 24];
-                }
-                if (q0 + WAVE * b < pieces) {
-                    unsigned long long colOff = u.model[0].colOff;
-#pragma unroll
-                    for (int i = 1; i < COUNT; ++i) {
-                        colOff = m[b] == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
-                    }
-                    *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + colOff + 4 * c[b]) = f;
-                }
-            }
-        }
-        return;
-    }
-    // merged rows, 16 bytes per lane, row contiguous when the column blocks are adjacent
+// The merged rows of one tile out of the models' symbol tiles: 16 bytes per lane, row contiguous when
+// the column blocks are adjacent. absent[m]: ballot of the tile's words that model m does not know
+// (nibble keys have no code for "absent").
+template <bool FAST, int COUNT, bool AVERAGE>
+__device__ __forceinline__ void outputUnionTile(
+    const UnionParams& u, const uint32_t* lds, const uint32_t* waveLds, unsigned long long tileBase, uint32_t tileWords,
+    uint32_t lane, const AbsentMasks& absent)
+{
+    const TrainedParams& first = u.model[0];
     const uint32_t piecesPerWord = first.dim / 4;
     const uint32_t pieces = tileWords * u.rowPieces;
     // two steps, so that a burst's symbol reads are all issued before the codebook reads that
@@ -917,21 +848,16 @@ __global__ void decode_trained_union(UnionParams u)
         for (int i = 1; i < COUNT; ++i) {
             keyTileOffset = model == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
         }
-        const uint32_t* keyTile = waveLds + model * u.perModelDwords + keyTileOffset;
+        const uint32_t* keyTile = waveLds + keyTileOffset;
         const uint32_t at = word * (first.keyRowBytes / (FAST ? 2 : 4)) + column;
         return FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
     };
     auto lookUp = [&](uint32_t model, uint32_t word, uint32_t k) -> float4 {
         const uint32_t* codebook = lds + u.codebookOffsetDwords + model * 512;
         if (FAST) {
-            unsigned long long mask = absent[0];
-#pragma unroll
-            for (int i = 1; i < COUNT; ++i) {
-                mask = model == static_cast<uint32_t>(i) ? absent[i] : mask;
-            }
             const float2 lo = reinterpret_cast<const float2*>(codebook)[k & 0xff];
             const float2 hi = reinterpret_cast<const float2*>(codebook)[k >> 8];
-            if ((mask >> (word * first.lanesPerWord)) & 1) {
+            if (absent.template lacks<COUNT>(model, word * first.lanesPerWord)) {
                 return make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return make_float4(lo.x, lo.y, hi.x, hi.y);
@@ -992,6 +918,156 @@ __global__ void decode_trained_union(UnionParams u)
             }
         }
     }
+}
+
+// One tile per wavefront: for tiles too wide for the persistent kernel's registers, and for batches
+// of less than one tile per resident wavefront.
+template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE>
+__global__ void decode_trained_union(UnionParams u)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const TrainedParams& first = u.model[0];
+    setUpUnionLds<COUNT>(u, lds);
+
+    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    const unsigned long long tileBase = tile * first.wordsPerWave;
+    if (tileBase >= first.n) {
+        return;
+    }
+    const uint32_t tileWords =
+        static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
+    const LaneRole role = laneRole(first, lane);
+    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
+
+    // the dependent hops of all models side by side: row ids, then offsets, then bitstreams
+    uint32_t rows[COUNT];
+    WordMeta meta[COUNT];
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        rows[m] = loadTileRow(u.model[m], tile, role);
+    }
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        meta[m] = loadWordMeta<ONE_TILE_NT_LOADS>(u.model[m], rows[m], role);
+    }
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        const TrainedParams& p = u.model[m];
+        unpackMeta(p, role, meta[m]);
+        uint32_t* slots = waveLds + u.slotOffsetDwords[m];
+        const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
+        for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
+            StreamRegisters v;
+            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta[m], lane, round, v);
+            writeStreams(p, slots, lane, round, v);
+        }
+    }
+    waveLdsFence();
+
+    AbsentMasks absent;
+#pragma unroll
+    for (int m = 0; m < COUNT; ++m) {
+        const TrainedParams& p = u.model[m];
+        uint32_t* slots = waveLds + u.slotOffsetDwords[m];
+        recordSegmentBits(p, slots, role, meta[m]);
+        decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+            p, reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots, waveLds + u.keyTileOffsetDwords[m], role, meta[m]);
+        absent.set(m, __ballot(!(meta[m].row < p.nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
+    }
+    waveLdsFence();
+    outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+}
+
+// The persistent form (the pipeline of decode_trained_persistent, see there). The unit of the pipeline
+// is (tile, model): a wavefront decodes its tile for model 0, then for model 1, ... -- each into that
+// model's symbol tile, all out of ONE set of bitstream slots -- and writes the merged rows after the last
+// model; while unit k is decoded, the bitstream bytes of unit k + 1 sit in registers and the index
+// records / row ids of units k + 2 / k + 3 are on their way. The loop body is unrolled over the models,
+// so which model a pipeline stage serves is a compile-time fact.
+template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE, bool NT>
+__global__ void decode_trained_union_persistent(UnionParams u)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const TrainedParams& first = u.model[0];
+    setUpUnionLds<COUNT>(u, lds);
+
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    const unsigned long long tiles = (first.n + first.wordsPerWave - 1) / first.wordsPerWave;
+    if (tile >= tiles) {
+        return;
+    }
+    const LaneRole role = laneRole(first, lane);
+    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
+    uint32_t* slots = waveLds + u.slotOffsetDwords[0];
+
+    // unit k of this wavefront: model k % COUNT of tile `tile + (k / COUNT) * stride`
+    #define UNION_MODEL(k) u.model[(k) % COUNT]
+    #define UNION_TILE(base, k) ((base) + static_cast<unsigned long long>((k) / COUNT) * stride)
+
+    // prologue: fill the pipeline
+    uint32_t rowLoading = loadTileRow(UNION_MODEL(3), UNION_TILE(tile, 3), role);
+    WordMeta meta0 = loadWordMeta<NT>(UNION_MODEL(0), loadTileRow(UNION_MODEL(0), UNION_TILE(tile, 0), role), role);
+    WordMeta meta1 = loadWordMeta<NT>(UNION_MODEL(1), loadTileRow(UNION_MODEL(1), UNION_TILE(tile, 1), role), role);
+    WordMeta metaLoading = loadWordMeta<NT>(UNION_MODEL(2), loadTileRow(UNION_MODEL(2), UNION_TILE(tile, 2), role), role);
+    unpackMeta(UNION_MODEL(0), role, meta0);
+    unpackMeta(UNION_MODEL(1), role, meta1);
+    StreamRegisters streams;
+    issueStreamLoads<NT>(UNION_MODEL(0), meta0, lane, 0, streams);
+    writeStreams(UNION_MODEL(0), slots, lane, 0, streams);
+    issueStreamLoads<NT>(UNION_MODEL(1), meta1, lane, 0, streams);
+    waveLdsFence();
+    recordSegmentBits(UNION_MODEL(0), slots, role, meta0);
+
+    AbsentMasks absent;
+    for (; tile < tiles; tile += stride) {
+        const unsigned long long tileBase = tile * first.wordsPerWave;
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
+#pragma unroll
+        for (int m = 0; m < COUNT; ++m) {
+            // invariant: slots hold the bitstreams of unit (tile, m); `streams` = unit + 1, `metaLoading` = unit + 2,
+            // `rowLoading` = unit + 3 in flight
+            decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+                u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
+                waveLds + u.keyTileOffsetDwords[m], role, meta0);
+            absent.set(m, __ballot(!(meta0.row < u.model[m].nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
+            waveLdsFence();
+
+            // consume point (see decode_trained_persistent)
+            writeStreams(UNION_MODEL(m + 1), slots, lane, 0, streams);
+            WordMeta meta2;
+            uint32_t row3;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed2) : "v"(metaLoading.packed2));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed3) : "v"(metaLoading.packed3));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
+            unpackMeta(UNION_MODEL(m + 2), role, meta2);
+            __builtin_amdgcn_sched_barrier(0);
+
+            if (m == COUNT - 1) {
+                // (the symbol tiles are read here and rewritten by the next units' decodes: same wavefront, in order)
+                outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            issueStreamLoads<NT>(UNION_MODEL(m + 2), meta2, lane, 0, streams);
+            metaLoading = loadWordMeta<NT>(UNION_MODEL(m + 3), row3, role);
+            rowLoading = loadTileRow(UNION_MODEL(m + 4), UNION_TILE(tile, m + 4), role);
+            meta0 = meta1;
+            meta1 = meta2;
+            waveLdsFence();
+            recordSegmentBits(UNION_MODEL(m + 1), slots, role, meta0);
+        }
+    }
+    #undef UNION_MODEL
+    #undef UNION_TILE
 }
 
 // Staging: streamStarts + segmentIndex -> rowMeta records (see TrainedParams::rowMeta). One thread per row.

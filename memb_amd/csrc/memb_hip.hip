@@ -113,6 +113,8 @@ struct Switches {
     bool persistent = true;        // MEMB_HIP_PERSISTENT
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
+    uint32_t gridPolicy = 1;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
+                                   // make the same number of rounds, so that all of them walk the same number of tiles
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -331,7 +333,14 @@ hipError_t launchPersistentVariant(
         perCu = std::min(perCu, ctx->switches.blocksPerCu);
     }
     const uint32_t resident = perCu * ctx->cuCount;
-    const uint32_t blocks = std::min(tileBlocks, resident);
+    uint32_t blocks = std::min(tileBlocks, resident);
+    if (ctx->switches.gridPolicy == 1 && tileBlocks > resident) {
+        // Wavefront w walks tiles w, w + W, w + 2 W, ...: with every slot taken, a batch of 3.05 tiles per slot
+        // leaves a few wavefronts a fourth tile to do alone at the end. The same number of rounds with fewer
+        // wavefronts gives all of them the same work (to within one tile).
+        const uint32_t rounds = (tileBlocks + resident - 1) / resident;
+        blocks = (tileBlocks + rounds - 1) / rounds;
+    }
     hipLaunchKernelGGL(
         (decode_trained_persistent<HAS_SUB, MODE, FAST, NT>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
@@ -485,37 +494,95 @@ int launchTrained(
     return MEMB_HIP_OK;
 }
 
+struct UnionLaunch {
+    uint32_t blocks;         // one tile per wavefront
+    uint32_t threads;
+    uint32_t ldsBytes;
+    bool persistent;
+    bool ntLoads;
+    uint32_t blocksPerCuCap;
+    uint32_t cuCount;
+    bool evenRounds;
+};
+
 template <bool HAS_SUB, bool FAST, bool AVERAGE, int COUNT>
-hipError_t launchUnionCount(const UnionParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+hipError_t launchUnionCount(const UnionParams& params, const UnionLaunch& launch, hipStream_t stream)
 {
-    static thread_local int configuredDevice = -1;
-    int device = 0;
-    (void)hipGetDevice(&device);
-    if (configuredDevice != device) {
-        hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (status != hipSuccess) {
-            return status;
+    if (!launch.persistent) {
+        static thread_local int configuredDevice = -1;
+        int device = 0;
+        (void)hipGetDevice(&device);
+        if (configuredDevice != device) {
+            hipError_t status = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (status != hipSuccess) {
+                return status;
+            }
+            configuredDevice = device;
         }
-        configuredDevice = device;
+        hipLaunchKernelGGL(
+            (decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>), dim3(launch.blocks), dim3(launch.threads), launch.ldsBytes,
+            stream, params);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(
-        (decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
-    return hipGetLastError();
+    // persistent: as many blocks as are resident at once, each wavefront strides over the tiles
+    auto run = [&](auto kernel) -> hipError_t {
+        static thread_local int configuredDevice = -1;
+        static thread_local int blocksPerCu = 0;
+        static thread_local uint32_t configuredThreads = 0;
+        static thread_local uint32_t configuredLds = 0;
+        int device = 0;
+        (void)hipGetDevice(&device);
+        if (configuredDevice != device || configuredThreads != launch.threads || configuredLds != launch.ldsBytes) {
+            hipError_t status = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (status != hipSuccess) {
+                return status;
+            }
+            status = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &blocksPerCu, kernel, static_cast<int>(launch.threads), launch.ldsBytes);
+            if (status != hipSuccess) {
+                return status;
+            }
+            blocksPerCu = std::max(blocksPerCu, 1);
+            configuredDevice = device;
+            configuredThreads = launch.threads;
+            configuredLds = launch.ldsBytes;
+        }
+        uint32_t perCu = static_cast<uint32_t>(blocksPerCu);
+        if (launch.blocksPerCuCap) {
+            perCu = std::min(perCu, launch.blocksPerCuCap);
+        }
+        const uint32_t resident = perCu * launch.cuCount;
+        uint32_t blocks = std::min(launch.blocks, resident);
+        if (launch.evenRounds && launch.blocks > resident) {   // as launchPersistentVariant
+            const uint32_t rounds = (launch.blocks + resident - 1) / resident;
+            blocks = (launch.blocks + rounds - 1) / rounds;
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(launch.threads), launch.ldsBytes, stream, params);
+        return hipGetLastError();
+    };
+    // (two models only: the three- and four-model forms of the pipeline need more than 128 registers and
+    // still spill; launchTrainedUnion never asks for them)
+    if constexpr (COUNT == 2) {
+        return launch.ntLoads ? run(&decode_trained_union_persistent<HAS_SUB, FAST, COUNT, AVERAGE, true>)
+                              : run(&decode_trained_union_persistent<HAS_SUB, FAST, COUNT, AVERAGE, false>);
+    } else {
+        return hipErrorInvalidValue;
+    }
 }
 
 template <bool HAS_SUB, bool FAST, bool AVERAGE>
-hipError_t launchUnionVariant(
-    const UnionParams& params, size_t count, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+hipError_t launchUnionVariant(const UnionParams& params, size_t count, const UnionLaunch& launch, hipStream_t stream)
 {
     switch (count) {
         case 2:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 2>(params, blocks, threads, ldsBytes, stream);
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 2>(params, launch, stream);
         case 3:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 3>(params, blocks, threads, ldsBytes, stream);
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 3>(params, launch, stream);
         default:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 4>(params, blocks, threads, ldsBytes, stream);
+            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 4>(params, launch, stream);
     }
 }
 
@@ -543,9 +610,19 @@ int launchTrainedUnion(
         return MEMB_HIP_UNSUPPORTED;
     }
     const uint32_t wordsPerWave = WAVE / first->lanesPerWord;
+    const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
+
+    // The persistent pipeline keeps one unit's bitstreams in registers (as the single-model kernel does)
+    // and pays its prologue once per wavefront: used when every model's tile fits and there is more than
+    // one tile per resident wavefront to amortise it over.
+    bool persistent = first->switches.persistent && count == 2;
+    for (size_t m = 0; m < count; ++m) {
+        const uint32_t loadPieces = ctxs[m]->recordPieces ? ctxs[m]->recordPieces : ctxs[m]->slotDwords / 4;
+        persistent = persistent && (wordsPerWave * loadPieces + WAVE - 1) / WAVE <= STREAM_REGISTERS;
+    }
+
     UnionParams params{};
     uint32_t sharedDwords = 0;
-    uint32_t perModelDwords = 0;
     for (size_t m = 0; m < count; ++m) {
         memb_hip_ctx* ctx = ctxs[m];
         TrainedParams& p = params.model[m];
@@ -564,49 +641,91 @@ int launchTrainedUnion(
         p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(count) * (ctx->dim / 4));
         params.tableOffsetDwords[m] = sharedDwords;
         sharedDwords += ctx->tableDwords;
-        params.keyTileOffsetDwords[m] = wordsPerWave * ctx->slotDwords;
-        perModelDwords = std::max(perModelDwords, wordsPerWave * ctx->slotDwords + p.keyTileDwords);
     }
-    perModelDwords = (perModelDwords + 3) / 4 * 4;
     params.codebookOffsetDwords = sharedDwords;
     sharedDwords += static_cast<uint32_t>(count) * 512;
     params.sharedDwords = sharedDwords;
-    params.perModelDwords = perModelDwords;
     params.rowPieces = (average ? 1u : static_cast<uint32_t>(count)) * (first->dim / 4);
     params.rowMagic = magicFor(params.rowPieces, uint64_t(wordsPerWave) * params.rowPieces);
 
+    // one wavefront's LDS area
+    auto layOut = [&](bool sharedSlots) {
+        uint32_t at = 0;
+        if (sharedSlots) {
+            uint32_t slotDwords = 0;
+            for (size_t m = 0; m < count; ++m) {
+                slotDwords = std::max(slotDwords, wordsPerWave * ctxs[m]->slotDwords);
+                params.slotOffsetDwords[m] = 0;
+            }
+            at = roundUp4(slotDwords);
+        }
+        for (size_t m = 0; m < count; ++m) {
+            if (!sharedSlots) {
+                params.slotOffsetDwords[m] = at;
+                at += roundUp4(wordsPerWave * ctxs[m]->slotDwords);
+            }
+            params.keyTileOffsetDwords[m] = at;
+            at += roundUp4(params.model[m].keyTileDwords);
+        }
+        params.perWaveDwords = at;
+    };
+
     // waves per block: most resident wavefronts per CU, larger blocks on ties (as chooseGeometry)
+    auto chooseWaves = [&](uint32_t* waves, uint32_t* ldsBytes) {
+        double bestResident = -1;
+        *waves = 0;
+        for (uint32_t candidate : {8u, 4u, 2u, 1u}) {
+            if (first->switches.waves && candidate != first->switches.waves) {
+                continue;
+            }
+            const uint32_t bytes = 4u * (sharedDwords + candidate * params.perWaveDwords);
+            if (bytes > first->ldsLimit) {
+                continue;
+            }
+            const uint32_t blocksPerCu = std::min<uint32_t>(first->ldsLimit / ((bytes + 1023) / 1024 * 1024), 32 / candidate);
+            if (double(blocksPerCu) * candidate > bestResident) {
+                bestResident = double(blocksPerCu) * candidate;
+                *waves = candidate;
+                *ldsBytes = bytes;
+            }
+        }
+    };
     uint32_t waves = 0;
     uint32_t ldsBytes = 0;
-    double bestResident = -1;
-    for (uint32_t candidate : {8u, 4u, 2u, 1u}) {
-        const uint32_t bytes = 4u * (sharedDwords + candidate * static_cast<uint32_t>(count) * perModelDwords);
-        if (bytes > first->ldsLimit) {
-            continue;
+    if (persistent) {
+        layOut(true);
+        chooseWaves(&waves, &ldsBytes);
+        // fewer than two tiles per resident wavefront: the pipeline has nothing to overlap
+        if (!waves || tiles < 2ull * first->cuCount * 16) {
+            persistent = false;
         }
-        const uint32_t blocksPerCu = std::min<uint32_t>(first->ldsLimit / ((bytes + 1023) / 1024 * 1024), 32 / candidate);
-        if (double(blocksPerCu) * candidate > bestResident) {
-            bestResident = double(blocksPerCu) * candidate;
-            waves = candidate;
-            ldsBytes = bytes;
-        }
+    }
+    if (!persistent) {
+        layOut(false);
+        chooseWaves(&waves, &ldsBytes);
     }
     if (!waves) {
         return MEMB_HIP_UNSUPPORTED;
     }
-    const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
-    const uint32_t blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+    UnionLaunch launch{};
+    launch.blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+    launch.threads = waves * WAVE;
+    launch.ldsBytes = ldsBytes;
+    launch.persistent = persistent;
+    launch.ntLoads = first->switches.ntLoads;
+    launch.blocksPerCuCap = first->switches.blocksPerCu;
+    launch.cuCount = first->cuCount;
+    launch.evenRounds = first->switches.gridPolicy == 1;
     hipError_t status;
-    const uint32_t threads = waves * WAVE;
     if (first->fast) {
-        status = average ? launchUnionVariant<false, true, true>(params, count, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<false, true, false>(params, count, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, true, true>(params, count, launch, stream)
+                         : launchUnionVariant<false, true, false>(params, count, launch, stream);
     } else if (hasSub) {
-        status = average ? launchUnionVariant<true, false, true>(params, count, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<true, false, false>(params, count, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<true, false, true>(params, count, launch, stream)
+                         : launchUnionVariant<true, false, false>(params, count, launch, stream);
     } else {
-        status = average ? launchUnionVariant<false, false, true>(params, count, blocks, threads, ldsBytes, stream)
-                         : launchUnionVariant<false, false, false>(params, count, blocks, threads, ldsBytes, stream);
+        status = average ? launchUnionVariant<false, false, true>(params, count, launch, stream)
+                         : launchUnionVariant<false, false, false>(params, count, launch, stream);
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
@@ -885,6 +1004,7 @@ Switches readSwitches()
     switches.persistent = envUint("MEMB_HIP_PERSISTENT", 1) != 0;
     switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
     switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
+    switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1546,6 +1666,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "blocks_per_cu" && value <= 32) {
         ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
+    } else if (key == "grid_policy" && value <= 1) {
+        ctx->switches.gridPolicy = static_cast<uint32_t>(value);
     } else if (key == "persistent" && value <= 1) {
         ctx->switches.persistent = value != 0;
     } else if (key == "host_expand" && value <= 1) {

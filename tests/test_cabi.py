@@ -21,7 +21,17 @@ def test_header_declares_the_expected_entry_points():
         'memb_hip_device_count', 'memb_hip_ctx_create_trained', 'memb_hip_ctx_create_uniform',
         'memb_hip_ctx_create_full', 'memb_hip_ctx_destroy', 'memb_hip_ctx_get_info', 'memb_hip_decode_rows',
         'memb_hip_decode_rows_device', 'memb_hip_decode_rows_device_ex', 'memb_hip_decode_rows_union_device', 'memb_hip_sync', 'memb_hip_algorithmic_bytes', 'memb_hip_last_error',
+        'memb_hip_abi_version', 'memb_hip_ctx_set_option',
     ])
+
+
+def test_abi_version_and_options_without_compute(native):
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    header = open(os.path.join(REPO, 'include', 'memb_hip.h')).read()
+    assert library.memb_hip_abi_version() == int(re.search(r'#define MEMB_HIP_ABI_VERSION (\d+)', header).group(1))
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+    assert library.memb_hip_ctx_set_option(None, b'nt_loads', ctypes.c_uint64(1)) == 1   # MEMB_HIP_ERR_INVALID
+    assert library.memb_hip_ctx_get_info(None, None) == 1
 
 
 def test_header_is_plain_c_and_cxx():

@@ -37,7 +37,7 @@ cases = os.environ.get('AB3_CASES', 'sorted,random,100k').split(',')
 placement = int(os.environ.get('AB3_PLACEMENT', '0'))
 out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
 DEFAULTS = {'nt_loads': int(os.environ.get('MEMB_HIP_NT_LOADS', '0')), 'waves_per_block': 0, 'blocks_per_cu': 0,
-            'persistent': 1}
+            'persistent': 1, 'grid_policy': int(os.environ.get('MEMB_HIP_GRID_POLICY', '1'))}
 
 print('package: %s   model: %d words, %d-bit   rounds %d x %d launches after %.0f ms run-in' % (
     os.path.dirname(memb_amd.__file__), n, bits, rounds, reps, run_in_ms), flush=True)
@@ -79,8 +79,8 @@ def parse(spec):
     options, env = {}, {}
     for item in filter(None, rest.split(';')):
         key, _, value = item.partition('=')
-        if key.startswith('!'):
-            env[key[1:]] = value
+        if key.startswith('!') or key.startswith('MEMB_'):
+            env[key.lstrip('!')] = value
         else:
             options[key] = int(value, 0)
     return name, options, env
@@ -142,9 +142,38 @@ for name, options, env, reader in variants:
         print('variant %s: output differs from base (expected for measurement switches that skip work)' % name, flush=True)
 
 
+union = None
+if any(c.endswith('union') for c in cases):
+    # BASELINE.json configs[4]: concatenation of two 4-bit models, 500 000 words, a quarter missing per model;
+    # the options of the FIRST reader choose the kernel
+    from memb_amd import _memb
+    second_path, _ = synthetic.cached_model(1999995, 300, 'trained', 4, seed=4321)
+    second = memb_amd.Reader(second_path, device=0)
+    second.info()
+    rng = np.random.default_rng(17)
+    batch = 500000
+    ids = []
+    for count in (n, len(second)):
+        picks = rng.integers(0, count, size=batch).astype(np.uint32)
+        picks[rng.random(batch) < 0.25] = 0xFFFFFFFF
+        ids.append(torch.from_numpy(picks.view(np.int32)).cuda())
+    merged = torch.empty((batch, 600), dtype=torch.float32, device='cuda')
+    union = (second, ids, merged, batch)
+
+
+def run_union(reader):
+    second, ids, merged, batch = union
+    done = _memb.union_rows_to_device(
+        [reader._impl, second._impl], [ids[0].data_ptr(), ids[1].data_ptr()], [0, 300], batch, merged.data_ptr(),
+        merged.stride(0), torch.cuda.current_stream().cuda_stream, False)
+    assert done
+
+
 def run_case(reader, case, target):
     cold = case.startswith('cold')
     kind = case[4:] if cold else case
+    if kind == 'union':
+        return timeit(lambda: run_union(reader), cold)
     if kind == 'sorted':
         return timeit(lambda: reader.rows_embedding_device(rows, out=target), cold)
     if kind == 'random':

@@ -73,6 +73,8 @@ def parse_args():
     parser.add_argument('--no-configs', action='store_true',
                         help='skip the per-configuration array and the strong-scaling leg (profiling runs: only the timed kernel)')
     parser.add_argument('--small', action='store_true', help='shrink every model to 50 000 words (plumbing rehearsal)')
+    parser.add_argument('--host-writer', action='store_true',
+                        help='write the synthetic models with the host writer (default: memb_amd.Builder(device=...), same bytes)')
     parser.add_argument('--dry-launch', action='store_true',
                         help='--gpus N without a launcher: build, check, print the launch command and what the parent saw; start nothing')
     return parser.parse_args()
@@ -667,6 +669,12 @@ def main():
     if args.small:
         words, glove, fasttext = min(words, 50000), 50000, 49999
     os.environ['MEMB_BENCH_CACHE'] = args.cache_dir
+    # the synthetic models are written through the device writer (quantisation, histogram and bit packing on
+    # this rank's GPU; byte-identical files: tests/test_gpu_writer.py) unless asked otherwise
+    if args.host_writer:
+        os.environ.pop('MEMB_SYNTH_DEVICE', None)
+    else:
+        os.environ['MEMB_SYNTH_DEVICE'] = str(local_rank)
     build_seconds = 0.0
     library = ctypes.CDLL(memb_amd.HIP_LIBRARY_PATH)
     timer = Timer(torch)
@@ -868,6 +876,7 @@ def main():
         'geometry': {k: info.get(k) for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
                                               'max_code_bits', 'max_stream_bytes', 'device_bytes', 'row_layout', 'row_bytes')},
         'model_build_s': build_seconds,
+        'model_writer': 'host (memb_amd.Builder)' if args.host_writer else 'device (memb_amd.Builder(device={}): memb_hip_encoder_*)'.format(local_rank),
         'reader_open_s': open_seconds,
     }
     print(json.dumps(result))

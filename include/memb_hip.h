@@ -237,6 +237,40 @@ int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, si
 
 const char* memb_hip_last_error(void);
 
+/*
+ * Write side (optional; a file written with or without it has the same bytes). It replaces, for whole
+ * blocks of vectors, the per-scalar and per-word work of the reference's trained compressor
+ *     TrainedCompressor::finalize                    reference src/trained_compression.cpp:40-71
+ *       KMeansClusterizer::predict                   reference src/kmeans.cpp:66-80
+ *       HuffmanEncoderBuilder::updateFrequencies     reference src/huffman_encoder.cpp:22-29
+ *       HuffmanEncoder::encode / BitStream::push     reference src/huffman_encoder.cpp:88-97, src/bit_stream.h:18-34
+ * The caller keeps what depends on the order of the data or is tiny: the k-means fit on the first
+ * 10 000 words (src/kmeans.cpp:26-64) and the Huffman tree. Protocol:
+ *   create(split points = mid-points of neighbouring centroids, src/kmeans.cpp:121-128)
+ *   add_rows(...) any number of times, in insertion order  -> symbols kept in HBM, histogram updated
+ *   counts()                                                -> build the canonical code on the host
+ *   pack(codes, lengths)                                    -> per-word stream lengths; streams laid out back to
+ *                                                              back in insertion order (trained_compression.cpp:65-71)
+ *   fetch(buffer)                                           -> packed_values
+ * A symbol is the number of split points that compare less than the scalar (std::lower_bound; 0 for a NaN).
+ */
+typedef struct memb_hip_encoder memb_hip_encoder;
+
+int memb_hip_encoder_create(memb_hip_encoder** encoder, int device, uint32_t dim, const float* split_points, uint32_t n_split_points);
+void memb_hip_encoder_destroy(memb_hip_encoder* encoder);
+/* rows: host memory, n_rows x dim floats, row-major; consumed before the call returns */
+int memb_hip_encoder_add_rows(memb_hip_encoder* encoder, const float* rows, size_t n_rows);
+/* counts[256]: how often each symbol occurred so far */
+int memb_hip_encoder_counts(memb_hip_encoder* encoder, uint64_t* counts);
+/*
+ * codes[256] / lengths[256]: the prefix code of every symbol (length 0 = symbol never occurs), at most 16 bits.
+ * stream_bytes[rows added]: length of every word's byte-aligned stream; total_bytes: their sum.
+ */
+int memb_hip_encoder_pack(
+    memb_hip_encoder* encoder, const uint16_t* codes, const uint8_t* lengths, uint32_t* stream_bytes, uint64_t* total_bytes);
+/* the packed streams into host memory of at least total_bytes */
+int memb_hip_encoder_fetch(memb_hip_encoder* encoder, uint8_t* packed, uint64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,10 +18,17 @@ class Builder:
                      (per-word min/max, one byte per weight) or 'full' (fp32)
     bits_per_weight  precision asked of the storage; values a storage cannot
                      honour are clamped by it
+    device           (not in the reference API) HIP device index: the trained storage then quantises,
+                     counts and bit-packs on that GPU -- vectors stream to it as they are added, only
+                     the k-means fit on the first 10 000 words and the Huffman tree stay on the host.
+                     The file is byte for byte the one the host writes. None = host, as the reference.
     """
 
-    def __init__(self, dim, storage_type='trained', bits_per_weight=4):
-        self._native = _memb.Builder(dim, storage_type, bits_per_weight)
+    def __init__(self, dim, storage_type='trained', bits_per_weight=4, device=None):
+        if device is None:
+            self._native = _memb.Builder(dim, storage_type, bits_per_weight)
+        else:
+            self._native = _memb.Builder(dim, storage_type, bits_per_weight, int(device))
 
     def add_word(self, word, vector):
         """One word; `vector` is a float32 sequence of length dim. Raises on a

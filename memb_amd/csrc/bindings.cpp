@@ -155,6 +155,8 @@ OutputMatrix outputMatrix(const py::array& out)
 PYBIND11_MODULE(_memb, m) {
     py::class_<memb::Builder>(m, "Builder")
         .def(py::init<size_t, const std::string&, size_t>())
+        .def(py::init<size_t, const std::string&, size_t, int>(),
+             py::arg("dim"), py::arg("storage_type"), py::arg("bits_per_weight"), py::arg("device"))
         .def(
             "add_word",
             [](memb::Builder& builder, const std::string& word, py::array_t<float, py::array::c_style> values)

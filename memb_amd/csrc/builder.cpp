@@ -7,20 +7,21 @@
 
 namespace memb {
 
-void Builder::attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight)
+void Builder::attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight, int device)
 {
     storageType_ = strategy->storageType();
     compressor_ = strategy->createCompressor(buffer_, bitsPerWeight);
+    compressor_->setDevice(device);
 }
 
-Builder::Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight): dim_(dim)
+Builder::Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight, int device): dim_(dim)
 {
-    attach(createCompressionStrategy(storageType), bitsPerWeight);
+    attach(createCompressionStrategy(storageType), bitsPerWeight, device);
 }
 
-Builder::Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight): dim_(dim)
+Builder::Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight, int device): dim_(dim)
 {
-    attach(createCompressionStrategy(storageName), bitsPerWeight);
+    attach(createCompressionStrategy(storageName), bitsPerWeight, device);
 }
 
 // The two refusals and their messages are the reference's (src/builder.cpp:12-16, 34-48);
@@ -54,8 +55,19 @@ void Builder::addWords(const std::vector<std::string>& words, const float* matri
 {
     std::lock_guard<std::mutex> lock(mutex_);
     seen_.reserve(seen_.size() + words.size());
-    for (size_t row = 0; row < words.size(); ++row) {
-        addWordLocked(words[row], matrix + row * rowLength, rowLength);
+    if (rowLength != dim_ && !words.empty()) {
+        addWordLocked(words[0], matrix, rowLength);   // throws the reference's message
+    }
+    // the checks word by word; the rows that pass go to the compressor as one block
+    size_t accepted = 0;
+    for (; accepted < words.size(); ++accepted) {
+        if (!seen_.insert(words[accepted]).second) {
+            break;
+        }
+    }
+    compressor_->addMany(words.data(), matrix, accepted, dim_);
+    if (accepted < words.size()) {
+        throw std::runtime_error("Attempt to add duplicate word " + words[accepted] + " to index");
     }
 }
 

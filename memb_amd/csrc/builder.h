@@ -16,8 +16,11 @@ namespace memb {
 
 class Builder {
 public:
-    Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight);
-    Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight);
+    // device: HIP device that does the bulk of the compression (trained storage: quantisation, symbol
+    // histogram and bit packing, memb_hip_encoder_* in include/memb_hip.h); negative = everything on the
+    // host, as in the reference. The file has the same bytes either way.
+    Builder(size_t dim, wire::Storage storageType, size_t bitsPerWeight, int device = -1);
+    Builder(size_t dim, const std::string& storageName, size_t bitsPerWeight, int device = -1);
 
     // Throws std::runtime_error for a vector of the wrong length and for a repeated word.
     void addWord(const std::string& word, const float* embedding, size_t size);
@@ -36,7 +39,7 @@ public:
 
 private:
     void addWordLocked(const std::string& word, const float* embedding, size_t size);
-    void attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight);
+    void attach(const std::shared_ptr<CompressionStrategy>& strategy, size_t bitsPerWeight, int device);
 
     const size_t dim_;
     wire::Storage storageType_ = wire::Storage_NONE;

@@ -347,6 +347,8 @@ public:
     }
 
     const std::vector<float>& centroids() const { return centroids_; }
+    // the mid-points predict() searches: symbol = number of split points below the value
+    const std::vector<float>& splits() const { return splits_; }
 
 private:
     static constexpr size_t MAX_ITERATIONS = 30;

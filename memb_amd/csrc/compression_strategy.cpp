@@ -436,19 +436,50 @@ class TrainedCompressor : public Compressor {
 public:
     TrainedCompressor(wire::BufferBuilder& builder, size_t bitsPerWeight):
         builder_(builder),
-        quantizationLevels_(quantizationLevelsFor(bitsPerWeight))
+        quantizationLevels_(quantizationLevelsFor(bitsPerWeight)),
+        clusterizer_(quantizationLevels_)
     {}
+
+    ~TrainedCompressor() override
+    {
+        if (encoder_) {
+            memb_hip_encoder_destroy(encoder_);
+        }
+    }
+
+    void setDevice(int device) override { device_ = device; }
 
     void add(const std::string& word, const float* source, size_t dim) override
     {
         words_.push_back(word);
-        values_.insert(values_.end(), source, source + dim);
         dim_ = dim;
+        values_.insert(values_.end(), source, source + dim);
+        if (device_ >= 0) {
+            pendingDeviceRows(false);
+        }
+    }
+
+    void addMany(const std::string* words, const float* matrix, size_t count, size_t dim) override
+    {
+        if (count == 0) {
+            return;
+        }
+        words_.insert(words_.end(), words, words + count);
+        dim_ = dim;
+        if (device_ >= 0 && encoder_) {
+            // straight from the caller's matrix to the device, behind whatever single words are still waiting
+            pendingDeviceRows(true);
+            deviceCall(memb_hip_encoder_add_rows(encoder_, matrix, count));
+            return;
+        }
+        values_.insert(values_.end(), matrix, matrix + count * dim);
+        if (device_ >= 0) {
+            pendingDeviceRows(false);
+        }
     }
 
     wire::BufferBuilder::Ref finalize() override
     {
-        static const size_t CLUSTER_SAMPLE_SIZE = 10000;  // reference src/trained_compression.cpp:21
         const size_t wordCount = words_.size();
         if (wordCount == 0) {
             throw std::runtime_error("Nothing to encode");
@@ -464,81 +495,96 @@ public:
             }
             stamp = now;
         };
-        const size_t sampleWords = std::min(CLUSTER_SAMPLE_SIZE, wordCount);
-        std::vector<float> sample(values_.begin(), values_.begin() + sampleWords * dim_);
 
-        KMeansClusterizer clusterizer(quantizationLevels_);
-        clusterizer.fit(sample);
-        lap("k-means fit (10 000-word sample)");
-
-        // quantise everything, count symbol frequencies
-        std::vector<uint8_t> quantized(values_.size());
-        const size_t threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), wordCount / 4096 + 1));
-        const size_t wordsPerThread = (wordCount + threads - 1) / threads;
-        std::vector<std::vector<uint64_t>> partialCounts(threads, std::vector<uint64_t>(256, 0));
-        clusterizer.predict(values_.data(), values_.size(), quantized.data());   // threaded inside
-        lap("predict (every scalar)");
-        runParallel(threads, [&](size_t t) {
-            size_t first = std::min(wordCount, t * wordsPerThread) * dim_;
-            size_t last = std::min(wordCount, (t + 1) * wordsPerThread) * dim_;
-            for (size_t i = first; i < last; ++i) {
-                partialCounts[t][quantized[i]] += 1;
-            }
-        });
-        std::vector<float>().swap(values_);
-        std::vector<uint64_t> counts(256, 0);
-        for (const auto& partial : partialCounts) {
-            for (size_t k = 0; k < 256; ++k) {
-                counts[k] += partial[k];
-            }
-        }
-
-        lap("symbol histogram + free fp32");
-        auto codeLengths = huffmanCodeLengths(counts);
-        auto codes = canonicalCodes(codeLengths);
-        std::vector<PrefixCode> codebook(256, PrefixCode{0, 0});
-        for (size_t i = 0; i < codeLengths.size(); ++i) {
-            if (codes[i].bitsCount > MAX_CODE_BITS) {
-                throw std::runtime_error("Huffman codes longer than 16 bits are not supported");
-            }
-            codebook[codeLengths[i].key] = codes[i];
-        }
-
-        // one byte aligned stream per word, concatenated in insertion order
-        std::vector<std::vector<uint8_t>> partialStreams(threads);
         std::vector<uint32_t> streamLengths(wordCount);
-        runParallel(threads, [&](size_t t) {
-            size_t first = std::min(wordCount, t * wordsPerThread);
-            size_t last = std::min(wordCount, (t + 1) * wordsPerThread);
-            BitWriter writer;
-            size_t written = 0;
-            for (size_t w = first; w < last; ++w) {
-                const uint8_t* symbols = quantized.data() + w * dim_;
-                for (size_t i = 0; i < dim_; ++i) {
-                    const PrefixCode& code = codebook[symbols[i]];
-                    writer.push(code.code, code.bitsCount);
-                }
-                writer.flushToByte();
-                streamLengths[w] = static_cast<uint32_t>(writer.bytes().size() - written);
-                written = writer.bytes().size();
+        std::vector<uint8_t> packedValues;     // host path: the streams; device path: fetched straight into the file buffer
+        uint64_t totalBytes = 0;
+        std::vector<CodeInfo> codeLengths;
+        if (device_ >= 0) {
+            if (!encoder_) {
+                startEncoder();   // fewer words than the k-means sample: nothing has gone to the device yet
             }
-            partialStreams[t].swap(writer.bytes());
-        });
-        std::vector<uint8_t>().swap(quantized);
-        lap("Huffman code + bit packing");
+            lap("k-means fit (if not done while adding)");
+            pendingDeviceRows(true);
+            std::vector<uint64_t> counts(256, 0);
+            deviceCall(memb_hip_encoder_counts(encoder_, counts.data()));
+            lap("device: last rows + histogram");
+            codeLengths = huffmanCodeLengths(counts);
+            const std::vector<PrefixCode> codebook = codebookFor(codeLengths);
+            std::vector<uint16_t> codes(256, 0);
+            std::vector<uint8_t> lengths(256, 0);
+            for (size_t symbol = 0; symbol < 256; ++symbol) {
+                codes[symbol] = static_cast<uint16_t>(codebook[symbol].code);
+                lengths[symbol] = static_cast<uint8_t>(codebook[symbol].bitsCount);
+            }
+            deviceCall(memb_hip_encoder_pack(encoder_, codes.data(), lengths.data(), streamLengths.data(), &totalBytes));
+            lap("device: Huffman code + bit packing");
+        } else {
+            fitClusterizer();
+            lap("k-means fit (10 000-word sample)");
 
-        size_t totalBytes = 0;
-        for (const auto& part : partialStreams) {
-            totalBytes += part.size();
+            // quantise everything, count symbol frequencies
+            std::vector<uint8_t> quantized(values_.size());
+            const size_t threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), wordCount / 4096 + 1));
+            const size_t wordsPerThread = (wordCount + threads - 1) / threads;
+            std::vector<std::vector<uint64_t>> partialCounts(threads, std::vector<uint64_t>(256, 0));
+            clusterizer_.predict(values_.data(), values_.size(), quantized.data());   // threaded inside
+            lap("predict (every scalar)");
+            runParallel(threads, [&](size_t t) {
+                size_t first = std::min(wordCount, t * wordsPerThread) * dim_;
+                size_t last = std::min(wordCount, (t + 1) * wordsPerThread) * dim_;
+                for (size_t i = first; i < last; ++i) {
+                    partialCounts[t][quantized[i]] += 1;
+                }
+            });
+            std::vector<float>().swap(values_);
+            std::vector<uint64_t> counts(256, 0);
+            for (const auto& partial : partialCounts) {
+                for (size_t k = 0; k < 256; ++k) {
+                    counts[k] += partial[k];
+                }
+            }
+            lap("symbol histogram + free fp32");
+
+            codeLengths = huffmanCodeLengths(counts);
+            const std::vector<PrefixCode> codebook = codebookFor(codeLengths);
+
+            // one byte aligned stream per word, concatenated in insertion order
+            std::vector<std::vector<uint8_t>> partialStreams(threads);
+            runParallel(threads, [&](size_t t) {
+                size_t first = std::min(wordCount, t * wordsPerThread);
+                size_t last = std::min(wordCount, (t + 1) * wordsPerThread);
+                BitWriter writer;
+                size_t written = 0;
+                for (size_t w = first; w < last; ++w) {
+                    const uint8_t* symbols = quantized.data() + w * dim_;
+                    for (size_t i = 0; i < dim_; ++i) {
+                        const PrefixCode& code = codebook[symbols[i]];
+                        writer.push(code.code, code.bitsCount);
+                    }
+                    writer.flushToByte();
+                    streamLengths[w] = static_cast<uint32_t>(writer.bytes().size() - written);
+                    written = writer.bytes().size();
+                }
+                partialStreams[t].swap(writer.bytes());
+            });
+            std::vector<uint8_t>().swap(quantized);
+            lap("Huffman code + bit packing");
+
+            for (const auto& part : partialStreams) {
+                totalBytes += part.size();
+            }
+            if (totalBytes <= 0xFFFFFFFFull) {
+                packedValues.reserve(totalBytes);
+                for (auto& part : partialStreams) {
+                    packedValues.insert(packedValues.end(), part.begin(), part.end());
+                    std::vector<uint8_t>().swap(part);
+                }
+            }
+            lap("concatenate streams");
         }
         if (totalBytes > 0xFFFFFFFFull) {
             throw std::runtime_error("Packed values exceed 4 GiB");
-        }
-        std::vector<uint8_t> packedValues;
-        packedValues.reserve(totalBytes);
-        for (auto& part : partialStreams) {
-            packedValues.insert(packedValues.end(), part.begin(), part.end());
-            std::vector<uint8_t>().swap(part);
         }
 
         std::vector<uint32_t> insertionOffsets(wordCount);
@@ -550,7 +596,6 @@ public:
             }
         }
 
-        lap("concatenate streams");
         // sort words with std::string::operator< (reference :73-79)
         std::vector<uint32_t> order(wordCount);
         for (size_t w = 0; w < wordCount; ++w) {
@@ -574,11 +619,21 @@ public:
         std::vector<uint32_t> sizeOffsets;
         decoderDescription(codeLengths, &decoderKeys, &sizeOffsets);
 
-        builder_.reserve(packedValues.size() + packedWords.size() + 8 * wordCount + 4096);
+        builder_.reserve(totalBytes + packedWords.size() + 8 * wordCount + 4096);
         auto wordOffsetsRef = builder_.createVector(wordOffsets);
         auto valueOffsetsRef = builder_.createVector(valueOffsets);
         auto packedWordsRef = builder_.createString(packedWords);
-        auto packedValuesRef = builder_.createVector(packedValues);
+        wire::BufferBuilder::Ref packedValuesRef;
+        if (device_ >= 0) {
+            uint8_t* destination = nullptr;
+            packedValuesRef = builder_.createVectorUninitialized<uint8_t>(totalBytes, &destination);
+            deviceCall(memb_hip_encoder_fetch(encoder_, destination, totalBytes));
+            memb_hip_encoder_destroy(encoder_);
+            encoder_ = nullptr;
+            lap("device: streams -> file buffer");
+        } else {
+            packedValuesRef = builder_.createVector(packedValues);
+        }
 
         auto keysRef = builder_.createVector(decoderKeys);
         auto sizeOffsetsRef = builder_.createVector(sizeOffsets);
@@ -587,7 +642,7 @@ public:
         builder_.addOffset(wire::field::HuffmanDecoder_size_offsets, sizeOffsetsRef);
         auto decoderRef = builder_.endTable();
 
-        auto centroidsRef = builder_.createVector(clusterizer.centroids());
+        auto centroidsRef = builder_.createVector(clusterizer_.centroids());
         builder_.startTable();
         builder_.addOffset(wire::field::KMeansClusterizer_centroids, centroidsRef);
         auto clusterizerRef = builder_.endTable();
@@ -602,6 +657,69 @@ public:
         auto result = builder_.endTable();
         lap("flatbuffer assembly");
         return result;
+    }
+
+private:
+    static constexpr size_t CLUSTER_SAMPLE_SIZE = 10000;  // reference src/trained_compression.cpp:21
+
+    // The codebook is trained on the first min(10 000, all) words (reference :44-47). It depends on nothing
+    // that comes later, so the device path fits as soon as those words are there; values_ then still holds
+    // every row added so far.
+    void fitClusterizer()
+    {
+        const size_t sampleWords = std::min(CLUSTER_SAMPLE_SIZE, words_.size());
+        std::vector<float> sample(values_.begin(), values_.begin() + sampleWords * dim_);
+        clusterizer_.fit(sample);
+    }
+
+    static std::vector<PrefixCode> codebookFor(const std::vector<CodeInfo>& codeLengths)
+    {
+        auto codes = canonicalCodes(codeLengths);
+        std::vector<PrefixCode> codebook(256, PrefixCode{0, 0});
+        for (size_t i = 0; i < codeLengths.size(); ++i) {
+            if (codes[i].bitsCount > MAX_CODE_BITS) {
+                throw std::runtime_error("Huffman codes longer than 16 bits are not supported");
+            }
+            codebook[codeLengths[i].key] = codes[i];
+        }
+        return codebook;
+    }
+
+    static void deviceCall(int code)
+    {
+        if (code != MEMB_HIP_OK) {
+            throw std::runtime_error(std::string("memb builder on the HIP device: ") + memb_hip_last_error());
+        }
+    }
+
+    void startEncoder()
+    {
+        fitClusterizer();
+        const std::vector<float>& splits = clusterizer_.splits();
+        deviceCall(memb_hip_encoder_create(
+            &encoder_, device_, static_cast<uint32_t>(dim_), splits.data(), static_cast<uint32_t>(splits.size())));
+    }
+
+    // Device path: rows wait in values_ until the k-means sample is complete, then go to the device in blocks
+    // (single words are collected into blocks of 16 384; `all` sends whatever is waiting).
+    void pendingDeviceRows(bool all)
+    {
+        if (!encoder_) {
+            if (words_.size() < CLUSTER_SAMPLE_SIZE) {
+                return;
+            }
+            startEncoder();
+            all = true;
+        }
+        const size_t waiting = dim_ ? values_.size() / dim_ : 0;
+        if (waiting == 0 || (!all && waiting < 16384)) {
+            return;
+        }
+        deviceCall(memb_hip_encoder_add_rows(encoder_, values_.data(), waiting));
+        values_.clear();
+        if (all) {
+            std::vector<float>().swap(values_);
+        }
     }
 
 private:
@@ -623,9 +741,12 @@ private:
 
     wire::BufferBuilder& builder_;
     uint8_t quantizationLevels_;
+    KMeansClusterizer clusterizer_;
+    int device_ = -1;
+    memb_hip_encoder* encoder_ = nullptr;
     size_t dim_ = 0;
     std::vector<std::string> words_;
-    std::vector<float> values_;
+    std::vector<float> values_;   // host path: every row; device path: rows that have not gone to the device yet
 };
 
 }  // namespace

@@ -102,6 +102,18 @@ private:
 class Compressor {
 public:
     virtual void add(const std::string& word, const float* source, size_t dim) = 0;
+    // Rows of a row-major matrix (rowLength == dim floats per row) for words[0 .. count); same result as
+    // `count` calls of add.
+    virtual void addMany(const std::string* words, const float* matrix, size_t count, size_t dim)
+    {
+        for (size_t row = 0; row < count; ++row) {
+            add(words[row], matrix + row * dim, dim);
+        }
+    }
+    // HIP device that does the per-scalar and per-word work of finalize (memb_hip_encoder_*); negative =
+    // the host, as in the reference. The file has the same bytes either way. Storages without device
+    // work ignore it.
+    virtual void setDevice(int /*device*/) {}
     // Writes the storage table, returns its handle (the union value of Index.storage).
     virtual wire::BufferBuilder::Ref finalize() = 0;
     virtual ~Compressor() {}

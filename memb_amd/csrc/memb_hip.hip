@@ -78,6 +78,7 @@ int fail(int code, const std::string& message)
 #include "hip_device_common.h"
 #include "hip_trained_kernels.h"
 #include "hip_rowwise_kernels.h"
+#include "hip_encoder_kernels.h"
 
 // ceil(2^32 / d) for fastDivide: exact for every q <= maxQ when maxQ * d < 2^32.
 // Returns 0 (plain division) for d == 1, where the magic does not fit 32 bits,
@@ -113,8 +114,9 @@ struct Switches {
     bool persistent = true;        // MEMB_HIP_PERSISTENT
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
-    uint32_t gridPolicy = 1;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
+    uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
                                    // make the same number of rounds, so that all of them walk the same number of tiles
+                                   // (measured: 0 is 0.5-1 % faster on every batch kind, 2.7 % on the union: profiles/r03_experiments.txt)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -243,15 +245,17 @@ uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t words
 }
 
 // Waves per block: as many resident wavefronts per CU as LDS allows (the
-// decode is a chain of dependent LDS lookups, so occupancy is what hides it),
-// larger blocks on ties (fewer copies of the lookup table).
+// decode is a chain of dependent LDS lookups, so occupancy is what hides it);
+// on ties blocks of four wavefronts (measured against eight on one allocation,
+// A/A floor 0.5 %: key-order dump -1.3 %, shuffled -0.9 %, 100 k rows -1.2 %,
+// two-model union -3.4 %; profiles/r03_experiments.txt), then larger ones.
 TrainedGeometry chooseGeometry(
     const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out)
 {
     TrainedGeometry best{};
     double bestWaves = -1;
     const uint32_t forcedWaves = ctx->switches.waves;
-    for (uint32_t waves : {8u, 4u, 2u, 1u}) {
+    for (uint32_t waves : {4u, 8u, 2u, 1u}) {
         if (forcedWaves && waves != forcedWaves) {
             continue;
         }
@@ -674,7 +678,7 @@ int launchTrainedUnion(
     auto chooseWaves = [&](uint32_t* waves, uint32_t* ldsBytes) {
         double bestResident = -1;
         *waves = 0;
-        for (uint32_t candidate : {8u, 4u, 2u, 1u}) {
+        for (uint32_t candidate : {4u, 8u, 2u, 1u}) {
             if (first->switches.waves && candidate != first->switches.waves) {
                 continue;
             }
@@ -1945,6 +1949,12 @@ int algorithmic_bytes_checked(const memb_hip_ctx* ctx, const uint32_t* rows, siz
     return MEMB_HIP_OK;
 }
 
+}  // namespace
+
+#include "hip_encoder.h"
+
+namespace {
+
 // No C++ exception leaves the library: allocation failures and the like become error codes.
 template <typename Call>
 int guarded(Call call)
@@ -1997,6 +2007,37 @@ int memb_hip_ctx_create_full(memb_hip_ctx** out, int device, const memb_hip_full
 int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
 {
     return guarded([&] { return ctx_get_info_checked(ctx, info); });
+}
+
+int memb_hip_encoder_create(memb_hip_encoder** encoder, int device, uint32_t dim, const float* split_points, uint32_t n_split_points)
+{
+    return guarded([&] { return encoder_create_checked(encoder, device, dim, split_points, n_split_points); });
+}
+
+void memb_hip_encoder_destroy(memb_hip_encoder* encoder)
+{
+    destroyEncoder(encoder);
+}
+
+int memb_hip_encoder_add_rows(memb_hip_encoder* encoder, const float* rows, size_t n_rows)
+{
+    return guarded([&] { return encoder_add_rows_checked(encoder, rows, n_rows); });
+}
+
+int memb_hip_encoder_counts(memb_hip_encoder* encoder, uint64_t* counts)
+{
+    return guarded([&] { return encoder_counts_checked(encoder, counts); });
+}
+
+int memb_hip_encoder_pack(
+    memb_hip_encoder* encoder, const uint16_t* codes, const uint8_t* lengths, uint32_t* stream_bytes, uint64_t* total_bytes)
+{
+    return guarded([&] { return encoder_pack_checked(encoder, codes, lengths, stream_bytes, total_bytes); });
+}
+
+int memb_hip_encoder_fetch(memb_hip_encoder* encoder, uint8_t* packed, uint64_t capacity)
+{
+    return guarded([&] { return encoder_fetch_checked(encoder, packed, capacity); });
 }
 
 int memb_hip_abi_version(void)

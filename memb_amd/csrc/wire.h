@@ -253,6 +253,21 @@ public:
         return createVector(elements.data(), elements.size());
     }
 
+    // A vector whose elements the caller fills in afterwards (same bytes as createVector of the same
+    // elements). *elements stays valid until the next call that adds to the buffer.
+    template <typename T>
+    Ref createVectorUninitialized(size_t count, T** elements)
+    {
+        preAlign(count * sizeof(T), 4);
+        preAlign(count * sizeof(T), sizeof(T));
+        ensure(count * sizeof(T));
+        used_ += count * sizeof(T);
+        const size_t position = used_;
+        const Ref result = pushScalar<uint32_t>(static_cast<uint32_t>(count));   // (reserved below: no reallocation)
+        *elements = reinterpret_cast<T*>(at(position));
+        return result;
+    }
+
     Ref createString(const char* chars, size_t length)
     {
         preAlign(length + 1, 4);

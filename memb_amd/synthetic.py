@@ -61,17 +61,18 @@ def _vector_block(seed, block, rows, dim, distribution):
 
 
 def build_file(path, count, dim=300, storage_type='trained', bits_per_weight=4,
-               seed=1234, word_seed=7, distribution='normal', slice_words=200000):
+               seed=1234, word_seed=7, distribution='normal', slice_words=200000, device=None):
     '''Write a synthetic model; returns the words in insertion order.
     Vectors are drawn in blocks of `slice_words` words on a few threads (numpy's generators release
-    the GIL) while the main thread hands finished blocks to the builder in order.'''
+    the GIL) while the main thread hands finished blocks to the builder in order.
+    device: HIP device for the builder's bulk work (memb_amd.Builder); the file is the same either way.'''
     from concurrent.futures import ThreadPoolExecutor
     if distribution not in ('normal', 'student'):
         raise ValueError('unknown distribution ' + distribution)
     words = make_words(count, word_seed)
-    builder = Builder(dim, storage_type, bits_per_weight)
+    builder = Builder(dim, storage_type, bits_per_weight, device=device)
     starts = list(range(0, count, slice_words))
-    workers = max(1, min(8, os.cpu_count() or 1, len(starts)))
+    workers = max(1, min(16, os.cpu_count() or 1, len(starts)))
     with ThreadPoolExecutor(max_workers=workers) as pool:
         pending = []
         submitted = 0
@@ -93,9 +94,10 @@ def cache_dir():
     return os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench')
 
 
-def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed=1234, distribution='normal'):
-    '''Path of a synthetic model in the per-box cache, written on first use.
-    Returns (path, seconds spent building; 0.0 when it was already there)'''
+def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed=1234, distribution='normal', device=None):
+    '''Path of a synthetic model in the per-box cache, written on first use (device: see build_file;
+    MEMB_SYNTH_DEVICE in the environment supplies a default). Returns (path, seconds spent building;
+    0.0 when it was already there)'''
     import time
     # g2: generator version -- build_file draws blocks >= 1 from generators of their own since round 2, so a
     # model of more than 200 000 words written by an older tree has other contents under the old name
@@ -104,6 +106,8 @@ def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed
     if os.path.exists(path):
         return path, 0.0
     os.makedirs(cache_dir(), exist_ok=True)
+    if device is None and os.environ.get('MEMB_SYNTH_DEVICE', '') != '':
+        device = int(os.environ['MEMB_SYNTH_DEVICE'])
     start = time.time()
-    build_file(path, count, dim, storage_type, bits_per_weight, seed=seed, distribution=distribution)
+    build_file(path, count, dim, storage_type, bits_per_weight, seed=seed, distribution=distribution, device=device)
     return path, time.time() - start

@@ -1,0 +1,207 @@
+"""Write side on the device: Builder(..., device=N) quantises, counts and bit-packs on the GPU
+(memb_hip_encoder_*, reference src/trained_compression.cpp:40-71, src/kmeans.cpp:66-80,
+src/huffman_encoder.cpp:88-97, src/bit_stream.h:18-34) and must write the file the host writer writes, byte
+for byte; the entry points are also driven directly through the C ABI against numpy restatements."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SIX_WORDS, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def write(native, path, words, vectors, storage, bits, device, single=False, blocks=1):
+    builder = native.Builder(vectors.shape[1], storage, bits, device=device)
+    if single:
+        for word, vector in zip(words, vectors):
+            builder.add_word(word, vector)
+    else:
+        edges = np.linspace(0, len(words), blocks + 1).astype(int)
+        for start, stop in zip(edges[:-1], edges[1:]):
+            builder.add_words(words[start:stop], vectors[start:stop])
+    builder.save(path)
+    with open(path, 'rb') as f:
+        return f.read()
+
+
+@pytest.mark.parametrize('count,dim,bits,distribution,blocks', [
+    (30000, 300, 4, 'normal', 3),      # BASELINE configs[1] shape: the sample completes inside the first block
+    (25000, 300, 6, 'student', 5),     # configs[2] shape, heavier tails: byte keys, long codes
+    (12000, 300, 2, 'normal', 1),
+    (15000, 300, 8, 'student', 2),     # up to 255 centroids, codes beyond 8 bits
+    (4000, 300, 4, 'normal', 2),       # fewer words than the k-means sample: everything happens in save
+    (11000, 7, 4, 'normal', 4),        # rows that are not a multiple of four scalars
+    (10000, 50, 4, 'normal', 1),       # exactly the sample size
+])
+def test_device_writer_writes_the_host_writers_bytes(native, tmp_path, count, dim, bits, distribution, blocks):
+    from memb_amd import synthetic
+    import oracle
+    words = synthetic.make_words(count)
+    vectors = synthetic.make_vectors(count, dim, seed=99, distribution=distribution)
+    host = write(native, str(tmp_path / 'host.bin'), words, vectors, 'trained', bits, None, blocks=blocks)
+    device = write(native, str(tmp_path / 'device.bin'), words, vectors, 'trained', bits, 0, blocks=blocks)
+    assert len(host) == len(device)
+    assert host == device
+    # and the rows a reader decodes from it are the checker's
+    reader = native.Reader(str(tmp_path / 'device.bin'), device=0)
+    rows = np.arange(count, dtype=np.uint32)
+    expected = oracle.OracleReader(str(tmp_path / 'device.bin'), 4).rows_embedding(rows)
+    assert bits_equal(reader.rows_embedding(rows), expected)
+
+
+def test_device_writer_word_by_word_and_special_values(native, tmp_path):
+    from memb_amd import synthetic
+    count, dim = 10500, 12
+    words = synthetic.make_words(count)
+    vectors = synthetic.make_vectors(count, dim, seed=3)
+    vectors[10200, 3] = np.inf          # after the sample: symbols of the extremes, never part of the fit
+    vectors[10201, 0] = -np.inf
+    vectors[10300, 5] = np.nan          # lower_bound finds no split point below a NaN: symbol 0
+    host = write(native, str(tmp_path / 'host.bin'), words, vectors, 'trained', 4, None, single=True)
+    device = write(native, str(tmp_path / 'device.bin'), words, vectors, 'trained', 4, 0, single=True)
+    assert host == device
+    # the reference's six words (src/tests.cpp:20-27), far below the sample size, dim 3
+    small_words = sorted(SIX_WORDS)
+    small = np.array([SIX_WORDS[w] for w in small_words], dtype=np.float32)
+    assert write(native, str(tmp_path / 'h6.bin'), small_words, small, 'trained', 8, None) == \
+        write(native, str(tmp_path / 'd6.bin'), small_words, small, 'trained', 8, 0)
+    # storages without device work take the argument and write the same file
+    for storage in ('uniform', 'full'):
+        assert write(native, str(tmp_path / 'hu.bin'), small_words, small, storage, 8, None) == \
+            write(native, str(tmp_path / 'du.bin'), small_words, small, storage, 8, 0)
+
+
+def test_duplicate_in_a_block_leaves_the_words_before_it_added(native, tmp_path):
+    from memb_amd import synthetic
+    words = synthetic.make_words(12000)
+    vectors = synthetic.make_vectors(12000, 8, seed=5)
+    for device in (None, 0):
+        builder = native.Builder(8, 'trained', 4, device=device)
+        builder.add_words(words[:11000], vectors[:11000])
+        with pytest.raises(RuntimeError, match='Attempt to add duplicate word'):
+            builder.add_words(words[11000:11500] + [words[5]] + words[11500:], np.concatenate(
+                [vectors[11000:11500], vectors[5:6], vectors[11500:]]))
+        builder.save(str(tmp_path / 'dup_{}.bin'.format(device)))
+    with open(str(tmp_path / 'dup_None.bin'), 'rb') as a, open(str(tmp_path / 'dup_0.bin'), 'rb') as b:
+        assert a.read() == b.read()
+    assert len(native.Reader(str(tmp_path / 'dup_0.bin'), device=0)) == 11500
+
+
+# ---- the entry points themselves, through the C ABI ----
+
+def encoder_library(native):
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+    library.memb_hip_encoder_destroy.restype = None
+    library.memb_hip_encoder_destroy.argtypes = [ctypes.c_void_p]
+    return library
+
+
+def pack_reference(symbols, codes, lengths):
+    """bit strings, MSB first, zero padded to a byte (reference src/bit_stream.h:18-34)"""
+    streams = []
+    for row in symbols:
+        text = ''.join(format(int(codes[s]), '0{}b'.format(int(lengths[s]))) if lengths[s] else '' for s in row)
+        text += '0' * (-len(text) % 8)
+        streams.append(bytes(int(text[i:i + 8], 2) for i in range(0, len(text), 8)))
+    return streams
+
+
+@pytest.mark.parametrize('dim,n_splits,rows', [(300, 15, 5000), (7, 254, 3001), (64, 0, 100), (1, 3, 4097)])
+def test_encoder_entry_points_against_numpy(native, dim, n_splits, rows):
+    library = encoder_library(native)
+    rng = np.random.default_rng(dim * 1000 + n_splits)
+    splits = np.sort(rng.standard_normal(n_splits).astype(np.float32))
+    if n_splits > 4:
+        splits[2] = splits[3]   # equal split points are legal (two centroids one ulp apart)
+    values = rng.standard_normal((rows, dim)).astype(np.float32)
+    values.flat[::97] = splits[rng.integers(0, n_splits, size=len(values.flat[::97]))] if n_splits else 0.0   # exact hits
+    values[0, 0] = np.nan
+    values[-1, -1] = np.inf
+    values[rows // 2, 0] = -np.inf
+    encoder = ctypes.c_void_p()
+    assert library.memb_hip_encoder_create(
+        ctypes.byref(encoder), 0, dim, splits.ctypes.data_as(ctypes.c_void_p), n_splits) == 0, library.memb_hip_last_error()
+    try:
+        # three uneven blocks
+        edges = [0, rows // 3, rows // 3 + 1, rows]
+        for start, stop in zip(edges[:-1], edges[1:]):
+            block = np.ascontiguousarray(values[start:stop])
+            assert library.memb_hip_encoder_add_rows(
+                encoder, block.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(stop - start)) == 0, library.memb_hip_last_error()
+        # std::lower_bound(splits, x) = number of split points < x; none is below a NaN
+        expected = np.searchsorted(splits, values, side='left').astype(np.uint8)
+        expected[np.isnan(values)] = 0
+        counts = np.zeros(256, dtype=np.uint64)
+        assert library.memb_hip_encoder_counts(encoder, counts.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(counts, np.bincount(expected.ravel(), minlength=256).astype(np.uint64))
+
+        # the packer does not care whether the code is prefix free: any lengths up to 16 bits, any code values
+        used = np.flatnonzero(counts)
+        lengths = np.zeros(256, dtype=np.uint8)
+        codes = np.zeros(256, dtype=np.uint16)
+        if len(used) > 1:   # (a single symbol costs no bits: empty streams, as in the reference)
+            lengths[used] = rng.integers(1, 17, size=len(used))
+            lengths[used[0]] = 16
+            lengths[used[-1]] = 1
+            codes[used] = rng.integers(0, 1 << 16, size=len(used)) >> (16 - lengths[used].astype(np.int64))
+            codes[used[0]] = 0xFFFF
+        stream_bytes = np.zeros(rows, dtype=np.uint32)
+        total = ctypes.c_uint64(0)
+        assert library.memb_hip_encoder_pack(
+            encoder, codes.ctypes.data_as(ctypes.c_void_p), lengths.ctypes.data_as(ctypes.c_void_p),
+            stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 0, library.memb_hip_last_error()
+        streams = pack_reference(expected, codes, lengths)
+        assert np.array_equal(stream_bytes, np.array([len(s) for s in streams], dtype=np.uint32))
+        assert total.value == sum(len(s) for s in streams)
+        packed = np.zeros(max(total.value, 1), dtype=np.uint8)
+        assert library.memb_hip_encoder_fetch(encoder, packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(total.value)) == 0
+        assert packed[:total.value].tobytes() == b''.join(streams)
+        # refusals
+        assert library.memb_hip_encoder_fetch(encoder, packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(max(total.value, 1) - 1)) == (1 if total.value else 0)
+        assert library.memb_hip_encoder_add_rows(encoder, values.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(1)) == 1   # after pack
+        bad = codes.copy()
+        bad[used[0]] = 0xFFFF
+        lengths_bad = lengths.copy()
+        lengths_bad[used[0]] = 3
+        assert library.memb_hip_encoder_pack(
+            encoder, bad.ctypes.data_as(ctypes.c_void_p), lengths_bad.ctypes.data_as(ctypes.c_void_p),
+            stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 1
+    finally:
+        library.memb_hip_encoder_destroy(encoder)
+
+
+def test_encoder_refusals(native):
+    library = encoder_library(native)
+    encoder = ctypes.c_void_p()
+    unsorted = np.array([1.0, 0.0], dtype=np.float32)
+    assert library.memb_hip_encoder_create(ctypes.byref(encoder), 0, 4, unsorted.ctypes.data_as(ctypes.c_void_p), 2) == 1
+    assert b'sorted' in library.memb_hip_last_error() and not encoder.value
+    assert library.memb_hip_encoder_create(ctypes.byref(encoder), 0, 0, None, 0) == 1
+    assert library.memb_hip_encoder_create(ctypes.byref(encoder), 99, 4, None, 0) == 1
+    assert library.memb_hip_encoder_add_rows(None, None, 0) == 1
+    library.memb_hip_encoder_destroy(None)
+
+
+def test_full_size_model_is_byte_identical_and_faster(native, tmp_path):
+    """The GloVe-shaped 2.2 M-word 4-bit model (BASELINE configs[1] / the headline), host writer vs device writer."""
+    import time
+    from memb_amd import synthetic
+    count = 2196017
+    paths = {}
+    seconds = {}
+    for name, device in (('device', 0), ('host', None)):
+        paths[name] = str(tmp_path / (name + '.bin'))
+        start = time.time()
+        synthetic.build_file(paths[name], count, 300, 'trained', 4, device=device)
+        seconds[name] = time.time() - start
+    print('model build, {} words: host writer {:.2f} s, device writer {:.2f} s'.format(count, seconds['host'], seconds['device']))
+    with open(paths['host'], 'rb') as a, open(paths['device'], 'rb') as b:
+        while True:
+            left, right = a.read(1 << 24), b.read(1 << 24)
+            assert left == right
+            if not left:
+                break

@@ -411,3 +411,26 @@ def test_files_with_omitted_default_scalars(native, tmp_path):
         assert native.Reader(files[True]).keys() == sorted(SIX_WORDS)
         if storage == 'full':
             assert os.path.getsize(files[True]) < os.path.getsize(files[False])
+
+
+def test_device_builder_never_falls_back_to_the_host(native, tmp_path):
+    # Builder(..., device=N) means the GPU does the bulk work; on a host without one it says so (the host
+    # writer is what Builder() without a device is)
+    if native.hip_device_count() > 0:
+        pytest.skip('this host has a HIP device: tests/test_gpu_writer.py covers the device writer')
+    from memb_amd import synthetic
+    words = synthetic.make_words(300)
+    vectors = synthetic.make_vectors(300, 8)
+    builder = native.Builder(8, 'trained', 4, device=0)
+    builder.add_words(words, vectors)
+    with pytest.raises(RuntimeError, match='no HIP device available'):
+        builder.save(str(tmp_path / 'never.bin'))
+    # storages without device work ignore the argument
+    for storage in ('uniform', 'full'):
+        plain = native.Builder(8, storage, 8)
+        on_device = native.Builder(8, storage, 8, device=0)
+        for builder in (plain, on_device):
+            builder.add_words(words, vectors)
+        plain.save(str(tmp_path / 'a.bin'))
+        on_device.save(str(tmp_path / 'b.bin'))
+        assert open(str(tmp_path / 'a.bin'), 'rb').read() == open(str(tmp_path / 'b.bin'), 'rb').read()

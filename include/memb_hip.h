@@ -135,6 +135,8 @@ typedef struct memb_hip_ctx_info {
     uint32_t row_layout;         /* trained: 2 = row records (fixed-size row regions, record in front of the stream),
                                     1 = compact streams + one 16-byte index record per row, 0 = compact streams + index arrays */
     uint32_t row_bytes;          /* trained, row records: bytes every row owns */
+    uint32_t kernel_registers;   /* trained, persistent kernel: vector registers per lane as the runtime reports them */
+    uint32_t register_waves_per_cu;   /* ... and the wavefronts per CU those registers allow (32 = no limit from registers) */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);
@@ -156,6 +158,8 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "nt_loads"        0 / 1   non-temporal loads of bitstreams and index records (persistent kernel)
  *   "waves_per_block" 0 = choose, or 1, 2, 4, 8
  *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
+ *   "pipeline"        persistent kernel of row-record models: 0 = the general one, 1 = decode_records_persistent with
+ *                     stream registers, 2 = the same fed by LDS-DMA (global_load_lds)
  *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
  *                     that make the same number of rounds (equal tiles per wavefront)
  *   "persistent"      0 / 1   one tile per wavefront instead of the persistent pipeline

@@ -112,6 +112,8 @@ py::dict contextInfo(memb::Reader& reader)
     result["kernel"] = std::string(info.kernel);
     result["row_layout"] = info.row_layout;
     result["row_bytes"] = info.row_bytes;
+    result["kernel_registers"] = info.kernel_registers;
+    result["register_waves_per_cu"] = info.register_waves_per_cu;
     return result;
 }
 

@@ -596,12 +596,29 @@ public:
             }
         }
 
-        // sort words with std::string::operator< (reference :73-79)
+        // sort words with std::string::operator< (reference :73-79). The words are distinct, so the order is
+        // unique: chunks sorted on threads and merged pairwise give what one std::sort gives.
         std::vector<uint32_t> order(wordCount);
         for (size_t w = 0; w < wordCount; ++w) {
             order[w] = static_cast<uint32_t>(w);
         }
-        std::sort(order.begin(), order.end(), [this](uint32_t a, uint32_t b) { return words_[a] < words_[b]; });
+        {
+            auto before = [this](uint32_t a, uint32_t b) { return words_[a] < words_[b]; };
+            size_t chunks = 1;
+            while (chunks < 32 && chunks * 2 <= std::max<size_t>(1, std::thread::hardware_concurrency()) &&
+                   wordCount / (chunks * 2) >= 16384) {
+                chunks *= 2;
+            }
+            const size_t chunkWords = (wordCount + chunks - 1) / chunks;
+            auto bound = [&](size_t chunk) { return order.begin() + std::min(wordCount, chunk * chunkWords); };
+            runParallel(chunks, [&](size_t chunk) { std::sort(bound(chunk), bound(chunk + 1), before); });
+            for (size_t width = 1; width < chunks; width *= 2) {
+                runParallel(chunks / (2 * width), [&](size_t pair) {
+                    const size_t first = pair * 2 * width;
+                    std::inplace_merge(bound(first), bound(first + width), bound(first + 2 * width), before);
+                });
+            }
+        }
 
         std::string packedWords;
         std::vector<uint32_t> wordOffsets;

@@ -38,6 +38,7 @@ struct TrainedParams {
     uint32_t dim;
     uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
     uint32_t slotMagic;       // fastDivide magic for loadPieces
+    uint32_t dmaMagic;        // fastDivide magic for slotDwords / 4 (LDS-DMA: pieces of the slot image)
     uint32_t lanesPerWord;    // G
     uint32_t laneMagic;       // fastDivide magic for G
     uint32_t wordsPerWave;    // 64 / G
@@ -49,6 +50,7 @@ struct TrainedParams {
     uint32_t indexSegmentSymbols;
     uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
     uint32_t debugFlags;      // measurement builds only (MEMB_HIP_MEASURE; see measureFlags below)
+    uint32_t slotSets;        // sets of bitstream slots per wavefront in LDS: 1, or 2 (decode_records_persistent with LDS-DMA)
     uint32_t accumulate;      // epilogue: add to what the output already holds ...
     float divisor;            // ... and / or divide by this (0 = no division)
 };
@@ -196,6 +198,10 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
     }
     meta.segmentBits = segmentField(role.segment, meta.segmentBits, meta.packed2, meta.packed3);
 }
+
+#ifndef MEMB_HIP_OUTPUT_BURST
+#define MEMB_HIP_OUTPUT_BURST 5   // 16-byte pieces a lane gathers before it stores them back to back (outputTile)
+#endif
 
 constexpr int STREAM_REGISTERS = 4;   // 16-byte pieces one lane can hold for a prefetched tile
 
@@ -489,7 +495,7 @@ __device__ __forceinline__ void outputTile(
         // BURST pieces per lane are gathered first and then stored back to back, so a
         // tile reaches memory as one burst of consecutive KiBs rather than one KiB per
         // LDS round trip.
-        constexpr int BURST = 5;
+        constexpr int BURST = MEMB_HIP_OUTPUT_BURST;
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = tileWords * piecesPerWord;
         float* tileOut = p.out + tileBase * p.ld + p.colOff;
@@ -578,12 +584,13 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
 {
     const uint32_t wave = threadIdx.x / WAVE;
     uint32_t* codebookLds = lds + p.tableDwords;
-    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
+    const uint32_t slotSets = p.slotSets ? p.slotSets : 1u;
+    const uint32_t perWave = slotSets * p.wordsPerWave * p.slotDwords + p.keyTileDwords;
     WaveLds result;
     result.table = reinterpret_cast<const TableEntry*>(lds);
     result.codebook = codebookLds;
     result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
-    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
+    result.keyTile = result.slots + slotSets * p.wordsPerWave * p.slotDwords;
 
     for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
@@ -753,6 +760,146 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
 }
 
 // ---------------------------------------------------------------------------
+// decode_records_persistent: the persistent pipeline for the ROW-RECORD layout only
+// ---------------------------------------------------------------------------
+// Every model of the benchmark is staged as row records (TrainedParams::recordPieces): a row's address is
+// arithmetic and its segment offsets arrive with its bitstream, so the pipeline needs no index stage and a
+// tile in flight is its row ids -- nothing else. The general kernel above carries three index records of
+// five registers each and four stream registers whatever the layout (117 VGPRs: 4 wavefronts per SIMD);
+// this one keeps the row ids of three tiles and either
+//   DMA = false  two stream registers (a tile of at most 128 pieces), or
+//   DMA = true   no stream registers at all: the next tile's row regions go from HBM straight into a second
+//                set of LDS slots (`global_load_lds_dwordx4`: each lane names its 16 source bytes, the
+//                wavefront's 1 KiB lands contiguously, so lane q of a round fetches piece q of the slot image),
+// which is what lets twice as many wavefronts stay resident (tools/perf/isa.py prints the registers).
+// Timeline of a round, same as the general kernel: decode tile t out of LDS | wait for the loads issued one
+// decode ago (tile t + 1's streams, tile t + 2's row ids) | store tile t | issue the loads of tile t + 2
+// (row ids of t + 3).
+constexpr int RECORD_ROUNDS = 2;   // 64-lane rounds per tile: 8 words x (160-byte region + padding piece) = 88 pieces
+
+template <bool NT>
+__device__ __forceinline__ void issueRecordLoads(
+    const TrainedParams& p, uint32_t row, uint32_t lane, u32x4& first, u32x4& second)
+{
+    const uint32_t start = row < p.nRows ? row * p.recordPieces : 0u;   // absent words read row 0 and never emit it
+    issueStreamLoad<NT>(p, start, lane, 0, first);
+    issueStreamLoad<NT>(p, start, lane, 1, second);
+}
+
+// LDS-DMA form: piece q of the slot image = 16 bytes of word q / slotPieces; the image is exactly what
+// writeStreams lays out (slots of slotDwords, an odd number of pieces), its padding pieces re-read piece 0
+// of their word (same line as a neighbouring lane's request: no extra traffic).
+__device__ __forceinline__ void issueRecordDma(
+    const TrainedParams& p, uint32_t row, uint32_t lane, uint32_t* slots)
+{
+    const uint32_t start = row < p.nRows ? row * p.recordPieces : 0u;
+    const uint32_t slotPieces = p.slotDwords / 4;
+    const uint32_t totalPieces = p.wordsPerWave * slotPieces;
+#pragma unroll
+    for (int round = 0; round < RECORD_ROUNDS; ++round) {
+        const uint32_t q = round * WAVE + lane;
+        if (q < totalPieces) {
+            const uint32_t w = fastDivide(q, p.dmaMagic, slotPieces);
+            uint32_t piece = q - w * slotPieces;
+            piece = piece < p.recordPieces ? piece : 0u;
+            const uint32_t wordStart = __shfl(start, w * p.lanesPerWord);
+            const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
+            // (C-style casts: generic -> global / LDS address spaces)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)source,
+                (__attribute__((address_space(3))) void*)(slots + round * WAVE * 4), 16, 0, 0);
+        }
+    }
+}
+
+template <bool HAS_SUB, int MODE, bool FAST, bool DMA>
+__global__ void decode_records_persistent(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr bool PACKED = !FAST;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
+    const LaneRole role = laneRole(p, lane);
+    // row ids before the table copy, which hides their latency
+    uint32_t rowCurrent = loadTileRow(p, tile, role);
+    uint32_t rowNext = loadTileRow(p, tile + stride, role);
+    uint32_t rowLoading = loadTileRow(p, tile + 2 * stride, role);
+    const WaveLds mem = setUpLds<MODE>(p, lds);
+    if (tile >= tiles) {
+        return;
+    }
+    const uint32_t setDwords = p.wordsPerWave * p.slotDwords;
+    uint32_t* slots = mem.slots;                        // the set being decoded
+    uint32_t* otherSlots = mem.slots + setDwords;       // DMA: the set being filled
+    u32x4 stream0, stream1;                             // !DMA: the next tile's pieces
+
+    // prologue
+    if (DMA) {
+        issueRecordDma(p, rowCurrent, lane, slots);
+        issueRecordDma(p, rowNext, lane, otherSlots);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        issueRecordLoads<false>(p, rowCurrent, lane, stream0, stream1);
+        writeStream(p, slots, lane, 0, stream0);
+        writeStream(p, slots, lane, 1, stream1);
+        issueRecordLoads<false>(p, rowNext, lane, stream0, stream1);
+    }
+    waveLdsFence();
+
+    for (; tile < tiles; tile += stride) {
+        const unsigned long long tileBase = tile * p.wordsPerWave;
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+        WordMeta meta;
+        meta.row = rowCurrent;
+        meta.start = 0;
+        meta.packed2 = 0;
+        meta.packed3 = 0;
+        recordSegmentBits(p, slots, role, meta);
+        if (!(measureFlags(p) & 1)) {
+            decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, slots, mem.keyTile, role, meta);
+        }
+        waveLdsFence();
+
+        // consume point: everything issued one decode ago
+        uint32_t rowAfterNext;
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the other set holds tile t + 1 now
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
+            uint32_t* swap = slots;
+            slots = otherSlots;
+            otherSlots = swap;
+        } else {
+            writeStream(p, slots, lane, 0, stream0);
+            writeStream(p, slots, lane, 1, stream1);
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (!(measureFlags(p) & 2)) {
+            outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowCurrent < p.nRows);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // the loads of tile t + 2 (its row ids landed a round ago) and the row ids of tile t + 3
+        if (DMA) {
+            issueRecordDma(p, rowAfterNext, lane, otherSlots);   // the set tile t was decoded from
+        } else {
+            issueRecordLoads<false>(p, rowAfterNext, lane, stream0, stream1);
+        }
+        rowLoading = loadTileRow(p, tile + 3 * stride, role);
+        rowCurrent = rowNext;
+        rowNext = rowAfterNext;
+        waveLdsFence();
+    }
+    if (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be landing when the block's LDS is handed on
+    }
+}
+
+// ---------------------------------------------------------------------------
 // decode_trained_union: ReadersUnion 'concatenate' in one launch
 // ---------------------------------------------------------------------------
 // The reference concatenates the readers' results on the host (python/memb/readers_union.py:32).
@@ -830,8 +977,13 @@ struct AbsentMasks {
 };
 
 // The merged rows of one tile out of the models' symbol tiles: 16 bytes per lane, row contiguous when
-// the column blocks are adjacent. absent[m]: ballot of the tile's words that model m does not know
+// the column blocks are adjacent. absent: per model, the ballot of the tile's words the model does not know
 // (nibble keys have no code for "absent").
+// The tile is walked as tileWords * COUNT "half rows" of dim / 4 pieces (one model's vector of one word):
+// piece q -> half row h = q / (dim / 4), word h / COUNT, model h % COUNT. Everything that depends on the
+// model only -- symbol tile, codebook, column -- is one multiply-add away, and whether a half row is absent
+// is one bit of a per-tile mask: the round-2 form spent more vector instructions here than in the decode
+// (profiles/r03_union_*: 112 VALU instructions per decoded word against 68 in the single-model kernel).
 template <bool FAST, int COUNT, bool AVERAGE>
 __device__ __forceinline__ void outputUnionTile(
     const UnionParams& u, const uint32_t* lds, const uint32_t* waveLds, unsigned long long tileBase, uint32_t tileWords,
@@ -839,66 +991,69 @@ __device__ __forceinline__ void outputUnionTile(
 {
     const TrainedParams& first = u.model[0];
     const uint32_t piecesPerWord = first.dim / 4;
-    const uint32_t pieces = tileWords * u.rowPieces;
-    // two steps, so that a burst's symbol reads are all issued before the codebook reads that
-    // depend on them
-    auto readKey = [&](uint32_t model, uint32_t word, uint32_t column) -> uint32_t {
-        uint32_t keyTileOffset = u.keyTileOffsetDwords[0];
+    // bit h of absentHalves: half row h (word h / COUNT of model h % COUNT) is absent. Lane h works its own bit out.
+    unsigned long long absentHalves = 0;
+    if (FAST) {
+        const uint32_t word = lane / COUNT;
+        const uint32_t model = lane - word * COUNT;
+        absentHalves = __ballot(lane < first.wordsPerWave * COUNT && absent.template lacks<COUNT>(model, word * first.lanesPerWord));
+    }
+    const uint32_t keyRowUnits = first.keyRowBytes / (FAST ? 2 : 4);   // symbol-tile row in 16-bit (nibble keys) or 32-bit units
+    // symbol tiles and column blocks of the models as "model 0 + model * step" where the steps are equal, else by select
+    auto keyTileOf = [&](uint32_t model) -> const uint32_t* {
+        uint32_t offset = u.keyTileOffsetDwords[0];
 #pragma unroll
         for (int i = 1; i < COUNT; ++i) {
-            keyTileOffset = model == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : keyTileOffset;
+            offset = model == static_cast<uint32_t>(i) ? u.keyTileOffsetDwords[i] : offset;
         }
-        const uint32_t* keyTile = waveLds + keyTileOffset;
-        const uint32_t at = word * (first.keyRowBytes / (FAST ? 2 : 4)) + column;
+        return waveLds + offset;
+    };
+    auto readKey = [&](uint32_t model, uint32_t word, uint32_t column) -> uint32_t {
+        const uint32_t* keyTile = keyTileOf(model);
+        const uint32_t at = word * keyRowUnits + column;
         return FAST ? reinterpret_cast<const uint16_t*>(keyTile)[at] : keyTile[at];
     };
-    auto lookUp = [&](uint32_t model, uint32_t word, uint32_t k) -> float4 {
+    auto gather = [&](uint32_t model, uint32_t k) -> float4 {
         const uint32_t* codebook = lds + u.codebookOffsetDwords + model * 512;
         if (FAST) {
             const float2 lo = reinterpret_cast<const float2*>(codebook)[k & 0xff];
             const float2 hi = reinterpret_cast<const float2*>(codebook)[k >> 8];
-            if (absent.template lacks<COUNT>(model, word * first.lanesPerWord)) {
-                return make_float4(0.f, 0.f, 0.f, 0.f);
-            }
             return make_float4(lo.x, lo.y, hi.x, hi.y);
         }
         const float* centroids = reinterpret_cast<const float*>(codebook);
         return make_float4(centroids[k & 0xff], centroids[(k >> 8) & 0xff], centroids[(k >> 16) & 0xff], centroids[k >> 24]);
     };
-    constexpr int BURST = AVERAGE ? 2 : 4;
-    constexpr int KEYS = AVERAGE ? COUNT : 1;   // symbol words a piece needs
-    for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
-        uint32_t k[BURST][KEYS];
-        uint32_t w[BURST];
-        uint32_t m[BURST];
-        uint32_t c[BURST];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (AVERAGE) {
+        const uint32_t pieces = tileWords * piecesPerWord;
+        constexpr int BURST = 2;
+        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+            uint32_t k[BURST][COUNT];
+            uint32_t w[BURST];
+            uint32_t c[BURST];
 #pragma unroll
-        for (int b = 0; b < BURST; ++b) {
-            const uint32_t q = min(q0 + WAVE * b, pieces - 1);
-            w[b] = fastDivide(q, u.rowMagic, u.rowPieces);
-            const uint32_t inRow = q - w[b] * u.rowPieces;
-            if (AVERAGE) {
-                m[b] = 0;
-                c[b] = inRow;
+            for (int b = 0; b < BURST; ++b) {
+                const uint32_t q = min(q0 + WAVE * b, pieces - 1);
+                w[b] = fastDivide(q, first.pieceMagic, piecesPerWord);
+                c[b] = q - w[b] * piecesPerWord;
 #pragma unroll
                 for (int i = 0; i < COUNT; ++i) {
-                    k[b][i] = readKey(i, w[b], inRow);
+                    k[b][i] = readKey(i, w[b], c[b]);
                 }
-            } else {
-                m[b] = fastDivide(inRow, first.pieceMagic, piecesPerWord);
-                c[b] = inRow - m[b] * piecesPerWord;
-                k[b][0] = readKey(m[b], w[b], c[b]);
             }
-        }
 #pragma unroll
-        for (int b = 0; b < BURST; ++b) {
-            float4 f;
-            unsigned long long colOff = u.model[0].colOff;
-            if (AVERAGE) {
-                f = lookUp(0, w[b], k[b][0]);
+            for (int b = 0; b < BURST; ++b) {
+                float4 f = gather(0, k[b][0]);
+                if (FAST && ((absentHalves >> (w[b] * COUNT)) & 1)) {
+                    f = zero;
+                }
 #pragma unroll
                 for (int i = 1; i < COUNT; ++i) {
-                    const float4 next = lookUp(i, w[b], k[b][i]);
+                    float4 next = gather(i, k[b][i]);
+                    if (FAST && ((absentHalves >> (w[b] * COUNT + i)) & 1)) {
+                        next = zero;
+                    }
                     f.x = addRn(f.x, next.x);
                     f.y = addRn(f.y, next.y);
                     f.z = addRn(f.z, next.z);
@@ -906,15 +1061,43 @@ __device__ __forceinline__ void outputUnionTile(
                 }
                 const float count = static_cast<float>(COUNT);
                 f = make_float4(__fdiv_rn(f.x, count), __fdiv_rn(f.y, count), __fdiv_rn(f.z, count), __fdiv_rn(f.w, count));
-            } else {
-                f = lookUp(m[b], w[b], k[b][0]);
-#pragma unroll
-                for (int i = 1; i < COUNT; ++i) {
-                    colOff = m[b] == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
+                if (q0 + WAVE * b < pieces) {
+                    *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + first.colOff + 4 * c[b]) = f;
                 }
             }
+        }
+        return;
+    }
+
+    const uint32_t pieces = tileWords * COUNT * piecesPerWord;
+    float* tileOut = first.out + tileBase * first.ld;
+    constexpr int BURST = 4;
+    for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+        uint32_t k[BURST];
+        uint32_t h[BURST];
+        uint32_t c[BURST];
+#pragma unroll
+        for (int b = 0; b < BURST; ++b) {
+            const uint32_t q = min(q0 + WAVE * b, pieces - 1);
+            h[b] = fastDivide(q, first.pieceMagic, piecesPerWord);
+            c[b] = q - h[b] * piecesPerWord;
+            k[b] = readKey(h[b] % COUNT, h[b] / COUNT, c[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < BURST; ++b) {
+            const uint32_t word = h[b] / COUNT;
+            const uint32_t model = h[b] % COUNT;
+            float4 f = gather(model, k[b]);
+            if (FAST && ((absentHalves >> h[b]) & 1)) {
+                f = zero;
+            }
+            unsigned long long colOff = u.model[0].colOff;
+#pragma unroll
+            for (int i = 1; i < COUNT; ++i) {
+                colOff = model == static_cast<uint32_t>(i) ? u.model[i].colOff : colOff;
+            }
             if (q0 + WAVE * b < pieces) {
-                *reinterpret_cast<float4*>(first.out + (tileBase + w[b]) * first.ld + colOff + 4 * c[b]) = f;
+                *reinterpret_cast<float4*>(tileOut + word * first.ld + colOff + 4 * c[b]) = f;
             }
         }
     }
@@ -980,48 +1163,53 @@ __global__ void decode_trained_union(UnionParams u)
     outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
-// The persistent form (the pipeline of decode_trained_persistent, see there). The unit of the pipeline
-// is (tile, model): a wavefront decodes its tile for model 0, then for model 1, ... -- each into that
-// model's symbol tile, all out of ONE set of bitstream slots -- and writes the merged rows after the last
-// model; while unit k is decoded, the bitstream bytes of unit k + 1 sit in registers and the index
-// records / row ids of units k + 2 / k + 3 are on their way. The loop body is unrolled over the models,
-// so which model a pipeline stage serves is a compile-time fact.
-template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE, bool NT>
-__global__ void decode_trained_union_persistent(UnionParams u)
+// The persistent form, for models staged as row records (the pipeline of decode_records_persistent, see
+// there). The unit of the pipeline is (tile, model): a wavefront decodes its tile for model 0, then for
+// model 1, ... -- each into that model's symbol tile, all out of ONE set of bitstream slots (two with
+// LDS-DMA) -- and writes the merged rows after the last model; while unit k is decoded, the row regions of
+// unit k + 1 are in registers (or landing in the other slot set) and the row ids of units k + 2 and k + 3
+// are on their way. The loop body is unrolled over the models, so which model a pipeline stage serves is
+// a compile-time fact.
+template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE, bool DMA>
+__global__ void decode_records_union_persistent(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = threadIdx.x / WAVE;
     const TrainedParams& first = u.model[0];
-    setUpUnionLds<COUNT>(u, lds);
-
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
     const unsigned long long tiles = (first.n + first.wordsPerWave - 1) / first.wordsPerWave;
-    if (tile >= tiles) {
-        return;
-    }
     const LaneRole role = laneRole(first, lane);
-    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
-    uint32_t* slots = waveLds + u.slotOffsetDwords[0];
 
     // unit k of this wavefront: model k % COUNT of tile `tile + (k / COUNT) * stride`
     #define UNION_MODEL(k) u.model[(k) % COUNT]
     #define UNION_TILE(base, k) ((base) + static_cast<unsigned long long>((k) / COUNT) * stride)
 
-    // prologue: fill the pipeline
-    uint32_t rowLoading = loadTileRow(UNION_MODEL(3), UNION_TILE(tile, 3), role);
-    WordMeta meta0 = loadWordMeta<NT>(UNION_MODEL(0), loadTileRow(UNION_MODEL(0), UNION_TILE(tile, 0), role), role);
-    WordMeta meta1 = loadWordMeta<NT>(UNION_MODEL(1), loadTileRow(UNION_MODEL(1), UNION_TILE(tile, 1), role), role);
-    WordMeta metaLoading = loadWordMeta<NT>(UNION_MODEL(2), loadTileRow(UNION_MODEL(2), UNION_TILE(tile, 2), role), role);
-    unpackMeta(UNION_MODEL(0), role, meta0);
-    unpackMeta(UNION_MODEL(1), role, meta1);
-    StreamRegisters streams;
-    issueStreamLoads<NT>(UNION_MODEL(0), meta0, lane, 0, streams);
-    writeStreams(UNION_MODEL(0), slots, lane, 0, streams);
-    issueStreamLoads<NT>(UNION_MODEL(1), meta1, lane, 0, streams);
+    // row ids of the first three units before the copy of tables and codebooks, which hides their latency
+    uint32_t rowCurrent = loadTileRow(UNION_MODEL(0), UNION_TILE(tile, 0), role);
+    uint32_t rowNext = loadTileRow(UNION_MODEL(1), UNION_TILE(tile, 1), role);
+    uint32_t rowLoading = loadTileRow(UNION_MODEL(2), UNION_TILE(tile, 2), role);
+    setUpUnionLds<COUNT>(u, lds);
+    if (tile >= tiles) {
+        return;
+    }
+    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
+    uint32_t* slots = waveLds + u.slotOffsetDwords[0];          // the set being decoded
+    uint32_t* otherSlots = waveLds + u.slotOffsetDwords[1];     // DMA: the set being filled
+    u32x4 stream0, stream1;                                      // !DMA: the next unit's pieces
+
+    if (DMA) {
+        issueRecordDma(UNION_MODEL(0), rowCurrent, lane, slots);
+        issueRecordDma(UNION_MODEL(1), rowNext, lane, otherSlots);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        issueRecordLoads<false>(UNION_MODEL(0), rowCurrent, lane, stream0, stream1);
+        writeStream(UNION_MODEL(0), slots, lane, 0, stream0);
+        writeStream(UNION_MODEL(0), slots, lane, 1, stream1);
+        issueRecordLoads<false>(UNION_MODEL(1), rowNext, lane, stream0, stream1);
+    }
     waveLdsFence();
-    recordSegmentBits(UNION_MODEL(0), slots, role, meta0);
 
     AbsentMasks absent;
     for (; tile < tiles; tile += stride) {
@@ -1030,25 +1218,32 @@ __global__ void decode_trained_union_persistent(UnionParams u)
             static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
 #pragma unroll
         for (int m = 0; m < COUNT; ++m) {
-            // invariant: slots hold the bitstreams of unit (tile, m); `streams` = unit + 1, `metaLoading` = unit + 2,
-            // `rowLoading` = unit + 3 in flight
+            // invariant: `slots` hold the row regions of unit (tile, m); unit + 1 in registers / landing in the
+            // other set, the row ids of unit + 2 landed, those of unit + 3 in flight
+            WordMeta meta;
+            meta.row = rowCurrent;
+            meta.start = 0;
+            meta.packed2 = 0;
+            meta.packed3 = 0;
+            recordSegmentBits(u.model[m], slots, role, meta);
             decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
                 u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
-                waveLds + u.keyTileOffsetDwords[m], role, meta0);
-            absent.set(m, __ballot(!(meta0.row < u.model[m].nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
+                waveLds + u.keyTileOffsetDwords[m], role, meta);
+            absent.set(m, __ballot(!(rowCurrent < u.model[m].nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
             waveLdsFence();
 
-            // consume point (see decode_trained_persistent)
-            writeStreams(UNION_MODEL(m + 1), slots, lane, 0, streams);
-            WordMeta meta2;
-            uint32_t row3;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed2) : "v"(metaLoading.packed2));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed3) : "v"(metaLoading.packed3));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
-            unpackMeta(UNION_MODEL(m + 2), role, meta2);
+            // consume point: everything issued one decode ago
+            uint32_t rowAfterNext;
+            if (DMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t* swap = slots;
+                slots = otherSlots;
+                otherSlots = swap;
+            } else {
+                writeStream(UNION_MODEL(m + 1), slots, lane, 0, stream0);
+                writeStream(UNION_MODEL(m + 1), slots, lane, 1, stream1);
+            }
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
             __builtin_amdgcn_sched_barrier(0);
 
             if (m == COUNT - 1) {
@@ -1057,14 +1252,19 @@ __global__ void decode_trained_union_persistent(UnionParams u)
             }
             __builtin_amdgcn_sched_barrier(0);
 
-            issueStreamLoads<NT>(UNION_MODEL(m + 2), meta2, lane, 0, streams);
-            metaLoading = loadWordMeta<NT>(UNION_MODEL(m + 3), row3, role);
-            rowLoading = loadTileRow(UNION_MODEL(m + 4), UNION_TILE(tile, m + 4), role);
-            meta0 = meta1;
-            meta1 = meta2;
+            if (DMA) {
+                issueRecordDma(UNION_MODEL(m + 2), rowAfterNext, lane, otherSlots);
+            } else {
+                issueRecordLoads<false>(UNION_MODEL(m + 2), rowAfterNext, lane, stream0, stream1);
+            }
+            rowLoading = loadTileRow(UNION_MODEL(m + 3), UNION_TILE(tile, m + 3), role);
+            rowCurrent = rowNext;
+            rowNext = rowAfterNext;
             waveLdsFence();
-            recordSegmentBits(UNION_MODEL(m + 1), slots, role, meta0);
         }
+    }
+    if (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be landing when the block's LDS is handed on
     }
     #undef UNION_MODEL
     #undef UNION_TILE

@@ -114,6 +114,8 @@ struct Switches {
     bool persistent = true;        // MEMB_HIP_PERSISTENT
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
+    uint32_t pipeline = 0;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
+                                   // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA
     uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
                                    // make the same number of rounds, so that all of them walk the same number of tiles
                                    // (measured: 0 is 0.5-1 % faster on every batch kind, 2.7 % on the union: profiles/r03_experiments.txt)
@@ -235,9 +237,9 @@ uint32_t packedTableDwords(const memb_hip_ctx* ctx)
 }
 
 // withKeys: a lookup kernel (symbol tiles; byte-key models then use the PACKED layout); without: the index pass
-uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys)
+uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys, uint32_t slotSets = 1)
 {
-    uint32_t perWave = wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
+    uint32_t perWave = slotSets * wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
     if (withKeys && !ctx->fast) {
         return 4u * (packedTableDwords(ctx) + codebookDwords(ctx) + waves * perWave);
     }
@@ -249,8 +251,12 @@ uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t words
 // on ties blocks of four wavefronts (measured against eight on one allocation,
 // A/A floor 0.5 %: key-order dump -1.3 %, shuffled -0.9 %, 100 k rows -1.2 %,
 // two-model union -3.4 %; profiles/r03_experiments.txt), then larger ones.
+// slotSets: sets of bitstream slots per wavefront (2 for the LDS-DMA pipeline). registerWavesPerCu: how many
+// wavefronts of the kernel about to be launched its registers let a CU hold (32 when unknown): a block size
+// whose LDS would allow more resident wavefronts than the registers do gains nothing by it.
 TrainedGeometry chooseGeometry(
-    const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out)
+    const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out, uint32_t slotSets = 1,
+    uint32_t registerWavesPerCu = 32)
 {
     TrainedGeometry best{};
     double bestWaves = -1;
@@ -259,12 +265,14 @@ TrainedGeometry chooseGeometry(
         if (forcedWaves && waves != forcedWaves) {
             continue;
         }
-        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true);
+        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true, slotSets);
         if (ldsBytes > ctx->ldsLimit) {
             continue;
         }
-        // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU.
-        uint32_t blocksPerCu = std::min<uint32_t>(ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), 32 / waves);
+        // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU, fewer when the kernel's
+        // registers say so (512 per lane and SIMD, MI355X_MICROARCH.md "Register files")
+        uint32_t blocksPerCu = std::min<uint32_t>(
+            ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), std::max<uint32_t>(1, std::min<uint32_t>(32, registerWavesPerCu) / waves));
         double residentWaves = blocksPerCu * waves;
         if (residentWaves > bestWaves) {
             bestWaves = residentWaves;
@@ -305,31 +313,129 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
     return hipGetLastError();
 }
 
-template <bool HAS_SUB, int MODE, bool FAST, bool NT>
-hipError_t launchPersistentVariant(
-    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+typedef void (*TrainedKernel)(TrainedParams);
+
+// Which persistent kernel serves a context: pipeline 0 = decode_trained_persistent (any layout),
+// 1 = decode_records_persistent with stream registers, 2 = the same with LDS-DMA (row records only).
+template <bool HAS_SUB, int MODE, bool FAST>
+TrainedKernel persistentKernelOf(uint32_t pipeline, bool ntLoads)
 {
-    static thread_local int configuredDevice = -1;
-    static thread_local int blocksPerCu = 0;
-    static thread_local uint32_t configuredThreads = 0;
-    static thread_local uint32_t configuredLds = 0;
+    switch (pipeline) {
+        case 1:
+            return &decode_records_persistent<HAS_SUB, MODE, FAST, false>;
+        case 2:
+            return &decode_records_persistent<HAS_SUB, MODE, FAST, true>;
+        default:
+            return ntLoads ? &decode_trained_persistent<HAS_SUB, MODE, FAST, true>
+                           : &decode_trained_persistent<HAS_SUB, MODE, FAST, false>;
+    }
+}
+
+template <int MODE>
+TrainedKernel persistentKernelOfMode(const memb_hip_ctx* ctx, uint32_t pipeline)
+{
+    if (ctx->fast) {
+        return persistentKernelOf<false, MODE, true>(pipeline, ctx->switches.ntLoads);
+    }
+    return ctx->byteTable.hasSubTables ? persistentKernelOf<true, MODE, false>(pipeline, ctx->switches.ntLoads)
+                                       : persistentKernelOf<false, MODE, false>(pipeline, ctx->switches.ntLoads);
+}
+
+TrainedKernel persistentKernel(const memb_hip_ctx* ctx, int mode, uint32_t pipeline)
+{
+    switch (mode) {
+        case OUT_FLAT:
+            return persistentKernelOfMode<OUT_FLAT>(ctx, pipeline);
+        case OUT_VEC4:
+            return persistentKernelOfMode<OUT_VEC4>(ctx, pipeline);
+        case OUT_KEYS:
+            return persistentKernelOfMode<OUT_KEYS>(ctx, pipeline);
+        default:
+            return persistentKernelOfMode<OUT_SCALAR>(ctx, pipeline);
+    }
+}
+
+// What the runtime knows about a kernel on a device: registers (-> wavefronts a CU can hold) and, per
+// (block size, LDS), the resident blocks per CU. Looked up once.
+struct KernelFacts {
+    int numRegs = 0;
+    uint32_t registerWavesPerCu = 32;
+    bool ldsRaised = false;
+    std::vector<std::pair<std::pair<uint32_t, uint32_t>, int>> blocksPerCu;   // (threads, ldsBytes) -> blocks
+};
+
+std::mutex g_kernelFactsMutex;
+std::vector<std::pair<std::pair<const void*, int>, KernelFacts>> g_kernelFacts;   // (kernel, device) ->
+
+// (caller holds g_kernelFactsMutex)
+hipError_t kernelFactsLocked(const void* kernel, KernelFacts** out)
+{
     int device = 0;
     (void)hipGetDevice(&device);
-    const void* kernel = reinterpret_cast<const void*>(&decode_trained_persistent<HAS_SUB, MODE, FAST, NT>);
-    if (configuredDevice != device || configuredThreads != threads || configuredLds != ldsBytes) {
-        hipError_t status = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (auto& entry : g_kernelFacts) {
+        if (entry.first.first == kernel && entry.first.second == device) {
+            *out = &entry.second;
+            return hipSuccess;
+        }
+    }
+    KernelFacts facts;
+    hipFuncAttributes attributes;
+    hipError_t status = hipFuncGetAttributes(&attributes, kernel);
+    if (status != hipSuccess) {
+        return status;
+    }
+    facts.numRegs = attributes.numRegs;
+    // allocation granule 8 registers, 512 per lane per SIMD, 4 SIMDs, at most 8 wavefronts each
+    const int allocated = std::max(8, (attributes.numRegs + 7) / 8 * 8);
+    facts.registerWavesPerCu = 4u * static_cast<uint32_t>(std::min(8, 512 / allocated));
+    status = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (status != hipSuccess) {
+        return status;
+    }
+    facts.ldsRaised = true;
+    g_kernelFacts.push_back({{kernel, device}, facts});
+    *out = &g_kernelFacts.back().second;
+    return hipSuccess;
+}
+
+hipError_t registerWavesPerCu(TrainedKernel kernel, uint32_t* waves, int* numRegs)
+{
+    std::lock_guard<std::mutex> lock(g_kernelFactsMutex);
+    KernelFacts* facts = nullptr;
+    hipError_t status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
+    if (status == hipSuccess) {
+        *waves = facts->registerWavesPerCu;
+        *numRegs = facts->numRegs;
+    }
+    return status;
+}
+
+// launch(blocks) enqueues `kernel` (threads per block, ldsBytes of dynamic LDS) with that many blocks.
+template <typename Launch>
+hipError_t launchPersistentGeneric(
+    const memb_hip_ctx* ctx, const void* kernel, Launch launch, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes)
+{
+    int blocksPerCu = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_kernelFactsMutex);
+        KernelFacts* facts = nullptr;
+        hipError_t status = kernelFactsLocked(kernel, &facts);
         if (status != hipSuccess) {
             return status;
         }
-        status = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &blocksPerCu, decode_trained_persistent<HAS_SUB, MODE, FAST, NT>, static_cast<int>(threads), ldsBytes);
-        if (status != hipSuccess) {
-            return status;
+        for (const auto& known : facts->blocksPerCu) {
+            if (known.first.first == threads && known.first.second == ldsBytes) {
+                blocksPerCu = known.second;
+            }
         }
-        blocksPerCu = std::max(blocksPerCu, 1);
-        configuredDevice = device;
-        configuredThreads = threads;
-        configuredLds = ldsBytes;
+        if (!blocksPerCu) {
+            status = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCu, kernel, static_cast<int>(threads), ldsBytes);
+            if (status != hipSuccess) {
+                return status;
+            }
+            blocksPerCu = std::max(blocksPerCu, 1);
+            facts->blocksPerCu.push_back({{threads, ldsBytes}, blocksPerCu});
+        }
     }
     // as many blocks as are resident at once; each wavefront strides over the tiles
     uint32_t perCu = static_cast<uint32_t>(blocksPerCu);
@@ -341,34 +447,22 @@ hipError_t launchPersistentVariant(
     if (ctx->switches.gridPolicy == 1 && tileBlocks > resident) {
         // Wavefront w walks tiles w, w + W, w + 2 W, ...: with every slot taken, a batch of 3.05 tiles per slot
         // leaves a few wavefronts a fourth tile to do alone at the end. The same number of rounds with fewer
-        // wavefronts gives all of them the same work (to within one tile).
+        // wavefronts gives all of them the same work (to within one tile). (Measured: no gain; kept as an option.)
         const uint32_t rounds = (tileBlocks + resident - 1) / resident;
         blocks = (tileBlocks + rounds - 1) / rounds;
     }
-    hipLaunchKernelGGL(
-        (decode_trained_persistent<HAS_SUB, MODE, FAST, NT>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
+    launch(blocks);
     return hipGetLastError();
 }
 
-template <bool HAS_SUB, int MODE, bool FAST>
-hipError_t launchPersistentLoads(
-    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+hipError_t launchPersistent(
+    const memb_hip_ctx* ctx, TrainedKernel kernel, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads,
+    uint32_t ldsBytes, hipStream_t stream)
 {
-    return ctx->switches.ntLoads
-        ? launchPersistentVariant<HAS_SUB, MODE, FAST, true>(ctx, params, tileBlocks, threads, ldsBytes, stream)
-        : launchPersistentVariant<HAS_SUB, MODE, FAST, false>(ctx, params, tileBlocks, threads, ldsBytes, stream);
-}
-
-template <int MODE>
-hipError_t launchPersistentMode(
-    const memb_hip_ctx* ctx, const TrainedParams& params, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
-{
-    if (ctx->fast) {
-        return launchPersistentLoads<false, MODE, true>(ctx, params, blocks, threads, ldsBytes, stream);
-    }
-    return ctx->byteTable.hasSubTables
-        ? launchPersistentLoads<true, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream)
-        : launchPersistentLoads<false, MODE, false>(ctx, params, blocks, threads, ldsBytes, stream);
+    return launchPersistentGeneric(
+        ctx, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
+        }, tileBlocks, threads, ldsBytes);
 }
 
 template <int MODE>
@@ -412,20 +506,72 @@ struct Epilogue {
     float divisor = 0.f;
 };
 
+// Which kernel a batch of this output shape runs, and with what launch geometry.
+struct TrainedPlan {
+    bool persistent = false;
+    uint32_t pipeline = 0;               // 0 general, 1 records + stream registers, 2 records + LDS-DMA
+    TrainedGeometry geometry{};
+    TrainedKernel kernel = nullptr;      // persistent only
+    uint32_t registerWavesPerCu = 32;    // persistent only: what the kernel's registers allow
+    int numRegs = 0;
+};
+
+// (the context's device is current)
+int planTrained(const memb_hip_ctx* ctx, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan)
+{
+    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
+    // (long streams with few lanes per word) take the one-shot kernel.
+    const uint32_t tilePieces = wordsPerWave * (ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4);
+    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS && ctx->switches.persistent;
+    // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
+    // both need the tile's slot image to fit two 64-lane rounds.
+    plan->pipeline = 0;
+    if (plan->persistent && ctx->recordPieces && ctx->switches.pipeline &&
+        wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE) {
+        plan->pipeline = ctx->switches.pipeline;
+    }
+    const uint32_t slotSets = plan->pipeline == 2 ? 2 : 1;
+    plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, slotSets);
+    if (keysOut) {
+        plan->geometry.mode = OUT_KEYS;
+    }
+    if (plan->persistent && plan->geometry.waves) {
+        // again with what the kernel's registers allow (a block size whose LDS would hold more wavefronts than
+        // the registers admit is no better than a smaller one)
+        plan->kernel = persistentKernel(ctx, plan->geometry.mode, plan->pipeline);
+        hipError_t status = registerWavesPerCu(plan->kernel, &plan->registerWavesPerCu, &plan->numRegs);
+        if (status != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
+        }
+        const int mode = plan->geometry.mode;
+        plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, slotSets, plan->registerWavesPerCu);
+        plan->geometry.mode = mode;
+    }
+    return MEMB_HIP_OK;
+}
+
 // keysOut: `out` receives rows of centroid indices (OUT_KEYS) instead of fp32 rows; ld = dim, colOff = 0.
 int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
     const Epilogue& epilogue, bool keysOut = false)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-    TrainedGeometry geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out);
-    if (keysOut) {
-        geometry.mode = OUT_KEYS;
+    TrainedPlan plan;
+    int planned = planTrained(ctx, ld, colOff, out, keysOut, &plan);
+    if (planned != MEMB_HIP_OK) {
+        return planned;
     }
+    const bool persistent = plan.persistent;
+    const uint32_t pipeline = plan.pipeline;
+    TrainedGeometry geometry = plan.geometry;
+    TrainedKernel kernel = plan.kernel;
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
     TrainedParams params = baseTrainedParams(ctx);
+    params.slotSets = pipeline == 2 ? 2 : 1;
+    params.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -459,7 +605,7 @@ int launchTrained(
             params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
             uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
             (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
-            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
+            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true, params.slotSets) &&
             (ctx->fast || (params.table != nullptr && params.tableDwords >= (1u << params.rootBits))) &&
             geometry.ldsBytes <= ctx->ldsLimit && ld >= colOff + params.dim;
         if (!consistent) {
@@ -469,28 +615,24 @@ int launchTrained(
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;
-    // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
-    // (long streams with few lanes per word) take the one-shot kernel.
-    const uint32_t streamRounds = (wordsPerWave * params.loadPieces + WAVE - 1) / WAVE;
-    const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
     hipError_t status;
-    switch (geometry.mode) {
-        case OUT_FLAT:
-            status = persistent ? launchPersistentMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
-                                : launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
-            break;
-        case OUT_VEC4:
-            status = persistent ? launchPersistentMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
-                                : launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
-            break;
-        case OUT_KEYS:
-            status = persistent ? launchPersistentMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
-                                : launchTrainedMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
-            break;
-        default:
-            status = persistent ? launchPersistentMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream)
-                                : launchTrainedMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
-            break;
+    if (persistent) {
+        status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
+    } else {
+        switch (geometry.mode) {
+            case OUT_FLAT:
+                status = launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                break;
+            case OUT_VEC4:
+                status = launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                break;
+            case OUT_KEYS:
+                status = launchTrainedMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                break;
+            default:
+                status = launchTrainedMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                break;
+        }
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained launch: ") + hipGetErrorString(status));
@@ -498,96 +640,36 @@ int launchTrained(
     return MEMB_HIP_OK;
 }
 
-struct UnionLaunch {
-    uint32_t blocks;         // one tile per wavefront
-    uint32_t threads;
-    uint32_t ldsBytes;
-    bool persistent;
-    bool ntLoads;
-    uint32_t blocksPerCuCap;
-    uint32_t cuCount;
-    bool evenRounds;
-};
+typedef void (*UnionKernel)(UnionParams);
 
-template <bool HAS_SUB, bool FAST, bool AVERAGE, int COUNT>
-hipError_t launchUnionCount(const UnionParams& params, const UnionLaunch& launch, hipStream_t stream)
+// pipeline: 0 = one tile per wavefront, 1 = persistent with stream registers, 2 = persistent with LDS-DMA
+// (both persistent forms: two models staged as row records)
+template <bool HAS_SUB, bool FAST, bool AVERAGE>
+UnionKernel unionKernelOf(size_t count, uint32_t pipeline)
 {
-    if (!launch.persistent) {
-        static thread_local int configuredDevice = -1;
-        int device = 0;
-        (void)hipGetDevice(&device);
-        if (configuredDevice != device) {
-            hipError_t status = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (status != hipSuccess) {
-                return status;
-            }
-            configuredDevice = device;
-        }
-        hipLaunchKernelGGL(
-            (decode_trained_union<HAS_SUB, FAST, COUNT, AVERAGE>), dim3(launch.blocks), dim3(launch.threads), launch.ldsBytes,
-            stream, params);
-        return hipGetLastError();
+    if (pipeline) {
+        return pipeline == 2 ? &decode_records_union_persistent<HAS_SUB, FAST, 2, AVERAGE, true>
+                             : &decode_records_union_persistent<HAS_SUB, FAST, 2, AVERAGE, false>;
     }
-    // persistent: as many blocks as are resident at once, each wavefront strides over the tiles
-    auto run = [&](auto kernel) -> hipError_t {
-        static thread_local int configuredDevice = -1;
-        static thread_local int blocksPerCu = 0;
-        static thread_local uint32_t configuredThreads = 0;
-        static thread_local uint32_t configuredLds = 0;
-        int device = 0;
-        (void)hipGetDevice(&device);
-        if (configuredDevice != device || configuredThreads != launch.threads || configuredLds != launch.ldsBytes) {
-            hipError_t status = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (status != hipSuccess) {
-                return status;
-            }
-            status = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &blocksPerCu, kernel, static_cast<int>(launch.threads), launch.ldsBytes);
-            if (status != hipSuccess) {
-                return status;
-            }
-            blocksPerCu = std::max(blocksPerCu, 1);
-            configuredDevice = device;
-            configuredThreads = launch.threads;
-            configuredLds = launch.ldsBytes;
-        }
-        uint32_t perCu = static_cast<uint32_t>(blocksPerCu);
-        if (launch.blocksPerCuCap) {
-            perCu = std::min(perCu, launch.blocksPerCuCap);
-        }
-        const uint32_t resident = perCu * launch.cuCount;
-        uint32_t blocks = std::min(launch.blocks, resident);
-        if (launch.evenRounds && launch.blocks > resident) {   // as launchPersistentVariant
-            const uint32_t rounds = (launch.blocks + resident - 1) / resident;
-            blocks = (launch.blocks + rounds - 1) / rounds;
-        }
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(launch.threads), launch.ldsBytes, stream, params);
-        return hipGetLastError();
-    };
-    // (two models only: the three- and four-model forms of the pipeline need more than 128 registers and
-    // still spill; launchTrainedUnion never asks for them)
-    if constexpr (COUNT == 2) {
-        return launch.ntLoads ? run(&decode_trained_union_persistent<HAS_SUB, FAST, COUNT, AVERAGE, true>)
-                              : run(&decode_trained_union_persistent<HAS_SUB, FAST, COUNT, AVERAGE, false>);
-    } else {
-        return hipErrorInvalidValue;
+    switch (count) {
+        case 2:
+            return &decode_trained_union<HAS_SUB, FAST, 2, AVERAGE>;
+        case 3:
+            return &decode_trained_union<HAS_SUB, FAST, 3, AVERAGE>;
+        default:
+            return &decode_trained_union<HAS_SUB, FAST, 4, AVERAGE>;
     }
 }
 
-template <bool HAS_SUB, bool FAST, bool AVERAGE>
-hipError_t launchUnionVariant(const UnionParams& params, size_t count, const UnionLaunch& launch, hipStream_t stream)
+UnionKernel unionKernel(bool hasSub, bool fast, bool average, size_t count, uint32_t pipeline)
 {
-    switch (count) {
-        case 2:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 2>(params, launch, stream);
-        case 3:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 3>(params, launch, stream);
-        default:
-            return launchUnionCount<HAS_SUB, FAST, AVERAGE, 4>(params, launch, stream);
+    if (fast) {
+        return average ? unionKernelOf<false, true, true>(count, pipeline) : unionKernelOf<false, true, false>(count, pipeline);
     }
+    if (hasSub) {
+        return average ? unionKernelOf<true, false, true>(count, pipeline) : unionKernelOf<true, false, false>(count, pipeline);
+    }
+    return average ? unionKernelOf<false, false, true>(count, pipeline) : unionKernelOf<false, false, false>(count, pipeline);
 }
 
 // See memb_hip_decode_rows_union_device. MEMB_HIP_UNSUPPORTED when the models cannot share the kernel.
@@ -621,9 +703,9 @@ int launchTrainedUnion(
     // one tile per resident wavefront to amortise it over.
     bool persistent = first->switches.persistent && count == 2;
     for (size_t m = 0; m < count; ++m) {
-        const uint32_t loadPieces = ctxs[m]->recordPieces ? ctxs[m]->recordPieces : ctxs[m]->slotDwords / 4;
-        persistent = persistent && (wordsPerWave * loadPieces + WAVE - 1) / WAVE <= STREAM_REGISTERS;
+        persistent = persistent && ctxs[m]->recordPieces && wordsPerWave * (ctxs[m]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     }
+    const bool dma = first->switches.pipeline == 2;
 
     UnionParams params{};
     uint32_t sharedDwords = 0;
@@ -642,7 +724,8 @@ int launchTrainedUnion(
         p.segmentSymbols = ctx->segmentSymbols;
         p.keyRowBytes = keyRowBytes(ctx);
         p.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
-        p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(count) * (ctx->dim / 4));
+        p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * count * (ctx->dim / 4));
+        p.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
         params.tableOffsetDwords[m] = sharedDwords;
         sharedDwords += ctx->tableDwords;
     }
@@ -662,6 +745,10 @@ int launchTrainedUnion(
                 params.slotOffsetDwords[m] = 0;
             }
             at = roundUp4(slotDwords);
+            if (dma) {   // a second set, filled by LDS-DMA while the first is decoded (slotOffsetDwords[1]: count == 2)
+                params.slotOffsetDwords[1] = at;
+                at *= 2;
+            }
         }
         for (size_t m = 0; m < count; ++m) {
             if (!sharedSlots) {
@@ -674,8 +761,9 @@ int launchTrainedUnion(
         params.perWaveDwords = at;
     };
 
-    // waves per block: most resident wavefronts per CU, larger blocks on ties (as chooseGeometry)
-    auto chooseWaves = [&](uint32_t* waves, uint32_t* ldsBytes) {
+    // waves per block: most resident wavefronts per CU -- by LDS and by the kernel's registers --, blocks of
+    // four on ties (as chooseGeometry)
+    auto chooseWaves = [&](uint32_t registerWaves, uint32_t* waves, uint32_t* ldsBytes) {
         double bestResident = -1;
         *waves = 0;
         for (uint32_t candidate : {4u, 8u, 2u, 1u}) {
@@ -686,7 +774,8 @@ int launchTrainedUnion(
             if (bytes > first->ldsLimit) {
                 continue;
             }
-            const uint32_t blocksPerCu = std::min<uint32_t>(first->ldsLimit / ((bytes + 1023) / 1024 * 1024), 32 / candidate);
+            const uint32_t blocksPerCu = std::min<uint32_t>(
+                first->ldsLimit / ((bytes + 1023) / 1024 * 1024), std::max<uint32_t>(1, std::min<uint32_t>(32, registerWaves) / candidate));
             if (double(blocksPerCu) * candidate > bestResident) {
                 bestResident = double(blocksPerCu) * candidate;
                 *waves = candidate;
@@ -696,40 +785,48 @@ int launchTrainedUnion(
     };
     uint32_t waves = 0;
     uint32_t ldsBytes = 0;
-    if (persistent) {
-        layOut(true);
-        chooseWaves(&waves, &ldsBytes);
-        // fewer than two tiles per resident wavefront: the pipeline has nothing to overlap
-        if (!waves || tiles < 2ull * first->cuCount * 16) {
-            persistent = false;
-        }
+    UnionKernel kernel = nullptr;
+    uint32_t registerWaves = 32;
+    int numRegs = 0;
+    // fewer than two tiles per resident wavefront: the pipeline has nothing to overlap
+    if (persistent && tiles < 2ull * first->cuCount * 16) {
+        persistent = false;
     }
-    if (!persistent) {
-        layOut(false);
-        chooseWaves(&waves, &ldsBytes);
+    for (int attempt = 0; attempt < 2 && !waves; ++attempt) {
+        layOut(persistent);
+        kernel = unionKernel(hasSub, first->fast, average, count, persistent ? (dma ? 2u : 1u) : 0u);
+        hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
+        if (status != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
+        }
+        chooseWaves(registerWaves, &waves, &ldsBytes);
+        if (!waves && persistent) {
+            persistent = false;   // the one-tile kernel's layout may still fit
+        } else {
+            break;
+        }
     }
     if (!waves) {
         return MEMB_HIP_UNSUPPORTED;
     }
-    UnionLaunch launch{};
-    launch.blocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
-    launch.threads = waves * WAVE;
-    launch.ldsBytes = ldsBytes;
-    launch.persistent = persistent;
-    launch.ntLoads = first->switches.ntLoads;
-    launch.blocksPerCuCap = first->switches.blocksPerCu;
-    launch.cuCount = first->cuCount;
-    launch.evenRounds = first->switches.gridPolicy == 1;
+    const uint32_t threads = waves * WAVE;
+    const uint32_t tileBlocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
     hipError_t status;
-    if (first->fast) {
-        status = average ? launchUnionVariant<false, true, true>(params, count, launch, stream)
-                         : launchUnionVariant<false, true, false>(params, count, launch, stream);
-    } else if (hasSub) {
-        status = average ? launchUnionVariant<true, false, true>(params, count, launch, stream)
-                         : launchUnionVariant<true, false, false>(params, count, launch, stream);
+    if (persistent) {
+        status = launchPersistentGeneric(
+            first, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
+            }, tileBlocks, threads, ldsBytes);
     } else {
-        status = average ? launchUnionVariant<false, false, true>(params, count, launch, stream)
-                         : launchUnionVariant<false, false, false>(params, count, launch, stream);
+        {
+            std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
+            KernelFacts* facts = nullptr;
+            status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
+        }
+        if (status == hipSuccess) {
+            hipLaunchKernelGGL(kernel, dim3(tileBlocks), dim3(threads), ldsBytes, stream, params);
+            status = hipGetLastError();
+        }
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
@@ -1009,6 +1106,7 @@ Switches readSwitches()
     switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
     switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
     switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
+    switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 2);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1670,6 +1768,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "blocks_per_cu" && value <= 32) {
         ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
+    } else if (key == "pipeline" && value <= 2) {
+        ctx->switches.pipeline = static_cast<uint32_t>(value);
     } else if (key == "grid_policy" && value <= 1) {
         ctx->switches.gridPolicy = static_cast<uint32_t>(value);
     } else if (key == "persistent" && value <= 1) {
@@ -1700,22 +1800,33 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         info->max_code_bits = table.maxCodeBits;
         info->table_entries = static_cast<uint32_t>(table.entries.size());
         info->max_stream_bytes = ctx->maxStreamBytes;
-        TrainedGeometry geometry = chooseGeometry(ctx, WAVE / ctx->lanesPerWord, ctx->dim, 0, nullptr);
+        // the plan of a dense device-resident batch
+        TrainedPlan plan;
+        {
+            DeviceScope deviceScope(ctx->device);
+            HIP_TRY(deviceScope.status());
+            const int planned = planTrained(ctx, ctx->dim, 0, nullptr, false, &plan);
+            if (planned != MEMB_HIP_OK) {
+                return planned;
+            }
+        }
+        const TrainedGeometry geometry = plan.geometry;
         info->waves_per_block = geometry.waves;
+        info->kernel_registers = static_cast<uint32_t>(plan.numRegs);
+        info->register_waves_per_cu = plan.persistent ? plan.registerWavesPerCu : 0;
         info->lanes_per_word = ctx->lanesPerWord;
         info->segment_symbols = ctx->segmentSymbols;
         info->lds_bytes_per_block = geometry.ldsBytes;
         info->row_layout = ctx->recordPieces ? 2u : (ctx->rowMeta ? 1u : 0u);
         info->row_bytes = ctx->recordPieces * 16;
-        // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys>
-        const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-        const uint32_t loadPieces = ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4;
-        const uint32_t streamRounds = (wordsPerWave * loadPieces + WAVE - 1) / WAVE;
-        const bool persistent = streamRounds <= STREAM_REGISTERS && ctx->switches.persistent;
+        // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys, ...>
+        const char* name = !plan.persistent ? "decode_trained" : plan.pipeline ? "decode_records_persistent" : "decode_trained_persistent";
+        const char* last = !plan.persistent ? "" : plan.pipeline ? (plan.pipeline == 2 ? ", true" : ", false")
+                                                                 : (ctx->switches.ntLoads ? ", true" : ", false");
         std::snprintf(
-            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s%s>", persistent ? "decode_trained_persistent" : "decode_trained",
+            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s%s>", name,
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
-            ctx->fast ? "true" : "false", !persistent ? "" : (ctx->switches.ntLoads ? ", true" : ", false"));
+            ctx->fast ? "true" : "false", last);
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
         std::snprintf(

@@ -858,3 +858,72 @@ def test_concurrent_callers(native, make_model):
     for thread in threads:
         thread.join()
     assert not failures
+
+
+@pytest.mark.parametrize('bits,distribution', [(4, 'normal'), (2, 'normal'), (6, 'student'), (8, 'student')])
+def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distribution):
+    """decode_records_persistent (option 'pipeline': 1 = stream registers, 2 = LDS-DMA) against the general
+    persistent kernel and the checker: dense rows, strided rows, unaligned output (scalar stores), host
+    batches (centroid indices over PCIe) and ragged / tiny batches, with missing rows in every one."""
+    import torch
+    path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
+    checker = oracle.OracleReader(path)
+    reader = native.Reader(path, device=0)
+    assert reader.info()['row_layout'] == 2   # row records: the layout these kernels are for
+    rng = np.random.default_rng(bits)
+    for count in (20000, 4097, 9, 1):
+        rows = rng.integers(0, len(words), size=count).astype(np.uint32)
+        rows[rng.integers(0, count, size=max(1, count // 50))] = 0xFFFFFFFF
+        if count == 20000:
+            rows[:12000] = np.arange(12000, dtype=np.uint32)   # a key-order run as well
+        expected = checker.rows_embedding(rows)
+        ids = torch.from_numpy(rows.view(np.int32)).cuda()
+        for pipeline in (0, 1, 2):
+            reader.set_option('pipeline', pipeline)
+            name = reader.info()['kernel']
+            assert name.startswith('decode_records_persistent' if pipeline else 'decode_trained_persistent'), name
+            dense = reader.rows_embedding_device(ids)
+            assert bits_equal(dense.cpu().numpy(), expected), (pipeline, count)
+            wide = torch.full((count, 640), 7.0, dtype=torch.float32, device='cuda')
+            reader.rows_embedding_device(ids, out=wide, col_off=320)
+            assert bits_equal(wide[:, 320:620].cpu().numpy(), expected), (pipeline, count)
+            assert bool((wide[:, :320] == 7.0).all()) and bool((wide[:, 620:] == 7.0).all())
+            odd = torch.zeros((count, 301), dtype=torch.float32, device='cuda')   # rows not 16-byte aligned: scalar stores
+            reader.rows_embedding_device(ids, out=odd, col_off=1)
+            assert bits_equal(odd[:, 1:].cpu().numpy(), expected), (pipeline, count)
+            assert bits_equal(reader.rows_embedding(rows), expected), (pipeline, count)   # host buffers
+    reader.set_option('pipeline', 0)
+
+
+@pytest.mark.parametrize('bits_a,bits_b', [(4, 4), (6, 8), (2, 4)])
+def test_persistent_union_kernels(native, make_model, bits_a, bits_b):
+    """decode_records_union_persistent (batches of more than two tiles per resident wavefront; option 'pipeline' of the
+    first reader: 2 = LDS-DMA, else stream registers) and the one-tile kernel ('persistent' = 0) against numpy over the
+    checker's rows: concatenation and average, words missing from either model."""
+    import torch
+    from memb_amd import _memb
+    path_a, words_a = make_model(20000, 300, 'trained', bits_a, seed=1234)
+    path_b, words_b = make_model(15000, 300, 'trained', bits_b, seed=99)
+    readers = [native.Reader(path_a, device=0), native.Reader(path_b, device=0)]
+    checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+    rng = np.random.default_rng(bits_a * 10 + bits_b)
+    batch = 90001   # 11 251 tiles: more than two per resident wavefront (256 CUs x 16), the last tile ragged
+    rows = []
+    for count in (20000, 15000):
+        picks = rng.integers(0, count, size=batch).astype(np.uint32)
+        picks[rng.random(batch) < 0.2] = 0xFFFFFFFF
+        rows.append(picks)
+    expected = [checker.rows_embedding(picks) for checker, picks in zip(checkers, rows)]
+    ids = [torch.from_numpy(picks.view(np.int32)).cuda() for picks in rows]
+    stream = torch.cuda.current_stream().cuda_stream
+    for persistent, pipeline in ((1, 0), (1, 2), (0, 0)):
+        readers[0].set_option('persistent', persistent)
+        readers[0].set_option('pipeline', pipeline)
+        merged = torch.full((batch, 600), 3.0, dtype=torch.float32, device='cuda')
+        assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 300], batch,
+                                          merged.data_ptr(), 600, stream, False)
+        assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline)
+        mean = torch.full((batch, 300), 3.0, dtype=torch.float32, device='cuda')
+        assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 0], batch,
+                                          mean.data_ptr(), 300, stream, True)
+        assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (persistent, pipeline)

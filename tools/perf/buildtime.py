@@ -6,7 +6,9 @@ from memb_amd import synthetic
 from memb_amd.builder import Builder
 n = int(os.environ.get('BT_WORDS', '2196017')); bits = int(os.environ.get('BT_BITS', '4'))
 t = time.time(); words = synthetic.make_words(n); print('make_words %.2fs' % (time.time() - t), flush=True)
-builder = Builder(300, 'trained', bits)
+device = os.environ.get('BT_DEVICE')
+builder = Builder(300, 'trained', bits, device=None if device in (None, '') else int(device))
+print('writer:', 'host' if device in (None, '') else 'device ' + device, flush=True)
 rng = np.random.default_rng(1234)
 t_rng = t_add = 0.0
 for start in range(0, n, 200000):

@@ -798,11 +798,12 @@ __device__ __forceinline__ void issueRecordDma(
 #pragma unroll
     for (int round = 0; round < RECORD_ROUNDS; ++round) {
         const uint32_t q = round * WAVE + lane;
+        // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
+        const uint32_t w = fastDivide(min(q, totalPieces - 1), p.dmaMagic, slotPieces);
+        const uint32_t wordStart = __shfl(start, w * p.lanesPerWord);
         if (q < totalPieces) {
-            const uint32_t w = fastDivide(q, p.dmaMagic, slotPieces);
             uint32_t piece = q - w * slotPieces;
             piece = piece < p.recordPieces ? piece : 0u;
-            const uint32_t wordStart = __shfl(start, w * p.lanesPerWord);
             const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
             // (C-style casts: generic -> global / LDS address spaces)
             __builtin_amdgcn_global_load_lds(

@@ -162,8 +162,8 @@ struct memb_hip_ctx {
     uint32_t cuCount = 0;
 
     // uniform / full
-    uint8_t* uniformValues = nullptr;
-    float2* minMax = nullptr;
+    uint4* uniformRecords = nullptr;     // row records: {min, max, 0, 0} + the weights, regionPieces 16-byte pieces per row
+    uint32_t regionPieces = 0;
     float levels = 0.f;
     float* fullValues = nullptr;
 
@@ -902,14 +902,38 @@ int launchUniform(
     params.n = n;
     params.ld = ld;
     params.colOff = colOff;
-    params.values = ctx->uniformValues;
-    params.minMax = ctx->minMax;
+    params.records = ctx->uniformRecords;
+    params.regionPieces = ctx->regionPieces;
     params.nRows = ctx->nRows;
     params.dim = ctx->dim;
     params.wordsPerBlock = rowwiseWordsPerBlock(ctx->dim);
     params.levels = ctx->levels;
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    // The persistent LDS-DMA pipeline: 16-byte output pieces, a tile's regions within UNIFORM_ROUNDS rounds, and
+    // more than one tile per resident wavefront (smaller batches: the block-per-13-words kernel below spreads wider).
+    const uint32_t wordsPerWave = std::min<uint32_t>(WAVE, UNIFORM_ROUNDS * WAVE / std::max<uint32_t>(ctx->regionPieces, 1));
+    if (vec && wordsPerWave >= 1 && ctx->switches.persistent && n >= size_t(wordsPerWave) * ctx->cuCount * 16 &&
+        uint64_t(ctx->nRows + 1) * ctx->regionPieces < (1ull << 32)) {
+        params.wordsPerWave = wordsPerWave;
+        params.regionMagic = magicFor(ctx->regionPieces, uint64_t(UNIFORM_ROUNDS) * WAVE);
+        params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
+        const uint32_t waves = 4;
+        const uint32_t threads = waves * WAVE;
+        const uint32_t ldsBytes = waves * 2 * wordsPerWave * ctx->regionPieces * 16;
+        const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
+        const uint32_t tileBlocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+        const bool flat = ld == ctx->dim && colOff == 0;
+        void (*kernel)(UniformParams) = flat ? &dequant_uniform_persistent<true> : &dequant_uniform_persistent<false>;
+        hipError_t launched = launchPersistentGeneric(
+            ctx, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
+            }, tileBlocks, threads, ldsBytes);
+        if (launched != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("dequant_uniform_persistent launch: ") + hipGetErrorString(launched));
+        }
+        return MEMB_HIP_OK;
+    }
     const uint32_t blocks = static_cast<uint32_t>((n + params.wordsPerBlock - 1) / params.wordsPerBlock);
     if (vec) {
         params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(params.wordsPerBlock) * (ctx->dim / 4));
@@ -1658,32 +1682,29 @@ int ctx_create_uniform_checked(memb_hip_ctx** out, int device, const memb_hip_un
     ctx->nRows = desc->n_rows;
     ctx->levels = static_cast<float>(desc->quantization_levels);
 
-    // HBM layout: dense [n_rows][dim] bytes plus one {min, max} pair per row.
-    // The file scatters each row in its own table; rows shorter than dim are
-    // zero padded (the reference writes only values->size() outputs there).
-    std::vector<uint8_t> values(size_t(desc->n_rows) * desc->dim, 0);
-    std::vector<float2> minMax(desc->n_rows);
+    // HBM layout: ROW RECORDS (UniformParams::records) -- every row owns 16 bytes of {min, max} and its
+    // weights, one byte each, zero padded to whole 16-byte pieces. The file scatters each row in its own
+    // table; rows shorter than dim are zero padded (the reference writes only values->size() outputs there).
+    ctx->regionPieces = 1 + (desc->dim + 15) / 16;
+    const size_t regionBytes = size_t(ctx->regionPieces) * 16;
+    std::vector<uint8_t> records((size_t(desc->n_rows) + 1) * regionBytes, 0);   // + one region of guard
     for (uint64_t r = 0; r < desc->n_rows; ++r) {
         const memb_hip_uniform_row& row = desc->rows[r];
+        uint8_t* region = records.data() + r * regionBytes;
+        const float header[2] = {row.min_value, row.max_value};
+        std::memcpy(region, header, sizeof(header));
         size_t count = std::min<size_t>(row.n_values, desc->dim);
         if (count) {
-            std::memcpy(values.data() + r * desc->dim, row.values, count);
+            std::memcpy(region + 16, row.values, count);
         }
-        minMax[r] = make_float2(row.min_value, row.max_value);
     }
 
     int code = openDevice(ctx, device);
     if (code == MEMB_HIP_OK) {
-        code = deviceAlloc(ctx, &ctx->uniformValues, values.size() + 16);
+        code = deviceAlloc(ctx, &ctx->uniformRecords, records.size());
     }
     if (code == MEMB_HIP_OK) {
-        code = copyToDevice(ctx->uniformValues, values.data(), values.size());
-    }
-    if (code == MEMB_HIP_OK) {
-        code = deviceAlloc(ctx, &ctx->minMax, minMax.size() * sizeof(float2));
-    }
-    if (code == MEMB_HIP_OK) {
-        code = copyToDevice(ctx->minMax, minMax.data(), minMax.size() * sizeof(float2));
+        code = copyToDevice(ctx->uniformRecords, records.data(), records.size());
     }
     if (code != MEMB_HIP_OK) {
         return code;
@@ -1829,9 +1850,11 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
             ctx->fast ? "true" : "false", last);
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
+        const bool pipelined = ctx->storage == memb::wire::Storage_Uniform && ctx->dim % 4 == 0 && ctx->switches.persistent &&
+            ctx->regionPieces <= UNIFORM_ROUNDS * WAVE;
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<true>",
-            ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");
+            pipelined ? "dequant_uniform_persistent" : ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");
     }
     return MEMB_HIP_OK;
 }

@@ -505,6 +505,7 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
             _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64), ('rows', ctypes.c_void_p),
                         ('quantization_levels', ctypes.c_uint8)]
 
+        values = values + [values[-1]] * (-len(values) % 4)   # whole 16-byte output pieces: the vector kernels
         payload = np.array(values, dtype=np.uint8)
         rows = (Row * len(pairs))()
         for i, (low, high) in enumerate(pairs):
@@ -518,6 +519,17 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
             context, ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(pairs)),
             out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(values)), ctypes.c_size_t(0))
         assert code == 0, library.memb_hip_last_error()
+        # the same rows many times over: a batch large enough for dequant_uniform_persistent (LDS-DMA pipeline)
+        many = np.tile(ids, 70000 // len(ids) + 1)
+        many[5::1001] = 0xFFFFFFFF
+        out_many = np.empty((len(many), len(values)), dtype=np.float32)
+        code = library.memb_hip_decode_rows(
+            context, many.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(many)),
+            out_many.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(values)), ctypes.c_size_t(0))
+        assert code == 0, library.memb_hip_last_error()
+        present = many != 0xFFFFFFFF
+        assert nan_aware_equal(out_many[present], out[many[present]]), levels
+        assert not out_many[~present].view(np.uint32).any()
         library.memb_hip_ctx_destroy(context)
         expected = {(c[0], c[1], c[2]): c[4] for c in subset}
         for i, (low, high) in enumerate(pairs):
@@ -927,3 +939,33 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b):
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 0], batch,
                                           mean.data_ptr(), 300, stream, True)
         assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (persistent, pipeline)
+
+
+def test_uniform_persistent_pipeline(native, make_model):
+    """dequant_uniform_persistent (row records fetched by LDS-DMA; batches of more than one tile per resident
+    wavefront) against the checker: dense, strided, accumulate / divide epilogue, unaligned output (which takes the
+    block kernel), missing rows, a ragged last tile; bit-exact as every uniform result."""
+    import torch
+    path, words = make_model(3000, 300, 'uniform', 8)
+    reader = native.Reader(path, device=0)
+    checker = oracle.OracleReader(path)
+    assert reader.info()['kernel'].startswith('dequant_uniform')
+    rng = np.random.default_rng(8)
+    for count in (60001, 36863):
+        rows = rng.integers(0, len(words), size=count).astype(np.uint32)
+        rows[rng.random(count) < 0.03] = 0xFFFFFFFF
+        rows[:3000] = np.arange(3000, dtype=np.uint32)
+        expected = checker.rows_embedding(rows)
+        ids = torch.from_numpy(rows.view(np.int32)).cuda()
+        assert bits_equal(reader.rows_embedding_device(ids).cpu().numpy(), expected)
+        wide = torch.full((count, 640), 7.0, dtype=torch.float32, device='cuda')
+        reader.rows_embedding_device(ids, out=wide, col_off=320)
+        assert bits_equal(wide[:, 320:620].cpu().numpy(), expected)
+        assert bool((wide[:, :320] == 7.0).all()) and bool((wide[:, 620:] == 7.0).all())
+        odd = torch.zeros((count, 301), dtype=torch.float32, device='cuda')
+        reader.rows_embedding_device(ids, out=odd, col_off=1)
+        assert bits_equal(odd[:, 1:].cpu().numpy(), expected)
+        accumulated = torch.full((count, 300), 0.5, dtype=torch.float32, device='cuda')
+        reader.rows_embedding_device(ids, out=accumulated, accumulate=True, divisor=2.0)
+        assert bits_equal(accumulated.cpu().numpy(), (np.float32(0.5) + expected) / np.float32(2.0))
+        assert bits_equal(reader.rows_embedding(rows), expected)   # host buffers

@@ -893,7 +893,9 @@ def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distri
         for pipeline in (0, 1, 2):
             reader.set_option('pipeline', pipeline)
             name = reader.info()['kernel']
-            assert name.startswith('decode_records_persistent' if pipeline else 'decode_trained_persistent'), name
+            # (rows too long for two 64-lane rounds per tile -- the 8-bit model -- stay on the general kernel)
+            if pipeline == 0 or bits <= 4:
+                assert name.startswith('decode_records_persistent' if pipeline else 'decode_trained_persistent'), name
             dense = reader.rows_embedding_device(ids)
             assert bits_equal(dense.cpu().numpy(), expected), (pipeline, count)
             wide = torch.full((count, 640), 7.0, dtype=torch.float32, device='cuda')

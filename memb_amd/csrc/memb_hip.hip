@@ -677,8 +677,9 @@ int launchTrainedUnion(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* colOffs, size_t count, size_t n, float* out,
     size_t ld, hipStream_t stream, bool average)
 {
+    // (MEMB_HIP_UNSUPPORTED is not an error, but memb_hip_last_error() says which condition it was)
     if (count < 2 || count > UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
-        return MEMB_HIP_UNSUPPORTED;
+        return fail(MEMB_HIP_UNSUPPORTED, "union kernel: two to four models (or switched off by MEMB_HIP_UNION_FUSED=0)");
     }
     const memb_hip_ctx* first = ctxs[0];
     bool hasSub = false;
@@ -688,12 +689,12 @@ int launchTrainedUnion(
             ctx->fast != first->fast || ctx->lanesPerWord != first->lanesPerWord ||
             ctx->segmentSymbols != first->segmentSymbols || ctx->dim % 4 != 0 || colOffs[m] % 4 != 0 ||
             ld < colOffs[m] + ctx->dim) {
-            return MEMB_HIP_UNSUPPORTED;
+            return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the models differ in storage, device, dim, key format or lane geometry");
         }
         hasSub = hasSub || ctx->hostTable.hasSubTables;
     }
     if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 || n > (size_t(1) << 37)) {
-        return MEMB_HIP_UNSUPPORTED;
+        return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the output is not 16-byte aligned in every row");
     }
     const uint32_t wordsPerWave = WAVE / first->lanesPerWord;
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
@@ -807,7 +808,7 @@ int launchTrainedUnion(
         }
     }
     if (!waves) {
-        return MEMB_HIP_UNSUPPORTED;
+        return fail(MEMB_HIP_UNSUPPORTED, "union kernel: tables and bitstream slots of the models do not fit into LDS together");
     }
     const uint32_t threads = waves * WAVE;
     const uint32_t tileBlocks = static_cast<uint32_t>((tiles + waves - 1) / waves);

@@ -917,9 +917,12 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b):
     import torch
     from memb_amd import _memb
     path_a, words_a = make_model(20000, 300, 'trained', bits_a, seed=1234)
-    path_b, words_b = make_model(15000, 300, 'trained', bits_b, seed=99)
+    path_b, words_b = make_model(15000, 300, 'trained', bits_b, seed=1234)
     readers = [native.Reader(path_a, device=0), native.Reader(path_b, device=0)]
     checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+    # (one key format for both: nibble keys need <= 16 centroids and codes of <= 8 bits -- a 4-bit model with a rare
+    # centroid has longer ones and then shares no kernel with a nibble-key model)
+    assert len({reader.info()['kernel'].split('<')[1].split(',')[2] for reader in readers}) == 1
     rng = np.random.default_rng(bits_a * 10 + bits_b)
     batch = 90001   # 11 251 tiles: more than two per resident wavefront (256 CUs x 16), the last tile ragged
     rows = []

@@ -619,6 +619,10 @@ int launchTrained(
     if (persistent) {
         status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
     } else {
+        // (blocks_per_cu also caps the residency of the one-tile kernel: LDS it does not use keeps further blocks off a CU)
+        if (ctx->switches.blocksPerCu) {
+            geometry.ldsBytes = std::max<uint32_t>(geometry.ldsBytes, ctx->ldsLimit / ctx->switches.blocksPerCu / 1024 * 1024);
+        }
         switch (geometry.mode) {
             case OUT_FLAT:
                 status = launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);

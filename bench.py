@@ -339,10 +339,10 @@ def host_api_timings(reader, path, rows_host):
     }
 
 
-def open_reader(memb_amd, path, device):
+def open_reader(memb_amd, path, device, batch_words=0):
     start = time.time()
     reader = memb_amd.Reader(path, device=device)
-    info = reader.info()   # stages the model to HBM
+    info = reader.info(batch_words)   # stages the model to HBM; the kernel named is the one a batch of that size runs
     return reader, info, time.time() - start
 
 
@@ -360,7 +360,7 @@ def measure_config(name, what, reader, path, rows_host, timer, library, torch, n
         lambda: reader.rows_embedding_device(rows, out=out), max(launches, 50))
     nbytes = algorithmic_bytes(library, reader, rows_host)
     parity = sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy())
-    info = reader.info()
+    info = reader.info(len(rows_host))
     result = {
         'workload': name,
         'what': what,
@@ -723,7 +723,7 @@ def main():
             dist.barrier()
         path, _ = synthetic.cached_model(words, 300, 'trained', bits)
 
-        reader, info, open_seconds = open_reader(memb_amd, path, local_rank)
+        reader, info, open_seconds = open_reader(memb_amd, path, local_rank, batch or 0)
         dim = reader.dim
         count = len(reader)
 

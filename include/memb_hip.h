@@ -137,6 +137,8 @@ typedef struct memb_hip_ctx_info {
     uint32_t row_bytes;          /* trained, row records: bytes every row owns */
     uint32_t kernel_registers;   /* trained, persistent kernel: vector registers per lane as the runtime reports them */
     uint32_t register_waves_per_cu;   /* ... and the wavefronts per CU those registers allow (32 = no limit from registers) */
+    uint64_t batch_words;        /* IN: the batch size `kernel` and the geometry fields are reported for (the kernel is chosen
+                                    by batch size); 0 = a large batch */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);
@@ -159,10 +161,10 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "waves_per_block" 0 = choose, or 1, 2, 4, 8
  *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
  *   "pipeline"        persistent kernel of row-record models: 0 = the general one, 1 = decode_records_persistent with
- *                     stream registers, 2 = the same fed by LDS-DMA (global_load_lds)
+ *                     stream registers, 2 = the same fed by LDS-DMA (global_load_lds), 3 = by batch size (default)
  *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
  *                     that make the same number of rounds (equal tiles per wavefront)
- *   "persistent"      0 / 1   one tile per wavefront instead of the persistent pipeline
+ *   "persistent"      0 = one tile per wavefront always, 1 = by batch size (default), 2 = the persistent pipeline always
  *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)
  * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug",
  * the measurement switches of hip_trained_kernels.h; the shipped library refuses it.

@@ -80,7 +80,7 @@ struct WordPointers {
     const char* const* data() const { return pointers.data(); }
 };
 
-py::dict contextInfo(memb::Reader& reader)
+py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
 {
     if (reader.device() == memb::CompressedStorage::HOST_DEVICE) {
         py::dict result;
@@ -92,6 +92,7 @@ py::dict contextInfo(memb::Reader& reader)
     }
     memb_hip_ctx_info info{};
     info.struct_size = sizeof(info);
+    info.batch_words = batchWords;
     if (memb_hip_ctx_get_info(reader.deviceContext(), &info) != MEMB_HIP_OK) {
         throw std::runtime_error(memb_hip_last_error());
     }
@@ -238,7 +239,7 @@ PYBIND11_MODULE(_memb, m) {
         .def("host_below", [](memb::Reader& reader) { return reader.hostBelow(); })
         .def("host_rows_decoded", [](memb::Reader& reader) { return reader.hostRowsDecoded(); })
         .def("storage_name", [](memb::Reader& reader) { return reader.storageName(); })
-        .def("info", &contextInfo)
+        .def("info", &contextInfo, py::arg("batch_words") = 0)
         .def(
             "set_option",
             [](memb::Reader& reader, const std::string& name, uint64_t value) {

@@ -1,5 +1,8 @@
 #include "builder.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <ostream>
 #include <sstream>
@@ -59,13 +62,21 @@ void Builder::addWords(const std::vector<std::string>& words, const float* matri
         addWordLocked(words[0], matrix, rowLength);   // throws the reference's message
     }
     // the checks word by word; the rows that pass go to the compressor as one block
+    const bool verbose = std::getenv("MEMB_BUILDER_VERBOSE") && std::getenv("MEMB_BUILDER_VERBOSE")[0] == '1';
+    auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double start = clock();
     size_t accepted = 0;
     for (; accepted < words.size(); ++accepted) {
         if (!seen_.insert(words[accepted]).second) {
             break;
         }
     }
+    const double checked = clock();
     compressor_->addMany(words.data(), matrix, accepted, dim_);
+    if (verbose) {
+        std::fprintf(stderr, "memb builder: addWords %zu words: duplicate check %.3f s, compressor %.3f s\n",
+                     words.size(), checked - start, clock() - checked);
+    }
     if (accepted < words.size()) {
         throw std::runtime_error("Attempt to add duplicate word " + words[accepted] + " to index");
     }

@@ -111,11 +111,12 @@ uint32_t envUint(const char* name, uint32_t fallback)
 struct Switches {
     uint32_t waves = 0;            // MEMB_HIP_WAVES: force the wavefronts per block (0 = choose)
     uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
-    bool persistent = true;        // MEMB_HIP_PERSISTENT
+    uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 0 = one tile per wavefront always, 1 = by batch size (one tile per
+                                   // wavefront while every tile finds a free wavefront slot), 2 = the persistent pipeline always
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
-    uint32_t pipeline = 0;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
-                                   // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA
+    uint32_t pipeline = 3;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
+                                   // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA, 3 = by batch size
     uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
                                    // make the same number of rounds, so that all of them walk the same number of tiles
                                    // (measured: 0 is 0.5-1 % faster on every batch kind, 2.7 % on the union: profiles/r03_experiments.txt)
@@ -517,19 +518,32 @@ struct TrainedPlan {
 };
 
 // (the context's device is current)
-int planTrained(const memb_hip_ctx* ctx, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan)
+// Which kernel by batch size (n words), measured on one allocation per model against an A/A floor of 0.5 %
+// (profiles/r03_experiments.txt, batches 4 and 5; 2-, 4- and 6-bit models; t = tiles, R = the general persistent
+// kernel's resident wavefronts, 16 per CU):
+//   t <= R        one tile per wavefront (decode_trained: 52 VGPRs, up to 32 wavefronts per CU, nothing to pipeline):
+//                 10 000 words -17..-19 % against the persistent kernel
+//   R < t <= 4 R  decode_records_persistent (row records only; 82 VGPRs, 20 wavefronts per CU, a prologue of one hop):
+//                 100 000 words -2..-9 %, 50 000 words 0..-5 %; from 250 000 words on it is 2-4 % SLOWER
+//   above         decode_trained_persistent at 16 wavefronts per CU: every step of occupancy above that costs the
+//                 dumps 1-15 % (20 / 24 / 28 wavefronts: +3 / +4 / +13 %), every step below it more (12: up to +15 %)
+// (the context's device is current)
+int planTrained(const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
+    const uint64_t generalResident = uint64_t(ctx->cuCount) * 16;
     // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
     // (long streams with few lanes per word) take the one-shot kernel.
     const uint32_t tilePieces = wordsPerWave * (ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4);
-    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS && ctx->switches.persistent;
+    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS &&
+        (ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > generalResident));
     // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
     // both need the tile's slot image to fit two 64-lane rounds.
     plan->pipeline = 0;
     if (plan->persistent && ctx->recordPieces && ctx->switches.pipeline &&
         wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE) {
-        plan->pipeline = ctx->switches.pipeline;
+        plan->pipeline = ctx->switches.pipeline == 3 ? (tiles <= 4 * generalResident ? 1u : 0u) : ctx->switches.pipeline;
     }
     const uint32_t slotSets = plan->pipeline == 2 ? 2 : 1;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, slotSets);
@@ -558,7 +572,7 @@ int launchTrained(
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     TrainedPlan plan;
-    int planned = planTrained(ctx, ld, colOff, out, keysOut, &plan);
+    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
@@ -794,7 +808,7 @@ int launchTrainedUnion(
     uint32_t registerWaves = 32;
     int numRegs = 0;
     // fewer than two tiles per resident wavefront: the pipeline has nothing to overlap
-    if (persistent && tiles < 2ull * first->cuCount * 16) {
+    if (persistent && first->switches.persistent != 2 && tiles < 2ull * first->cuCount * 16) {
         persistent = false;
     }
     for (int attempt = 0; attempt < 2 && !waves; ++attempt) {
@@ -1131,11 +1145,11 @@ Switches readSwitches()
 #ifdef MEMB_HIP_MEASURE
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
 #endif
-    switches.persistent = envUint("MEMB_HIP_PERSISTENT", 1) != 0;
+    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
     switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
     switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
     switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
-    switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 2);
+    switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 3);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1758,7 +1772,7 @@ int ctx_create_full_checked(memb_hip_ctx** out, int device, const memb_hip_full_
 }
 
 
-int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
+int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWords);
 
 int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
 {
@@ -1771,7 +1785,12 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         return fail(MEMB_HIP_ERR_INVALID, "memb_hip_ctx_info.struct_size must be set to sizeof(memb_hip_ctx_info)");
     }
     memb_hip_ctx_info filled;
-    const int code = fillInfo(ctx, &filled);
+    uint64_t batchWords = 0;
+    if (callerSize >= offsetof(memb_hip_ctx_info, batch_words) + sizeof(uint64_t)) {
+        batchWords = info->batch_words;
+    }
+    const int code = fillInfo(ctx, &filled, batchWords);
+    filled.batch_words = batchWords;
     if (code != MEMB_HIP_OK) {
         return code;
     }
@@ -1794,12 +1813,12 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "blocks_per_cu" && value <= 32) {
         ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
-    } else if (key == "pipeline" && value <= 2) {
+    } else if (key == "pipeline" && value <= 3) {
         ctx->switches.pipeline = static_cast<uint32_t>(value);
     } else if (key == "grid_policy" && value <= 1) {
         ctx->switches.gridPolicy = static_cast<uint32_t>(value);
-    } else if (key == "persistent" && value <= 1) {
-        ctx->switches.persistent = value != 0;
+    } else if (key == "persistent" && value <= 2) {
+        ctx->switches.persistent = static_cast<uint32_t>(value);
     } else if (key == "host_expand" && value <= 1) {
         ctx->switches.hostExpand = value != 0;
 #ifdef MEMB_HIP_MEASURE
@@ -1812,7 +1831,7 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
     return MEMB_HIP_OK;
 }
 
-int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
+int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWords)
 {
     std::memset(info, 0, sizeof(*info));
     info->device = ctx->device;
@@ -1831,7 +1850,7 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
         {
             DeviceScope deviceScope(ctx->device);
             HIP_TRY(deviceScope.status());
-            const int planned = planTrained(ctx, ctx->dim, 0, nullptr, false, &plan);
+            const int planned = planTrained(ctx, batchWords ? size_t(batchWords) : size_t(1) << 30, ctx->dim, 0, nullptr, false, &plan);
             if (planned != MEMB_HIP_OK) {
                 return planned;
             }
@@ -1855,8 +1874,9 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
             ctx->fast ? "true" : "false", last);
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
+        const uint32_t uniformWordsPerWave = std::min<uint32_t>(WAVE, UNIFORM_ROUNDS * WAVE / std::max<uint32_t>(ctx->regionPieces, 1));
         const bool pipelined = ctx->storage == memb::wire::Storage_Uniform && ctx->dim % 4 == 0 && ctx->switches.persistent &&
-            ctx->regionPieces <= UNIFORM_ROUNDS * WAVE;
+            uniformWordsPerWave >= 1 && (!batchWords || batchWords >= uint64_t(uniformWordsPerWave) * ctx->cuCount * 16);
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<true>",
             pipelined ? "dequant_uniform_persistent" : ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");

@@ -190,9 +190,10 @@ class Reader(BaseReader):
         embedding matrix of a model never crosses PCIe'''
         return self.batch_embedding_device(tokenizer_word_list(tokenizer))
 
-    def info(self):
-        '''Facts about the device context (stages the model on first call)'''
-        return self._impl.info()
+    def info(self, batch_words=0):
+        '''Facts about the device context (stages the model on first call). The kernel and its launch geometry
+        are chosen by batch size: batch_words names the size they are reported for (0 = a large batch).'''
+        return self._impl.info(int(batch_words))
 
     def set_option(self, name, value):
         '''Tuning knob of the device context ('nt_loads', 'waves_per_block', 'blocks_per_cu', 'persistent',

@@ -741,7 +741,7 @@ def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
                                          (8, 8, 1), (16, 2, 1), (25, 1, 0), (64, 1, 1)):
             monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
             monkeypatch.setenv('MEMB_HIP_WAVES', str(waves))
-            monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(persistent))
+            monkeypatch.setenv('MEMB_HIP_PERSISTENT', '2' if persistent else '0')   # 2 = persistent whatever the batch size
             reader = native.Reader(path)
             assert bits_equal(reader.rows_embedding(rows), expected), (bits, lanes, waves, persistent)
             wide = np.zeros((len(rows), 304), dtype=np.float32)
@@ -772,7 +772,7 @@ def test_row_layouts_give_identical_rows(native, make_model, monkeypatch):
                 monkeypatch.delenv(key, raising=False)
             for key, value in env.items():
                 monkeypatch.setenv(key, value)
-            for persistent in ('1', '0'):
+            for persistent in ('2', '1', '0'):   # always persistent / by batch size / one tile per wavefront
                 monkeypatch.setenv('MEMB_HIP_PERSISTENT', persistent)
                 reader = native.Reader(path)
                 assert bits_equal(reader.rows_embedding(rows), expected), (bits, name, persistent)
@@ -819,7 +819,7 @@ def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
         builder.save(path)
 
         monkeypatch.setenv('MEMB_HIP_LANES', str(int(rng.choice([1, 2, 3, 4, 8, 8, 16, 32]))))
-        monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(int(rng.random() < 0.7)))
+        monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(int(rng.integers(0, 3))))
         monkeypatch.setenv('MEMB_HIP_ROOT_BITS', str(int(rng.choice([1, 2, 4, 8, 11, 12]))))
         reader = native.Reader(path)
         checker = oracle.OracleReader(str(path))
@@ -882,6 +882,7 @@ def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distri
     checker = oracle.OracleReader(path)
     reader = native.Reader(path, device=0)
     assert reader.info()['row_layout'] == 2   # row records: the layout these kernels are for
+    reader.set_option('persistent', 2)        # the persistent kernels whatever the batch size (default: by size)
     rng = np.random.default_rng(bits)
     for count in (20000, 4097, 9, 1):
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)
@@ -933,7 +934,7 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b):
     expected = [checker.rows_embedding(picks) for checker, picks in zip(checkers, rows)]
     ids = [torch.from_numpy(picks.view(np.int32)).cuda() for picks in rows]
     stream = torch.cuda.current_stream().cuda_stream
-    for persistent, pipeline in ((1, 0), (1, 2), (0, 0)):
+    for persistent, pipeline in ((1, 3), (2, 1), (2, 2), (0, 0)):
         readers[0].set_option('persistent', persistent)
         readers[0].set_option('pipeline', pipeline)
         merged = torch.full((batch, 600), 3.0, dtype=torch.float32, device='cuda')

@@ -688,6 +688,24 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     if (syncOutput ? blockTile >= tiles : tile >= tiles) {
         return;
     }
+#ifdef MEMB_HIP_MEASURE
+    // Measurement (bits 14..17): a staggered start. Every wavefront begins at the same moment and walks its
+    // tiles in rounds of about the same length, so decode and store phases of the whole chip may stay in step;
+    // bits 14..15: delay unit (1, 2, 4, 8 x ~0.4 us), bit 16: by wavefront of the block, bit 17: by block.
+    if (measureFlags(p) & 0x30000) {
+        const uint32_t unit = 1u << ((measureFlags(p) >> 14) & 3);
+        uint32_t steps = 0;
+        if (measureFlags(p) & 0x10000) {
+            steps += threadIdx.x / WAVE;
+        }
+        if (measureFlags(p) & 0x20000) {
+            steps += blockIdx.x % 4 * (blockDim.x / WAVE);
+        }
+        for (uint32_t i = 0; i < steps * unit; ++i) {
+            __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles = ~0.43 us at 2.4 GHz
+        }
+    }
+#endif
 
     // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
     WordMeta meta0 = loadWordMeta<NT>(p, row0, role);

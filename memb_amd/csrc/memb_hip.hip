@@ -117,6 +117,7 @@ struct Switches {
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
     uint32_t pipeline = 3;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
                                    // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA, 3 = by batch size
+    bool autotune = true;          // MEMB_HIP_AUTOTUNE: the first large batch times both kernels for large batches (launchTrained)
     uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
                                    // make the same number of rounds, so that all of them walk the same number of tiles
                                    // (measured: 0 is 0.5-1 % faster on every batch kind, 2.7 % on the union: profiles/r03_experiments.txt)
@@ -156,6 +157,8 @@ struct memb_hip_ctx {
     bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
+    std::atomic<int> bigBatchKernel{-1};   // batches of more than 4 tiles per resident wavefront: -1 = not timed yet,
+                                         // 0 = the persistent pipeline, 1 = one tile per wavefront (launchTrained)
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
@@ -528,7 +531,13 @@ struct TrainedPlan {
 //   above         decode_trained_persistent at 16 wavefronts per CU: every step of occupancy above that costs the
 //                 dumps 1-15 % (20 / 24 / 28 wavefronts: +3 / +4 / +13 %), every step below it more (12: up to +15 %)
 // (the context's device is current)
-int planTrained(const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan)
+//   The "above" class is settled per context by timing: on 2- and 6-bit models the one-tile kernel beats the
+//   persistent one by 2-14 % on every box and in every row order, on the 4-bit model it loses the key-order dump by
+//   3-6 % on three boxes of four and wins shuffled rows by 2-4 % (batches 3, 5, 6, 7) -- so the first large batch a
+//   context sees runs both on that very batch (same bits either way) and keeps the faster: ctx->bigBatchKernel.
+// force: -1 = by the rules above, 0 = one tile per wavefront, 1 = persistent
+int planTrained(
+    const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
@@ -536,8 +545,14 @@ int planTrained(const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, con
     // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
     // (long streams with few lanes per word) take the one-shot kernel.
     const uint32_t tilePieces = wordsPerWave * (ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4);
-    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS &&
-        (ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > generalResident));
+    bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > generalResident);
+    if (ctx->switches.persistent == 1 && tiles > 4 * generalResident && ctx->bigBatchKernel.load(std::memory_order_relaxed) == 1) {
+        wantPersistent = false;
+    }
+    if (force >= 0) {
+        wantPersistent = force != 0;
+    }
+    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS && wantPersistent;
     // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
     // both need the tile's slot image to fit two 64-lane rounds.
     plan->pipeline = 0;
@@ -568,11 +583,74 @@ int planTrained(const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, con
 // keysOut: `out` receives rows of centroid indices (OUT_KEYS) instead of fp32 rows; ld = dim, colOff = 0.
 int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
-    const Epilogue& epilogue, bool keysOut = false)
+    const Epilogue& epilogue, bool keysOut = false, int force = -1);
+
+// The first large batch of a context: both kernels on that batch, three launches each (one to warm up, two between
+// a pair of events); the one-tile kernel is kept if it is at least 1.5 % faster. The batch is decoded six times
+// instead of once -- the same bits every time -- and the call waits for the device this once.
+int timeBigBatchKernels(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
+{
+    hipEvent_t begin = nullptr;
+    hipEvent_t end = nullptr;
+    HIP_TRY(hipEventCreate(&begin));
+    if (hipEventCreate(&end) != hipSuccess) {
+        (void)hipEventDestroy(begin);
+        return fail(MEMB_HIP_ERR_DEVICE, "hipEventCreate");
+    }
+    float ms[2] = {0.f, 0.f};
+    int code = MEMB_HIP_OK;
+    for (int kind = 0; kind < 2 && code == MEMB_HIP_OK; ++kind) {
+        const int force = kind == 0 ? 1 : 0;
+        code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, force);
+        hipError_t status = hipEventRecord(begin, stream);
+        for (int repeat = 0; repeat < 2 && code == MEMB_HIP_OK; ++repeat) {
+            code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, force);
+        }
+        if (status == hipSuccess) {
+            status = hipEventRecord(end, stream);
+        }
+        if (status == hipSuccess) {
+            status = hipEventSynchronize(end);
+        }
+        if (status == hipSuccess) {
+            status = hipEventElapsedTime(&ms[kind], begin, end);
+        }
+        if (status != hipSuccess && code == MEMB_HIP_OK) {
+            code = fail(MEMB_HIP_ERR_DEVICE, std::string("timing the kernels: ") + hipGetErrorString(status));
+        }
+    }
+    (void)hipEventDestroy(begin);
+    (void)hipEventDestroy(end);
+    if (code == MEMB_HIP_OK) {
+        ctx->bigBatchKernel.store(ms[1] < 0.985f * ms[0] ? 1 : 0, std::memory_order_relaxed);
+        if (ctx->switches.verbose) {
+            std::fprintf(stderr, "memb_hip: large batches: persistent %.4f ms, one tile per wavefront %.4f ms per launch -> %s\n",
+                         ms[0] / 2, ms[1] / 2, ctx->bigBatchKernel.load() ? "one tile per wavefront" : "persistent");
+        }
+    }
+    return code;
+}
+
+int launchTrained(
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
+    const Epilogue& epilogue, bool keysOut, int force)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    if (force < 0 && ctx->switches.persistent == 1 && ctx->switches.autotune && !keysOut && !epilogue.accumulate &&
+        epilogue.divisor == 0.f && ctx->bigBatchKernel.load(std::memory_order_relaxed) < 0 &&
+        (n + wordsPerWave - 1) / wordsPerWave > 4ull * ctx->cuCount * 16) {
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+            (void)hipGetLastError();
+            capture = hipStreamCaptureStatusActive;   // (the legacy stream while another one captures: leave it alone)
+        }
+        if (capture == hipStreamCaptureStatusNone) {
+            return timeBigBatchKernels(ctx, rows, n, out, ld, colOff, stream);   // (the batch is decoded by it)
+        }
+    }
     TrainedPlan plan;
-    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan);
+    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
@@ -1150,6 +1228,7 @@ Switches readSwitches()
     switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
     switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
     switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 3);
+    switches.autotune = envUint("MEMB_HIP_AUTOTUNE", 1) != 0;
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1813,6 +1892,13 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "blocks_per_cu" && value <= 32) {
         ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
+    } else if (key == "autotune" && value <= 2) {
+        // 0 / 1: off / on; 2: forget what was measured (the next large batch times the kernels again)
+        if (value == 2) {
+            ctx->bigBatchKernel.store(-1, std::memory_order_relaxed);
+        } else {
+            ctx->switches.autotune = value != 0;
+        }
     } else if (key == "pipeline" && value <= 3) {
         ctx->switches.pipeline = static_cast<uint32_t>(value);
     } else if (key == "grid_policy" && value <= 1) {

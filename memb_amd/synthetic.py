@@ -94,15 +94,19 @@ def cache_dir():
     return os.environ.get('MEMB_BENCH_CACHE', '/tmp/memb_amd_bench')
 
 
+def cached_model_path(count, dim=300, storage_type='trained', bits_per_weight=4, seed=1234, distribution='normal'):
+    # g2: generator version -- build_file draws blocks >= 1 from generators of their own since round 2, so a
+    # model of more than 200 000 words written by an older tree has other contents under the old name
+    name = 'synthetic_g2_{}w_{}d_{}{}bit_{}_{}.bin'.format(count, dim, storage_type, bits_per_weight, distribution, seed)
+    return os.path.join(cache_dir(), name)
+
+
 def cached_model(count, dim=300, storage_type='trained', bits_per_weight=4, seed=1234, distribution='normal', device=None):
     '''Path of a synthetic model in the per-box cache, written on first use (device: see build_file;
     MEMB_SYNTH_DEVICE in the environment supplies a default). Returns (path, seconds spent building;
     0.0 when it was already there)'''
     import time
-    # g2: generator version -- build_file draws blocks >= 1 from generators of their own since round 2, so a
-    # model of more than 200 000 words written by an older tree has other contents under the old name
-    name = 'synthetic_g2_{}w_{}d_{}{}bit_{}_{}.bin'.format(count, dim, storage_type, bits_per_weight, distribution, seed)
-    path = os.path.join(cache_dir(), name)
+    path = cached_model_path(count, dim, storage_type, bits_per_weight, seed, distribution)
     if os.path.exists(path):
         return path, 0.0
     os.makedirs(cache_dir(), exist_ok=True)

@@ -740,14 +740,12 @@ def main():
         args.no_configs = True
         args.no_cpu_baseline = True
         special = special_workload(workload, args, memb_amd, synthetic, library, torch, np, glove, fasttext)
-        build_seconds = special['build_seconds']
+        build_seconds += special['build_seconds']
         info, open_seconds, out, n, nbytes, step = special['info'], 0.0, special['out'], special['n'], special['nbytes'], special['step']
         dim, count, rows_host, reader, path = out.shape[1], special['n'], None, None, None
     else:
-        if rank == 0:
-            path, build_seconds = synthetic.cached_model(words, 300, 'trained', bits)   # written once per box
         if distributed:
-            dist.barrier()
+            dist.barrier()   # (rank 0 has written the models: prebuild_models above)
         path, _ = synthetic.cached_model(words, 300, 'trained', bits)
 
         reader, info, open_seconds = open_reader(memb_amd, path, local_rank, batch or 0)

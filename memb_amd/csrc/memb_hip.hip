@@ -585,48 +585,69 @@ int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
     const Epilogue& epilogue, bool keysOut = false, int force = -1);
 
-// The first large batch of a context: both kernels on that batch, three launches each (one to warm up, two between
-// a pair of events); the one-tile kernel is kept if it is at least 1.5 % faster. The batch is decoded six times
-// instead of once -- the same bits every time -- and the call waits for the device this once.
+// The first large batch of a context: both kernels on that very batch, ALTERNATING, six launches each, every launch
+// between its own pair of events, all enqueued without a gap and waited for once; the first two pairs are run-in and
+// the rest are summed. (Three launches of one kernel and then three of the other is not a measurement: after an idle
+// gap this part runs launches 3 to ~25 of a burst about 10 % slower than later ones -- DESIGN.md section 6 -- and the
+// kernel timed second lost every time.) The one-tile kernel is kept if it is at least 1.5 % faster. The batch is
+// decoded twelve times instead of once -- the same bits every time -- and the call waits for the device this once.
 int timeBigBatchKernels(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
 {
-    hipEvent_t begin = nullptr;
-    hipEvent_t end = nullptr;
-    HIP_TRY(hipEventCreate(&begin));
-    if (hipEventCreate(&end) != hipSuccess) {
-        (void)hipEventDestroy(begin);
-        return fail(MEMB_HIP_ERR_DEVICE, "hipEventCreate");
+    constexpr int ROUNDS = 6;
+    constexpr int RUN_IN = 2;
+    hipEvent_t events[ROUNDS][2][2] = {};
+    hipError_t status = hipSuccess;
+    for (int round = 0; round < ROUNDS && status == hipSuccess; ++round) {
+        for (int kind = 0; kind < 2 && status == hipSuccess; ++kind) {
+            for (int edge = 0; edge < 2 && status == hipSuccess; ++edge) {
+                status = hipEventCreate(&events[round][kind][edge]);
+            }
+        }
+    }
+    int code = status == hipSuccess ? MEMB_HIP_OK : fail(MEMB_HIP_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(status));
+    for (int round = 0; round < ROUNDS && code == MEMB_HIP_OK; ++round) {
+        for (int kind = 0; kind < 2 && code == MEMB_HIP_OK; ++kind) {   // 0 = persistent, 1 = one tile per wavefront
+            status = hipEventRecord(events[round][kind][0], stream);
+            code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, kind == 0 ? 1 : 0);
+            if (status == hipSuccess) {
+                status = hipEventRecord(events[round][kind][1], stream);
+            }
+            if (status != hipSuccess && code == MEMB_HIP_OK) {
+                code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(status));
+            }
+        }
     }
     float ms[2] = {0.f, 0.f};
-    int code = MEMB_HIP_OK;
-    for (int kind = 0; kind < 2 && code == MEMB_HIP_OK; ++kind) {
-        const int force = kind == 0 ? 1 : 0;
-        code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, force);
-        hipError_t status = hipEventRecord(begin, stream);
-        for (int repeat = 0; repeat < 2 && code == MEMB_HIP_OK; ++repeat) {
-            code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, force);
+    if (code == MEMB_HIP_OK) {
+        status = hipEventSynchronize(events[ROUNDS - 1][1][1]);
+        for (int round = RUN_IN; round < ROUNDS && status == hipSuccess; ++round) {
+            for (int kind = 0; kind < 2 && status == hipSuccess; ++kind) {
+                float one = 0.f;
+                status = hipEventElapsedTime(&one, events[round][kind][0], events[round][kind][1]);
+                ms[kind] += one;
+            }
         }
-        if (status == hipSuccess) {
-            status = hipEventRecord(end, stream);
-        }
-        if (status == hipSuccess) {
-            status = hipEventSynchronize(end);
-        }
-        if (status == hipSuccess) {
-            status = hipEventElapsedTime(&ms[kind], begin, end);
-        }
-        if (status != hipSuccess && code == MEMB_HIP_OK) {
+        if (status != hipSuccess) {
             code = fail(MEMB_HIP_ERR_DEVICE, std::string("timing the kernels: ") + hipGetErrorString(status));
         }
+    } else {
+        (void)hipStreamSynchronize(stream);
     }
-    (void)hipEventDestroy(begin);
-    (void)hipEventDestroy(end);
+    for (auto& round : events) {
+        for (auto& kind : round) {
+            for (hipEvent_t event : kind) {
+                if (event) {
+                    (void)hipEventDestroy(event);
+                }
+            }
+        }
+    }
     if (code == MEMB_HIP_OK) {
         ctx->bigBatchKernel.store(ms[1] < 0.985f * ms[0] ? 1 : 0, std::memory_order_relaxed);
         if (ctx->switches.verbose) {
             std::fprintf(stderr, "memb_hip: large batches: persistent %.4f ms, one tile per wavefront %.4f ms per launch -> %s\n",
-                         ms[0] / 2, ms[1] / 2, ctx->bigBatchKernel.load() ? "one tile per wavefront" : "persistent");
+                         ms[0] / (ROUNDS - RUN_IN), ms[1] / (ROUNDS - RUN_IN), ctx->bigBatchKernel.load() ? "one tile per wavefront" : "persistent");
         }
     }
     return code;

@@ -63,7 +63,7 @@ def test_single_gpu_line_and_configuration_array(native, tmp_path):
     roofline = line['roofline']
     assert roofline['bound'] == 'hbm' and roofline['peak'] == 8000.0 and roofline['unit'] == 'GB/s'
     assert abs(roofline['frac'] - roofline['achieved'] / roofline['peak']) < 1e-12
-    assert roofline['kernel'].startswith('decode_trained')
+    assert roofline['kernel'].startswith('decode_')   # (which kernel depends on the batch size: 50 000 words here)
     assert line['cpu_baseline']['kind'] in ('reference', 'port') and line['cpu_baseline']['cores'] >= 1
     workloads = [entry['workload'] for entry in line['configs']]
     for index in range(5):

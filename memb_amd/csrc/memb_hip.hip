@@ -585,17 +585,20 @@ int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
     const Epilogue& epilogue, bool keysOut = false, int force = -1);
 
-// The first large batch of a context: both kernels on that very batch, ALTERNATING, six launches each, every launch
-// between its own pair of events, all enqueued without a gap and waited for once; the first two pairs are run-in and
-// the rest are summed. (Three launches of one kernel and then three of the other is not a measurement: after an idle
-// gap this part runs launches 3 to ~25 of a burst about 10 % slower than later ones -- DESIGN.md section 6 -- and the
-// kernel timed second lost every time.) The one-tile kernel is kept if it is at least 1.5 % faster. The batch is
-// decoded twelve times instead of once -- the same bits every time -- and the call waits for the device this once.
+// The first large batch of a context: both kernels on that very batch, ALTERNATING, every launch between its own pair
+// of events, all enqueued without a gap and waited for once; the first RUN_IN pairs are not counted, the rest are
+// summed. Two things this has to get right (both seen): three launches of one kernel and then three of the other is
+// not a measurement -- after an idle gap this part runs launches 3 to ~25 of a burst about 10 % slower than later ones
+//  and the kernel timed second lost every time; and twelve alternating launches still sit inside
+// that transient, where the two kernels tie on models on which the one-tile kernel is 3-10 % faster once the part has
+// settled (batch 8) -- hence a run-in of 13 pairs (~15 ms). The one-tile kernel is kept if it is at least 1.5 % faster.
+// The batch is decoded 34 times instead of once -- the same bits every time -- and the call waits for the device this
+// once (~20 ms for a 2.2 M-word dump; a context's staging takes 50 times that).
 int timeBigBatchKernels(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
 {
-    constexpr int ROUNDS = 6;
-    constexpr int RUN_IN = 2;
+    constexpr int ROUNDS = 17;
+    constexpr int RUN_IN = 13;
     hipEvent_t events[ROUNDS][2][2] = {};
     hipError_t status = hipSuccess;
     for (int round = 0; round < ROUNDS && status == hipSuccess; ++round) {

@@ -6,6 +6,9 @@
 #   tools/perf/prof.sh r3_union decode_trained_union --workload union-concat-500k
 tag=$1; kernel=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# (the kernel a large batch runs is settled by timing two kernels on the first one: off here, so that every pass
+# profiles the same launches -- the persistent kernel, unless MEMB_HIP_PERSISTENT says otherwise)
+export MEMB_HIP_AUTOTUNE=${MEMB_HIP_AUTOTUNE:-0}
 out=gpurun_out/prof_$tag; mkdir -p $out
 long="bench.py $* --no-configs --no-cpu-baseline --steps 10 --warmup 3"
 short="bench.py $* --no-configs --no-cpu-baseline --steps 3 --warmup 1"

@@ -1090,6 +1090,12 @@ __device__ __forceinline__ void outputUnionTile(
 
     const uint32_t pieces = tileWords * COUNT * piecesPerWord;
     float* tileOut = first.out + tileBase * first.ld;
+    // (half row, column) of the lane's first piece by one division; each further piece lies 64 pieces on, which is
+    // stepHalves half rows and stepColumns columns with at most one carry -- no division per piece
+    const uint32_t stepHalves = WAVE / piecesPerWord;
+    const uint32_t stepColumns = WAVE - stepHalves * piecesPerWord;
+    uint32_t half = fastDivide(lane, first.pieceMagic, piecesPerWord);
+    uint32_t column = lane - half * piecesPerWord;
     constexpr int BURST = 4;
     for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
         uint32_t k[BURST];
@@ -1097,17 +1103,24 @@ __device__ __forceinline__ void outputUnionTile(
         uint32_t c[BURST];
 #pragma unroll
         for (int b = 0; b < BURST; ++b) {
-            const uint32_t q = min(q0 + WAVE * b, pieces - 1);
-            h[b] = fastDivide(q, first.pieceMagic, piecesPerWord);
-            c[b] = q - h[b] * piecesPerWord;
-            k[b] = readKey(h[b] % COUNT, h[b] / COUNT, c[b]);
+            h[b] = half;
+            c[b] = column;
+            // (past the tile's end: the last piece once more, never stored)
+            const bool inside = q0 + WAVE * b < pieces;
+            const uint32_t hh = inside ? half : tileWords * COUNT - 1;
+            const uint32_t cc = inside ? column : piecesPerWord - 1;
+            k[b] = readKey(hh % COUNT, hh / COUNT, cc);
+            column += stepColumns;
+            const bool carry = column >= piecesPerWord;
+            column -= carry ? piecesPerWord : 0u;
+            half += stepHalves + (carry ? 1u : 0u);
         }
 #pragma unroll
         for (int b = 0; b < BURST; ++b) {
             const uint32_t word = h[b] / COUNT;
             const uint32_t model = h[b] % COUNT;
             float4 f = gather(model, k[b]);
-            if (FAST && ((absentHalves >> h[b]) & 1)) {
+            if (FAST && ((absentHalves >> (h[b] & 63)) & 1)) {
                 f = zero;
             }
             unsigned long long colOff = u.model[0].colOff;

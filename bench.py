@@ -124,7 +124,9 @@ def spawn_ranks(args):
     build_native.build_all()
     rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
     available = kfd_gpu_count()
-    if not rehearsal and (available or 0) < args.gpus:
+    # refuse only what is certain: no compute driver at all, or a readable topology with fewer GPUs than asked for
+    # (a topology this user cannot read counts nothing: the ranks then find out for themselves)
+    if not rehearsal and (available is None or 0 < available < args.gpus):
         raise SystemExit('--gpus {}: this node has {} GPU(s) ({})'.format(
             args.gpus, available or 0, 'kfd topology' if available is not None else 'no /sys/class/kfd: no amdgpu compute driver'))
     with socket.socket() as probe:

@@ -391,6 +391,9 @@ def measure_config(name, what, reader, path, rows_host, timer, library, torch, n
         'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         'parity': parity,
     }
+    if info.get('large_batch_kernel', -1) >= 0:
+        result['large_batch_timing'] = {'chosen': 'one tile per wavefront' if info['large_batch_kernel'] else 'persistent',
+                                        'persistent_ms': info['large_batch_persistent_ms'], 'one_tile_ms': info['large_batch_one_tile_ms']}
     del rows, out
     return result
 
@@ -914,6 +917,10 @@ def main():
             'kernel': special['kernel'] if special else info.get('kernel', 'decode_trained_persistent'),
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_timing': kernel_timing,
+            'large_batch_timing': None if info.get('large_batch_kernel', -1) < 0 else {
+                'what': 'the first large batch of a context is decoded by both kernels for large batches, alternating, and the faster one is kept (DESIGN.md section 5)',
+                'chosen': 'one tile per wavefront' if info['large_batch_kernel'] else 'persistent',
+                'persistent_ms': info['large_batch_persistent_ms'], 'one_tile_ms': info['large_batch_one_tile_ms']},
             'kernel_min_ms': kernel_ms[0],
             'kernel_median_ms': kernel_ms[len(kernel_ms) // 2],
             'kernel_ms_in_launch_order': [round(starts[i].elapsed_time(stops[i]), 4) for i in range(args.steps)],

@@ -139,6 +139,9 @@ typedef struct memb_hip_ctx_info {
     uint32_t register_waves_per_cu;   /* ... and the wavefronts per CU those registers allow (32 = no limit from registers) */
     uint64_t batch_words;        /* IN: the batch size `kernel` and the geometry fields are reported for (the kernel is chosen
                                     by batch size); 0 = a large batch */
+    int32_t large_batch_kernel;  /* trained: -1 = not timed yet, 0 = the persistent pipeline, 1 = one tile per wavefront ("autotune") */
+    float large_batch_persistent_ms;   /* ... and what the timing read, per launch */
+    float large_batch_one_tile_ms;
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);

@@ -115,6 +115,9 @@ py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
     result["row_bytes"] = info.row_bytes;
     result["kernel_registers"] = info.kernel_registers;
     result["register_waves_per_cu"] = info.register_waves_per_cu;
+    result["large_batch_kernel"] = info.large_batch_kernel;
+    result["large_batch_persistent_ms"] = info.large_batch_persistent_ms;
+    result["large_batch_one_tile_ms"] = info.large_batch_one_tile_ms;
     return result;
 }
 

@@ -157,6 +157,7 @@ struct memb_hip_ctx {
     bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
+    float bigBatchMs[2] = {0.f, 0.f};      // what that timing read: persistent, one tile per wavefront (ms per launch)
     std::atomic<int> bigBatchKernel{-1};   // batches of more than 4 tiles per resident wavefront: -1 = not timed yet,
                                          // 0 = the persistent pipeline, 1 = one tile per wavefront (launchTrained)
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
@@ -647,6 +648,8 @@ int timeBigBatchKernels(
         }
     }
     if (code == MEMB_HIP_OK) {
+        ctx->bigBatchMs[0] = ms[0] / (ROUNDS - RUN_IN);
+        ctx->bigBatchMs[1] = ms[1] / (ROUNDS - RUN_IN);
         ctx->bigBatchKernel.store(ms[1] < 0.985f * ms[0] ? 1 : 0, std::memory_order_relaxed);
         if (ctx->switches.verbose) {
             std::fprintf(stderr, "memb_hip: large batches: persistent %.4f ms, one tile per wavefront %.4f ms per launch -> %s\n",
@@ -1967,6 +1970,9 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         }
         const TrainedGeometry geometry = plan.geometry;
         info->waves_per_block = geometry.waves;
+        info->large_batch_kernel = ctx->bigBatchKernel.load(std::memory_order_relaxed);
+        info->large_batch_persistent_ms = ctx->bigBatchMs[0];
+        info->large_batch_one_tile_ms = ctx->bigBatchMs[1];
         info->kernel_registers = static_cast<uint32_t>(plan.numRegs);
         info->register_waves_per_cu = plan.persistent ? plan.registerWavesPerCu : 0;
         info->lanes_per_word = ctx->lanesPerWord;

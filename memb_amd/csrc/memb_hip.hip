@@ -1952,6 +1952,7 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
     info->dim = ctx->dim;
     info->n_rows = ctx->nRows;
     info->device_bytes = ctx->deviceBytes;
+    info->large_batch_kernel = -1;
     if (ctx->storage == memb::wire::Storage_Trained) {
         const memb::DecodeTable& table = ctx->fast ? ctx->hostTable : ctx->byteTable;   // the lookup kernels' table
         info->root_bits = table.rootBits;

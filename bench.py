@@ -470,6 +470,19 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     results.append(measure_config(
         'glove840b-300d-4bit-100k (BASELINE.json configs[1])', '100 000 uniformly random rows of the 2.2 M-word 4-bit model, 1 % misses',
         reader4, path4, rows, timer, library, torch, np, launches=30))
+    # device-resident latency of small batches of the same model: the kernel is chosen by batch size (one tile per
+    # wavefront / decode_records_persistent / large-batch kernel), each timed as a burst of back-to-back launches
+    small = []
+    for count in (1000, 10000, 100000, 500000):
+        picks = batch_rows(len(reader4), count, np)
+        ids = torch.from_numpy(picks.view(np.int32)).cuda()
+        target = torch.empty((count, reader4.dim), dtype=torch.float32, device='cuda')
+        ms = timer.burst(lambda: reader4.rows_embedding_device(ids, out=target), 100 if count <= 100000 else 30)
+        nbytes = algorithmic_bytes(library, reader4, picks)
+        small.append({'batch': count, 'kernel': reader4.info(count)['kernel'], 'us_per_launch': ms * 1e3,
+                      'embeddings_per_s': count / (ms * 1e-3), 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+        del ids, target
+    results[-1]['small_batches_of_the_same_model'] = small
 
     path, spent = synthetic.cached_model(fasttext, 300, 'trained', 6)
     build_seconds += spent

@@ -620,11 +620,11 @@ __global__ void decode_trained(TrainedParams p)
         static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const unsigned long long tileBase = tile * p.wordsPerWave;
     const LaneRole role = laneRole(p, lane);
-    // The wavefront's dependent hops -- row ids, index records, the first four rounds of bitstream pieces -- are
-    // issued BEFORE the block copies table and codebook into LDS: none of them needs LDS, and the copy (one L2
-    // round trip and a barrier) then runs beside them instead of in front of them. (Past the batch's end
-    // loadTileRow yields no row and the loads read row 0's start: harmless, the wavefront returns below.)
-    const bool early = !(measureFlags(p) & 0x40000);   // (measurement builds: bit 18 = the loads behind the copy, as before round 3)
+    // (Measurement builds, bit 18: the wavefront's dependent hops -- row ids, index records, the first rounds of
+    // bitstream pieces -- issued BEFORE the block copies table and codebook into LDS, which none of them needs.
+    // Measured: 0.2-10 % SLOWER on every model and batch size -- 100 k rows +8..10 %, the 4-bit dump +4.6 % --
+    // so the loads stay behind the copy. profiles/r03_experiments.txt, batch 14.)
+    const bool early = (measureFlags(p) & 0x40000) != 0;
     WordMeta meta;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     StreamRegisters first;
@@ -688,11 +688,21 @@ __global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedPara
     // The row ids of the first four tiles before anything else: they depend on nothing, and the copy of
     // table and codebook into LDS then hides the first of the pipeline's dependent hops (a batch of a few
     // tiles per wavefront -- 100 000 words -- is mostly prologue).
-    const uint32_t row0 = loadTileRow(p, tile, role);
-    const uint32_t row1 = loadTileRow(p, tile + stride, role);
-    const uint32_t row2 = loadTileRow(p, tile + 2 * stride, role);
-    uint32_t rowLoading = loadTileRow(p, tile + 3 * stride, role);
+    const bool rowsFirst = !(measureFlags(p) & 0x80000);   // (measurement builds, bit 19: the row ids behind the copy)
+    uint32_t row0 = 0, row1 = 0, row2 = 0, rowLoading = 0;
+    if (rowsFirst) {
+        row0 = loadTileRow(p, tile, role);
+        row1 = loadTileRow(p, tile + stride, role);
+        row2 = loadTileRow(p, tile + 2 * stride, role);
+        rowLoading = loadTileRow(p, tile + 3 * stride, role);
+    }
     const WaveLds mem = setUpLds<MODE>(p, lds);
+    if (!rowsFirst) {
+        row0 = loadTileRow(p, tile, role);
+        row1 = loadTileRow(p, tile + stride, role);
+        row2 = loadTileRow(p, tile + 2 * stride, role);
+        rowLoading = loadTileRow(p, tile + 3 * stride, role);
+    }
     // Measurement (debugFlags bit 3): the wavefronts of a block meet at a barrier before every
     // output phase, so that the block's adjacent tiles reach memory together; every wavefront of
     // the block then makes the same number of rounds (idle ones past the end of the batch).
@@ -854,13 +864,22 @@ __global__ void decode_records_persistent(TrainedParams p)
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
     const LaneRole role = laneRole(p, lane);
-    // row ids before the table copy, which hides their latency
-    uint32_t rowCurrent = loadTileRow(p, tile, role);
-    uint32_t rowNext = loadTileRow(p, tile + stride, role);
-    uint32_t rowLoading = loadTileRow(p, tile + 2 * stride, role);
+    // row ids before the table copy, which hides their latency (measurement builds, bit 19: behind it)
+    const bool rowsFirst = !(measureFlags(p) & 0x80000);
+    uint32_t rowCurrent = 0, rowNext = 0, rowLoading = 0;
+    if (rowsFirst) {
+        rowCurrent = loadTileRow(p, tile, role);
+        rowNext = loadTileRow(p, tile + stride, role);
+        rowLoading = loadTileRow(p, tile + 2 * stride, role);
+    }
     const WaveLds mem = setUpLds<MODE>(p, lds);
     if (tile >= tiles) {
         return;
+    }
+    if (!rowsFirst) {
+        rowCurrent = loadTileRow(p, tile, role);
+        rowNext = loadTileRow(p, tile + stride, role);
+        rowLoading = loadTileRow(p, tile + 2 * stride, role);
     }
     const uint32_t setDwords = p.wordsPerWave * p.slotDwords;
     uint32_t* slots = mem.slots;                        // the set being decoded

@@ -625,11 +625,16 @@ __global__ void decode_trained(TrainedParams p)
     // Measured: 0.2-10 % SLOWER on every model and batch size -- 100 k rows +8..10 %, the 4-bit dump +4.6 % --
     // so the loads stay behind the copy. profiles/r03_experiments.txt, batch 14.)
     const bool early = (measureFlags(p) & 0x40000) != 0;
+    const bool rowEarly = (measureFlags(p) & 0x100000) != 0;   // (bit 20: only the row ids before the copy)
     WordMeta meta;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     StreamRegisters first;
+    uint32_t tileRow = 0;
+    if (early || rowEarly) {
+        tileRow = loadTileRow(p, tile, role);
+    }
     if (early) {
-        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, loadTileRow(p, tile, role), role);
+        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
         unpackMeta(p, role, meta);
         issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, 0, first);
     }
@@ -638,7 +643,10 @@ __global__ void decode_trained(TrainedParams p)
         return;
     }
     if (!early) {
-        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, loadTileRow(p, tile, role), role);
+        if (!rowEarly) {
+            tileRow = loadTileRow(p, tile, role);
+        }
+        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
         unpackMeta(p, role, meta);
         issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, 0, first);
     }

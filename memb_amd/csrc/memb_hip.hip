@@ -534,7 +534,7 @@ struct TrainedPlan {
 // (the context's device is current)
 //   The "above" class is settled per context by timing: on 2- and 6-bit models the one-tile kernel beats the
 //   persistent one by 2-14 % on every box and in every row order, on the 4-bit model it loses the key-order dump by
-//   3-6 % on three boxes of four and wins shuffled rows by 2-4 % (batches 3, 5, 6, 7) -- so the first large batch a
+//   3-6 % on four boxes of seven, wins it by 3-4 % on two, and wins shuffled rows by 2-4 % -- so the first large batch a
 //   context sees runs both on that very batch (same bits either way) and keeps the faster: ctx->bigBatchKernel.
 // force: -1 = by the rules above, 0 = one tile per wavefront, 1 = persistent
 int planTrained(

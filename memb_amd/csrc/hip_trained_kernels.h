@@ -892,7 +892,8 @@ __global__ void decode_records_persistent(TrainedParams p)
     const uint32_t setDwords = p.wordsPerWave * p.slotDwords;
     uint32_t* slots = mem.slots;                        // the set being decoded
     uint32_t* otherSlots = mem.slots + setDwords;       // DMA: the set being filled
-    u32x4 stream0, stream1;                             // !DMA: the next tile's pieces
+    u32x4 stream0 = {0, 0, 0, 0};                       // !DMA: the next tile's pieces (a tile of at most 64 pieces
+    u32x4 stream1 = {0, 0, 0, 0};                       // never loads the second one)
 
     // prologue
     if (DMA) {
@@ -1269,7 +1270,8 @@ __global__ void decode_records_union_persistent(UnionParams u)
     uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
     uint32_t* slots = waveLds + u.slotOffsetDwords[0];          // the set being decoded
     uint32_t* otherSlots = waveLds + u.slotOffsetDwords[1];     // DMA: the set being filled
-    u32x4 stream0, stream1;                                      // !DMA: the next unit's pieces
+    u32x4 stream0 = {0, 0, 0, 0};                                // !DMA: the next unit's pieces
+    u32x4 stream1 = {0, 0, 0, 0};
 
     if (DMA) {
         issueRecordDma(UNION_MODEL(0), rowCurrent, lane, slots);

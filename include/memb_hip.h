@@ -165,6 +165,8 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
  *   "pipeline"        persistent kernel of row-record models: 0 = the general one, 1 = decode_records_persistent with
  *                     stream registers, 2 = the same fed by LDS-DMA (global_load_lds), 3 = by batch size (default)
+ *   "tiles_per_wave"  0 = persistent kernels occupy the resident wavefront slots and walk all tiles (default); K = a grid of
+ *                     tiles / K wavefronts that walk about K tiles each and exit
  *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
  *                     that make the same number of rounds (equal tiles per wavefront)
  *   "persistent"      0 = one tile per wavefront always, 1 = by batch size (default), 2 = the persistent pipeline always

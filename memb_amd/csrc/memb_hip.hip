@@ -117,6 +117,9 @@ struct Switches {
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
     uint32_t pipeline = 3;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
                                    // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA, 3 = by batch size
+    uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: 0 = persistent kernels take the resident wavefront slots and walk all
+                                   // tiles; K = a grid of tiles / K wavefronts, each walks ~K tiles and exits (short-lived wavefronts
+                                   // with a pipeline: between one tile per wavefront and the persistent form)
     bool autotune = true;          // MEMB_HIP_AUTOTUNE: the first large batch times both kernels for large batches (launchTrained)
     uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
                                    // make the same number of rounds, so that all of them walk the same number of tiles
@@ -455,6 +458,9 @@ hipError_t launchPersistentGeneric(
         // wavefronts gives all of them the same work (to within one tile). (Measured: no gain; kept as an option.)
         const uint32_t rounds = (tileBlocks + resident - 1) / resident;
         blocks = (tileBlocks + rounds - 1) / rounds;
+    }
+    if (ctx->switches.tilesPerWave) {
+        blocks = std::max(blocks, (tileBlocks + ctx->switches.tilesPerWave - 1) / ctx->switches.tilesPerWave);
     }
     launch(blocks);
     return hipGetLastError();
@@ -1256,6 +1262,7 @@ Switches readSwitches()
     switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
     switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 3);
     switches.autotune = envUint("MEMB_HIP_AUTOTUNE", 1) != 0;
+    switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1926,6 +1933,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         } else {
             ctx->switches.autotune = value != 0;
         }
+    } else if (key == "tiles_per_wave" && value <= 65536) {
+        ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
     } else if (key == "pipeline" && value <= 3) {
         ctx->switches.pipeline = static_cast<uint32_t>(value);
     } else if (key == "grid_policy" && value <= 1) {

@@ -154,6 +154,10 @@ struct memb_hip_ctx {
     memb::DecodeTable byteTable;
     std::vector<memb::CodeInfo> codeLengths;   // kept to rebuild byteTable narrower when LDS is short
     uint32_t* table32 = nullptr;
+    // nibble-key models only: the table and the codebook in their BYTE-key forms as well (8-byte entries with the symbol
+    // replicated per byte, 256 plain centroids), so that a union with a byte-key model can run as one kernel
+    uint32_t* tableBytes = nullptr;
+    float* codebookBytes = nullptr;
     uint32_t maxStreamBytes = 0;
     uint32_t slotDwords = 0;
     uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
@@ -812,16 +816,20 @@ int launchTrainedUnion(
     }
     const memb_hip_ctx* first = ctxs[0];
     bool hasSub = false;
+    bool allFast = true;
     for (size_t m = 0; m < count; ++m) {
         const memb_hip_ctx* ctx = ctxs[m];
         if (ctx->storage != memb::wire::Storage_Trained || ctx->device != first->device || ctx->dim != first->dim ||
-            ctx->fast != first->fast || ctx->lanesPerWord != first->lanesPerWord ||
+            ctx->lanesPerWord != first->lanesPerWord ||
             ctx->segmentSymbols != first->segmentSymbols || ctx->dim % 4 != 0 || colOffs[m] % 4 != 0 ||
             ld < colOffs[m] + ctx->dim) {
-            return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the models differ in storage, device, dim, key format or lane geometry");
+            return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the models differ in storage, device, dim or lane geometry");
         }
         hasSub = hasSub || ctx->hostTable.hasSubTables;
+        allFast = allFast && ctx->fast;
     }
+    // Nibble keys (<= 16 centroids, codes <= 8 bits) only when every model has them; a mixed union decodes the
+    // nibble-key models through their byte-key tables (memb_hip_ctx::tableBytes): the same symbols, one per byte.
     if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 || n > (size_t(1) << 37)) {
         return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the output is not 16-byte aligned in every row");
     }
@@ -852,8 +860,13 @@ int launchTrainedUnion(
         p.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
         p.wordsPerWave = wordsPerWave;
         p.segmentSymbols = ctx->segmentSymbols;
-        p.keyRowBytes = keyRowBytes(ctx);
-        p.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
+        p.keyRowBytes = allFast ? keyRowBytes(ctx) : roundUp4(ctx->dim);
+        p.keyTileDwords = (wordsPerWave * p.keyRowBytes + 3) / 4 + 1;
+        if (!allFast && ctx->fast) {
+            p.table = ctx->tableBytes;
+            p.codebook = ctx->codebookBytes;
+            p.codebookDwords = 256;
+        }
         p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * count * (ctx->dim / 4));
         p.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
         params.tableOffsetDwords[m] = sharedDwords;
@@ -924,7 +937,7 @@ int launchTrainedUnion(
     }
     for (int attempt = 0; attempt < 2 && !waves; ++attempt) {
         layOut(persistent);
-        kernel = unionKernel(hasSub, first->fast, average, count, persistent ? (dma ? 2u : 1u) : 0u);
+        kernel = unionKernel(hasSub, allFast, average, count, persistent ? (dma ? 2u : 1u) : 0u);
         hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
         if (status != hipSuccess) {
             return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
@@ -1675,6 +1688,25 @@ int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         }
         code = copyToDevice(ctx->codebook, codebook.data(), 512 * 4);
         ctx->hostCodebook = codebook;
+        if (code == MEMB_HIP_OK && ctx->fast) {
+            // the byte-key forms (see memb_hip_ctx::tableBytes): 2 KiB + 1 KiB
+            std::vector<uint32_t> byteForm(ctx->tableDwords, 0);
+            for (size_t i = 0; i < ctx->hostTable.entries.size(); ++i) {
+                const uint32_t entry = ctx->hostTable.entries[i];   // (no pointers: nibble-key models have one-level tables)
+                byteForm[2 * i] = entry & 0xff;
+                byteForm[2 * i + 1] = ((entry >> 8) & 0xff) * 0x01010101u;
+            }
+            code = deviceAlloc(ctx, &ctx->tableBytes, byteForm.size() * 4);
+            if (code == MEMB_HIP_OK) {
+                code = copyToDevice(ctx->tableBytes, byteForm.data(), byteForm.size() * 4);
+            }
+            if (code == MEMB_HIP_OK) {
+                code = deviceAlloc(ctx, &ctx->codebookBytes, 256 * 4);
+            }
+            if (code == MEMB_HIP_OK) {
+                code = copyToDevice(ctx->codebookBytes, centroids.data(), 256 * 4);
+            }
+        }
     }
     return code;
 }

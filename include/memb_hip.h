@@ -232,8 +232,9 @@ int memb_hip_decode_rows_device_ex(
  * row i = (vector 0 + vector 1 + ...) / count, added in model order in fp32 and divided once,
  * as numpy.mean does, written at column col_offs[0].
  * Returns MEMB_HIP_UNSUPPORTED (and does nothing) when the models cannot share a
- * kernel: other than 2 to 4 trained storages of equal dim, lane geometry and key
- * format on one device, or an output that is not 16-byte aligned in every block.
+ * kernel: other than 2 to 4 trained storages of equal dim and lane geometry on one
+ * device, or an output that is not 16-byte aligned in every block
+ * (memb_hip_last_error() names the condition).
  */
 #define MEMB_HIP_UNION_AVERAGE 1u
 int memb_hip_decode_rows_union_device(

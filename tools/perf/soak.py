@@ -19,8 +19,12 @@ def check(got, want, what):
 while time.time()-start < seconds:
     path,words,checker=models[int(rng.integers(0,len(models)))]
     reader=memb_amd.Reader(path)
+    if rng.random()<0.5 and 'trained' in reader._impl.storage_name():
+        # round 3: the kernels are chosen by batch size; force other choices now and then (results never depend on them)
+        reader.set_option('pipeline', int(rng.integers(0,4))); reader.set_option('persistent', int(rng.integers(0,3)))
+        reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8]))); reader.set_option('blocks_per_cu', int(rng.choice([0,0,2,5])))
     for _ in range(int(rng.integers(1,6))):
-        n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000]))
+        n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
         if rng.random()<0.5: batch[::7]=['?']*len(batch[::7])
         want=checker.batch_embedding(batch)
@@ -40,7 +44,8 @@ while time.time()-start < seconds:
     if rng.random()<0.3:
         a=memb_amd.Reader(models[0][0]); b=memb_amd.Reader(models[1][0])
         pool=models[0][1][:2000]+models[1][1][:2000]
-        batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000])))]
+        if rng.random()<0.5: a.set_option('pipeline', int(rng.integers(0,4)))
+        batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000,90000])))]
         for mode in ('concatenate','average'):
             u=memb_amd.ReadersUnion([a,b],mode)
             rows=[models[0][2].batch_embedding(batch), models[1][2].batch_embedding(batch)]
@@ -49,6 +54,18 @@ while time.time()-start < seconds:
             check(u.batch_embedding(batch), want, 'union host '+mode)
         del a,b
     del reader
+    if rng.random()<0.05:
+        # the device writer: same bytes as the host writer
+        count=int(rng.choice([300,9999,10000,10001,25000])); dim=int(rng.choice([3,7,64,300]))
+        w=synthetic.make_words(count); v=synthetic.make_vectors(count,dim,seed=int(rng.integers(0,1000)))
+        bits_used=int(rng.choice([2,4,6,8]))
+        for device,name in ((None,'/tmp/soak_host.bin'),(0,'/tmp/soak_device.bin')):
+            b=memb_amd.Builder(dim,'trained',bits_used,device=device)
+            edges=np.linspace(0,count,int(rng.integers(1,5))+1).astype(int)
+            for lo,hi in zip(edges[:-1],edges[1:]): b.add_words(w[lo:hi],v[lo:hi])
+            b.save(name)
+        if open('/tmp/soak_host.bin','rb').read()!=open('/tmp/soak_device.bin','rb').read():
+            print('MISMATCH device writer',count,dim,bits_used,flush=True); os._exit(1)
     rounds+=1
     if rounds%50==0: print('round %d, %d lookups, %.0f s'%(rounds,lookups,time.time()-start), flush=True)
 print('soak ok: %d rounds, %d lookups in %.0f s'%(rounds,lookups,time.time()-start))

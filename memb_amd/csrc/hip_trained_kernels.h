@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void outputUnionTile(
             const bool inside = q0 + WAVE * b < pieces;
             const uint32_t hh = inside ? half : tileWords * COUNT - 1;
             const uint32_t cc = inside ? column : piecesPerWord - 1;
-            k[b] = readKey(hh % COUNT, hh / COUNT, cc);
+            k[b] = (measureFlags(first) & 0x2000) ? 0u : readKey(hh % COUNT, hh / COUNT, cc);   // (measurement: no LDS reads)
             column += stepColumns;
             const bool carry = column >= piecesPerWord;
             column -= carry ? piecesPerWord : 0u;
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void outputUnionTile(
         for (int b = 0; b < BURST; ++b) {
             const uint32_t word = h[b] / COUNT;
             const uint32_t model = h[b] % COUNT;
-            float4 f = gather(model, k[b]);
+            float4 f = (measureFlags(first) & 0x2000) ? make_float4(1.f, 2.f, 3.f, 4.f) : gather(model, k[b]);
             if (FAST && ((absentHalves >> (h[b] & 63)) & 1)) {
                 f = zero;
             }
@@ -1300,9 +1300,11 @@ __global__ void decode_records_union_persistent(UnionParams u)
             meta.packed2 = 0;
             meta.packed3 = 0;
             recordSegmentBits(u.model[m], slots, role, meta);
-            decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
-                u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
-                waveLds + u.keyTileOffsetDwords[m], role, meta);
+            if (!(measureFlags(first) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
+                decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+                    u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
+                    waveLds + u.keyTileOffsetDwords[m], role, meta);
+            }
             absent.set(m, __ballot(!(rowCurrent < u.model[m].nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
             waveLdsFence();
 
@@ -1320,7 +1322,7 @@ __global__ void decode_records_union_persistent(UnionParams u)
             asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
             __builtin_amdgcn_sched_barrier(0);
 
-            if (m == COUNT - 1) {
+            if (m == COUNT - 1 && !(measureFlags(first) & 2)) {
                 // (the symbol tiles are read here and rewritten by the next units' decodes: same wavefront, in order)
                 outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
             }

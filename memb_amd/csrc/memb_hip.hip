@@ -869,6 +869,7 @@ int launchTrainedUnion(
         }
         p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * count * (ctx->dim / 4));
         p.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
+        p.debugFlags = first->switches.debugFlags;   // (measurement builds: the first reader's switches for all)
         params.tableOffsetDwords[m] = sharedDwords;
         sharedDwords += ctx->tableDwords;
     }

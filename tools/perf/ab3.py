@@ -128,7 +128,11 @@ def apply(reader, options):
         settings['debug'] = 0
     settings.update(options)
     for key, value in settings.items():
-        reader.set_option(key, value)
+        try:
+            reader.set_option(key, value)
+        except RuntimeError:
+            if key != 'debug' or value:   # (a package root that is not a measurement build has no such option)
+                raise
 
 
 for name, options, env, reader in variants:

@@ -23,6 +23,7 @@ struct memb_hip_encoder {
     // result of pack
     uint8_t* packed = nullptr;
     uint64_t packedBytes = 0;
+    bool broken = false;   // a device call failed half way through a block: symbols and histogram no longer agree
     std::mutex mutex;
 };
 
@@ -167,6 +168,9 @@ int encoder_add_rows_checked(memb_hip_encoder* encoder, const float* rows, size_
     if (encoder->packed) {
         return fail(MEMB_HIP_ERR_INVALID, "encoder: rows cannot be added after pack");
     }
+    if (encoder->broken) {
+        return fail(MEMB_HIP_ERR_DEVICE, "encoder: an earlier block failed on the device; the encoder cannot be used further");
+    }
     DeviceScope deviceScope(encoder->device);
     HIP_TRY(deviceScope.status());
     int code = growSymbols(encoder, encoder->rows + nRows);
@@ -186,6 +190,8 @@ int encoder_add_rows_checked(memb_hip_encoder* encoder, const float* rows, size_
     while (firstStep * 2 <= std::max<uint32_t>(encoder->splitCount, 1)) {
         firstStep *= 2;
     }
+    // (from here on a failure leaves part of the block counted: the flag is cleared when the whole block is enqueued)
+    encoder->broken = true;
     int buffer = 0;
     for (size_t start = 0; start < nRows; start += rowsPerPiece, buffer ^= 1) {
         const size_t pieceRows = std::min(rowsPerPiece, nRows - start);
@@ -222,6 +228,7 @@ int encoder_add_rows_checked(memb_hip_encoder* encoder, const float* rows, size_
         // (the kernel reads staged[buffer]; the next copy into it is enqueued on the same stream, behind the kernel)
     }
     encoder->rows += nRows;
+    encoder->broken = false;
     return MEMB_HIP_OK;
 }
 
@@ -247,6 +254,9 @@ int encoder_pack_checked(
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
     std::lock_guard<std::mutex> lock(encoder->mutex);
+    if (encoder->broken) {
+        return fail(MEMB_HIP_ERR_DEVICE, "encoder: an earlier block failed on the device; the encoder cannot be used further");
+    }
     DeviceScope deviceScope(encoder->device);
     HIP_TRY(deviceScope.status());
     uint32_t longest = 0;
@@ -286,6 +296,9 @@ int encoder_pack_checked(
                 (void)hipFree(pointer);
             }
         }
+        deviceTable = nullptr;
+        deviceLengths = nullptr;
+        deviceOffsets = nullptr;
     };
     auto check = [&](hipError_t status, const char* what) {
         if (status != hipSuccess) {

@@ -54,6 +54,7 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr uint32_t MISSING = MEMB_HIP_MISSING_ROW;
+constexpr uint64_t BIG_BATCH_RESIDENT_MULTIPLE = 16;   // batches of more tiles than this x 16 wavefronts per CU: kernel chosen by timing
 constexpr uint32_t ZERO_KEY = 255;  // codebook slot that always holds 0.0f: at most 255 centroids exist
                                     // (reference src/trained_compression.cpp:29)
 
@@ -165,7 +166,7 @@ struct memb_hip_ctx {
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
     float bigBatchMs[2] = {0.f, 0.f};      // what that timing read: persistent, one tile per wavefront (ms per launch)
-    std::atomic<int> bigBatchKernel{-1};   // batches of more than 4 tiles per resident wavefront: -1 = not timed yet,
+    std::atomic<int> bigBatchKernel{-1};   // batches of more than 16 tiles per resident wavefront: -1 = not timed yet,
                                          // 0 = the persistent pipeline, 1 = one tile per wavefront (launchTrained)
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
@@ -535,14 +536,19 @@ struct TrainedPlan {
 // Which kernel by batch size (n words), measured on one allocation per model against an A/A floor of 0.5 %
 // (profiles/r03_experiments.txt, batches 4 and 5; 2-, 4- and 6-bit models; t = tiles, R = the general persistent
 // kernel's resident wavefronts, 16 per CU):
-//   t <= R        one tile per wavefront (decode_trained: 52 VGPRs, up to 32 wavefronts per CU, nothing to pipeline):
-//                 10 000 words -17..-19 % against the persistent kernel
-//   R < t <= 4 R  decode_records_persistent (row records only; 82 VGPRs, 20 wavefronts per CU, a prologue of one hop):
-//                 100 000 words -2..-9 %, 50 000 words 0..-5 %; from 250 000 words on it is 2-4 % SLOWER
-//   above         decode_trained_persistent at 16 wavefronts per CU: every step of occupancy above that costs the
-//                 dumps 1-15 % (20 / 24 / 28 wavefronts: +3 / +4 / +13 %), every step below it more (12: up to +15 %)
+//   t <= 2 R       one tile per wavefront (decode_trained: 52 VGPRs, up to 32 wavefronts per CU, nothing to pipeline):
+//                  10 000 words -17..-19 % against the persistent kernel, 35 000-65 000 words -3..-7 % against
+//                  decode_records_persistent (batch 29)
+//   2 R < t <= 4 R decode_records_persistent (row records only; 82 VGPRs, 20 wavefronts per CU, a prologue of one hop):
+//                  80 000-130 000 words 0..-8 % against one tile per wavefront, -3..-10 % against the general kernel
+//   4 R < t <= 16 R one tile per wavefront again: 160 000-500 000 words -3..-17 % against both persistent kernels (the
+//                  outputs of these batches no longer fit the 256 MB Infinity Cache, and the hardware's dispatch
+//                  balances the wavefronts over a memory system that has become the bound)
+//   above          decode_trained_persistent at 16 wavefronts per CU (every step of occupancy above that costs the
+//                  dumps 1-15 %: 20 / 24 / 28 wavefronts +3 / +4 / +13 %, every step below it more) or one tile per
+//                  wavefront, settled per context by timing
 // (the context's device is current)
-//   The "above" class is settled per context by timing: on 2- and 6-bit models the one-tile kernel beats the
+//   The "above" class: on 2- and 6-bit models the one-tile kernel beats the
 //   persistent one by 2-14 % on every box and in every row order, on the 4-bit model it loses the key-order dump by
 //   3-6 % on four boxes of seven, wins it by 3-4 % on two, and wins shuffled rows by 2-4 % -- so the first large batch a
 //   context sees runs both on that very batch (same bits either way) and keeps the faster: ctx->bigBatchKernel.
@@ -556,19 +562,23 @@ int planTrained(
     // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
     // (long streams with few lanes per word) take the one-shot kernel.
     const uint32_t tilePieces = wordsPerWave * (ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4);
-    bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > generalResident);
-    if (ctx->switches.persistent == 1 && tiles > 4 * generalResident && ctx->bigBatchKernel.load(std::memory_order_relaxed) == 1) {
-        wantPersistent = false;
+    // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
+    // both need the tile's slot image to fit two 64-lane rounds.
+    const bool recordsKernel = ctx->recordPieces && ctx->switches.pipeline && wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
+    bool wantPersistent = ctx->switches.persistent == 2;
+    if (ctx->switches.persistent == 1) {
+        if (tiles > BIG_BATCH_RESIDENT_MULTIPLE * generalResident) {
+            wantPersistent = ctx->bigBatchKernel.load(std::memory_order_relaxed) != 1;
+        } else {
+            wantPersistent = recordsKernel && tiles > 2 * generalResident && tiles <= 4 * generalResident;
+        }
     }
     if (force >= 0) {
         wantPersistent = force != 0;
     }
     plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS && wantPersistent;
-    // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
-    // both need the tile's slot image to fit two 64-lane rounds.
     plan->pipeline = 0;
-    if (plan->persistent && ctx->recordPieces && ctx->switches.pipeline &&
-        wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE) {
+    if (plan->persistent && recordsKernel) {
         plan->pipeline = ctx->switches.pipeline == 3 ? (tiles <= 4 * generalResident ? 1u : 0u) : ctx->switches.pipeline;
     }
     const uint32_t slotSets = plan->pipeline == 2 ? 2 : 1;
@@ -676,7 +686,7 @@ int launchTrained(
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     if (force < 0 && ctx->switches.persistent == 1 && ctx->switches.autotune && !keysOut && !epilogue.accumulate &&
         epilogue.divisor == 0.f && ctx->bigBatchKernel.load(std::memory_order_relaxed) < 0 &&
-        (n + wordsPerWave - 1) / wordsPerWave > 4ull * ctx->cuCount * 16) {
+        (n + wordsPerWave - 1) / wordsPerWave > BIG_BATCH_RESIDENT_MULTIPLE * ctx->cuCount * 16) {
         hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
             (void)hipGetLastError();

@@ -193,6 +193,9 @@ def run_case(reader, case, target):
         return timeit(lambda: reader.rows_embedding_device(rows, out=target), cold)
     if kind == 'random':
         return timeit(lambda: reader.rows_embedding_device(perm, out=target), cold)
+    if kind not in batches:   # any '<N>k': N thousand random rows
+        count = int(kind[:-1]) * 1000
+        batches[kind] = perm[1000000:1000000 + count].contiguous()
     batch = batches[kind]
     view = target[:len(batch)]
     return timeit(lambda: reader.rows_embedding_device(batch, out=view), cold)

@@ -942,8 +942,9 @@ int launchTrainedUnion(
     UnionKernel kernel = nullptr;
     uint32_t registerWaves = 32;
     int numRegs = 0;
-    // fewer than two tiles per resident wavefront: the pipeline has nothing to overlap
-    if (persistent && first->switches.persistent != 2 && tiles < 2ull * first->cuCount * 16) {
+    // One tile per wavefront below 16 tiles per CU's worth of wavefronts (32 k words on 256 CUs). Measured (batch 31):
+    // 30 k words a tie, 60 k words the persistent form 14 % ahead, 100 k - 1 M words 4-7 % ahead.
+    if (persistent && first->switches.persistent != 2 && tiles < 1ull * first->cuCount * 16) {
         persistent = false;
     }
     for (int attempt = 0; attempt < 2 && !waves; ++attempt) {

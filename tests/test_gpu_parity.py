@@ -912,7 +912,7 @@ def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distri
 
 @pytest.mark.parametrize('bits_a,bits_b,seed_b', [(4, 4, 1234), (6, 8, 1234), (2, 4, 1234), (4, 4, 99), (4, 6, 99)])
 def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
-    """decode_records_union_persistent (batches of more than two tiles per resident wavefront; option 'pipeline' of the
+    """decode_records_union_persistent (batches of at least one tile per resident wavefront -- 32 k words on 256 CUs; option 'pipeline' of the
     first reader: 2 = LDS-DMA, else stream registers) and the one-tile kernel ('persistent' = 0) against numpy over the
     checker's rows: concatenation and average, words missing from either model."""
     import torch

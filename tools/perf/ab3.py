@@ -166,7 +166,7 @@ if any(c.endswith('union') for c in cases):
     second = memb_amd.Reader(second_path, device=0)
     second.info()
     rng = np.random.default_rng(17)
-    batch = 500000
+    batch = int(os.environ.get('AB3_UNION_WORDS', '500000'))
     ids = []
     for count in (n, len(second)):
         picks = rng.integers(0, count, size=batch).astype(np.uint32)

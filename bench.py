@@ -436,9 +436,9 @@ def measure_union(reader_a, path_a, reader_b, path_b, timer, library, torch, np,
     return {
         'workload': 'union-concat-glove4bit+fasttext4bit-500k (BASELINE.json configs[4])',
         'what': 'ReadersUnion concatenate, two 4-bit models, 500 000 words, 25 % of them missing per model, (n, 600) fp32 output, ' +
-                ('one launch of the fused kernel (decode_records_union_persistent: row records, batches of more than two tiles per resident wavefront)' if one_launch else 'one launch per reader (key formats differ)'),
+                ('one launch of the fused kernel (named in `kernel`, as the library reports it)' if one_launch else 'one launch per reader (key formats differ)'),
         'batch': batch,
-        'kernel': 'decode_records_union_persistent' if one_launch else 'decode_trained x 2',
+        'kernel': (reader_a.info().get('union_kernel') or 'fused union kernel') if one_launch else 'decode_trained x 2',
         'kernel_ms': median,
         'kernel_min_ms': ms[0],
         'embeddings_per_s': batch / (median * 1e-3),
@@ -578,7 +578,8 @@ def special_workload(name, args, memb_amd, synthetic, library, torch, np, glove,
     return {
         'step': step, 'out': merged, 'n': batch,
         'nbytes': algorithmic_bytes(library, reader_a, rows_a) + algorithmic_bytes(library, reader_b, rows_b) - 4 * batch,
-        'kernel': 'decode_records_union_persistent', 'info': info, 'keep': (reader_a, reader_b, ids), 'parity': parity,
+        'kernel': 'decode_union_split', 'kernel_of': lambda: reader_a.info().get('union_kernel') or 'decode_union_split',
+        'info': info, 'keep': (reader_a, reader_b, ids), 'parity': parity,
         'config': {'vocabulary': [len(reader_a), len(reader_b)], 'dim': reader_a.dim + reader_b.dim, 'storage': 'trained + trained',
                    'bits_per_weight': 4, 'batch': '500 000 random words, 25 % missing per model, ReadersUnion concatenate in one launch'},
         'build_seconds': build_seconds,
@@ -927,7 +928,7 @@ def main():
             'frac': achieved_gbps / HBM_PEAK_GBPS,
             'traffic': traffic,
             'traffic_source': traffic_source,
-            'kernel': special['kernel'] if special else info.get('kernel', 'decode_trained_persistent'),
+            'kernel': (special['kernel_of']() if 'kernel_of' in special else special['kernel']) if special else info.get('kernel', 'decode_trained_persistent'),
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_timing': kernel_timing,
             'large_batch_timing': None if info.get('large_batch_kernel', -1) < 0 else {

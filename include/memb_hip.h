@@ -142,6 +142,8 @@ typedef struct memb_hip_ctx_info {
     int32_t large_batch_kernel;  /* trained: -1 = not timed yet, 0 = the persistent pipeline, 1 = one tile per wavefront ("autotune") */
     float large_batch_persistent_ms;   /* ... and what the timing read, per launch */
     float large_batch_one_tile_ms;
+    char union_kernel[96];       /* the kernel the last memb_hip_decode_rows_union_device call with this context as its FIRST
+                                    model launched ("" = none yet, or the call returned MEMB_HIP_UNSUPPORTED) */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);
@@ -170,6 +172,8 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
  *                     that make the same number of rounds (equal tiles per wavefront)
  *   "persistent"      0 = one tile per wavefront always, 1 = by batch size (default), 2 = the persistent pipeline always
+ *   "union_split"     1 (default) = a union of two nibble-key models whose row records have one size runs decode_union_split
+ *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
  *   "autotune"        1 (default): with "persistent" = 1, the first batch of more than 16 tiles per resident wavefront (524 288 words on 256 CUs) a context
  *                     sees is decoded by both kernels in turn, 17 launches each (~20 ms), on the caller's stream, and the faster one serves
  *                     large batches from then on (that one call waits for the device; results are the same bits);

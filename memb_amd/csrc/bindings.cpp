@@ -118,6 +118,7 @@ py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
     result["large_batch_kernel"] = info.large_batch_kernel;
     result["large_batch_persistent_ms"] = info.large_batch_persistent_ms;
     result["large_batch_one_tile_ms"] = info.large_batch_one_tile_ms;
+    result["union_kernel"] = std::string(info.union_kernel);
     return result;
 }
 

@@ -298,7 +298,7 @@ __device__ __forceinline__ void recordSegmentBits(
 template <bool HAS_SUB, int MODE, bool FAST, bool PACKED = false>
 __device__ __forceinline__ void decodeSegment(
     const TrainedParams& p, const TableEntry* tableLds, const uint32_t* slots, uint32_t* keyTile,
-    const LaneRole& role, const WordMeta& meta)
+    const LaneRole& role, const WordMeta& meta, uint32_t rootBits = 0)   // rootBits: of the lane's table when lanes differ
 {
     static_assert(!(FAST && PACKED), "nibble keys use the 8-byte table");
     constexpr int GROUP = FAST ? 8 : 4;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void decodeSegment(
     const uint32_t* slot = slots + role.word * p.slotDwords;
     uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
     uint32_t lastWindow = p.slotDwords - 3;
-    const uint32_t rootShift = 32 - p.rootBits;
+    const uint32_t rootShift = 32 - (rootBits ? rootBits : p.rootBits);
     uint32_t bitPos = meta.segmentBits;   // streams start on a slot boundary
     if (p.recordPieces) {
         // row records: the slot begins with the row's record (read by recordSegmentBits), the bitstream follows it
@@ -1234,6 +1234,84 @@ __global__ void decode_trained_union(UnionParams u)
     }
     waveLdsFence();
     outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+}
+
+// Two nibble-key models staged as row records of one size: the wavefront's lanes are SPLIT between the models -- the
+// lower half of its word slots decodes the tile's words for model 0, the upper half the same words for model 1, in ONE
+// pass of the decoder -- so a tile is wordsPerWave / 2 words, its LDS footprint that of the single-model kernel
+// (decode_trained_union needs slots and a symbol tile per model, which caps it at 20 wavefronts per CU), and the chain
+// of a wavefront is row ids -> regions -> one decode -> merged rows, as short as the single-model one-tile kernel's.
+// u.model[2] = model 0's geometry with nRows = 2^32 - 1 (rows are checked per lane against the lane's model here and
+// arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
+template <bool AVERAGE>
+__global__ void decode_union_split(UnionParams u)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const TrainedParams& both = u.model[2];
+    setUpUnionLds<2>(u, lds);
+
+    const uint32_t half = both.wordsPerWave / 2;   // words of a tile
+    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    const unsigned long long tileBase = tile * half;
+    if (tileBase >= both.n) {
+        return;
+    }
+    const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(half), both.n - tileBase));
+    const LaneRole role = laneRole(both, lane);
+    const bool upper = role.word >= half;           // the lane's model
+    const uint32_t word = role.word - (upper ? half : 0u);
+    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
+    uint32_t* slots = waveLds + u.slotOffsetDwords[0];
+
+    uint32_t row = MISSING;
+    if (!role.spare && word < tileWords) {
+        const uint32_t* ids = upper ? u.model[1].rows : u.model[0].rows;
+        const unsigned long long index = tileBase + word;
+        row = ids ? ids[index] : static_cast<uint32_t>(index);
+        row = row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
+    }
+    // the regions of all eight (word, model) pairs: piece q of the slot image belongs to word slot q / loadPieces
+    const uint32_t start = row != MISSING ? row * both.recordPieces : 0u;   // absent words read row 0 and never emit it
+    const uint32_t totalPieces = both.wordsPerWave * both.loadPieces;
+    u32x4 pieces[RECORD_ROUNDS];
+#pragma unroll
+    for (int round = 0; round < RECORD_ROUNDS; ++round) {
+        pieces[round] = u32x4{0, 0, 0, 0};
+        // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
+        const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
+        const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
+        const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
+        if (static_cast<uint32_t>(round) * WAVE < totalPieces) {
+            const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
+            pieces[round] = loadPiece<ONE_TILE_NT_LOADS>(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
+        }
+    }
+#pragma unroll
+    for (int round = 0; round < RECORD_ROUNDS; ++round) {
+        writeStream(both, slots, lane, round, pieces[round]);
+    }
+    waveLdsFence();
+
+    WordMeta meta;
+    meta.row = row;
+    meta.start = 0;
+    meta.packed2 = 0;
+    meta.packed3 = 0;
+    recordSegmentBits(both, slots, role, meta);
+    const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
+    decodeSegment<false, OUT_VEC4, true>(
+        both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
+        upper ? u.model[1].rootBits : u.model[0].rootBits);
+    // per model, bit (word * lanesPerWord): the model lacks the tile's word
+    const unsigned long long lacking = __ballot(row == MISSING && !role.spare && role.segment == 0 && word < tileWords);
+    AbsentMasks absent;
+    const uint32_t upperShift = half * both.lanesPerWord;   // 32 with eight lanes per word
+    absent.set(0, upperShift < 64 ? lacking & ((1ull << upperShift) - 1) : lacking);
+    absent.set(1, upperShift < 64 ? lacking >> upperShift : 0ull);
+    waveLdsFence();
+    outputUnionTile<true, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
 // The persistent form, for models staged as row records (the pipeline of decode_records_persistent, see

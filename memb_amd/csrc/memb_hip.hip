@@ -114,6 +114,8 @@ struct Switches {
     uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
     uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 0 = one tile per wavefront always, 1 = by batch size (one tile per
                                    // wavefront while every tile finds a free wavefront slot), 2 = the persistent pipeline always
+    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of nibble-key models with equal row
+                                   // records: 0 = never, 1 = whenever the pair qualifies (every batch size: batch 32)
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
     uint32_t pipeline = 3;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
@@ -165,6 +167,7 @@ struct memb_hip_ctx {
     bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
+    char unionKernel[96] = {0};            // what the last union launch with this context as its first model ran
     float bigBatchMs[2] = {0.f, 0.f};      // what that timing read: persistent, one tile per wavefront (ms per launch)
     std::atomic<int> bigBatchKernel{-1};   // batches of more than 16 tiles per resident wavefront: -1 = not timed yet,
                                          // 0 = the persistent pipeline, 1 = one tile per wavefront (launchTrained)
@@ -942,6 +945,50 @@ int launchTrainedUnion(
     UnionKernel kernel = nullptr;
     uint32_t registerWaves = 32;
     int numRegs = 0;
+
+    // decode_union_split: two nibble-key models whose row records have one size -- the wavefront's word slots are
+    // divided between the models, a tile is half as many words, LDS per wavefront as in the single-model kernel.
+    // Against the forms below (batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
+    bool split = count == 2 && allFast && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
+        ((wordsPerWave / 2) * params.model[0].keyRowBytes) % 4 == 0;
+    for (size_t m = 0; m < count && split; ++m) {
+        split = ctxs[m]->recordPieces && ctxs[m]->recordPieces == first->recordPieces && ctxs[m]->slotDwords == first->slotDwords &&
+            wordsPerWave * (ctxs[m]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
+    }
+    if (split) {
+        const uint32_t half = wordsPerWave / 2;
+        params.model[2] = params.model[0];
+        params.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
+        params.slotOffsetDwords[0] = 0;
+        params.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * first->slotDwords);
+        params.keyTileOffsetDwords[1] = params.keyTileOffsetDwords[0] + half * params.model[0].keyRowBytes / 4;
+        params.perWaveDwords = params.keyTileOffsetDwords[0] + roundUp4(params.model[0].keyTileDwords);
+        kernel = average ? &decode_union_split<true> : &decode_union_split<false>;
+        hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
+        if (status != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
+        }
+        chooseWaves(registerWaves, &waves, &ldsBytes);
+        if (waves) {
+            const size_t splitTiles = (n + half - 1) / half;
+            {
+                std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
+                KernelFacts* facts = nullptr;
+                status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
+            }
+            if (status == hipSuccess) {
+                hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((splitTiles + waves - 1) / waves)), dim3(waves * WAVE), ldsBytes, stream, params);
+                status = hipGetLastError();
+            }
+            if (status != hipSuccess) {
+                return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_union_split launch: ") + hipGetErrorString(status));
+            }
+            std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_union_split<%s>", average ? "true" : "false");
+            return MEMB_HIP_OK;
+        }
+        // (does not fit: the forms below lay their areas out afresh)
+        registerWaves = 32;
+    }
     // One tile per wavefront below 16 tiles per CU's worth of wavefronts (32 k words on 256 CUs). Measured (batch 31):
     // 30 k words a tie, 60 k words the persistent form 14 % ahead, 100 k - 1 M words 4-7 % ahead.
     if (persistent && first->switches.persistent != 2 && tiles < 1ull * first->cuCount * 16) {
@@ -986,6 +1033,9 @@ int launchTrainedUnion(
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
     }
+    std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "%s<%s, %s, %zu, %s%s>",
+                  persistent ? "decode_records_union_persistent" : "decode_trained_union", hasSub ? "true" : "false",
+                  allFast ? "true" : "false", count, average ? "true" : "false", persistent ? (dma ? ", true" : ", false") : "");
     return MEMB_HIP_OK;
 }
 
@@ -1282,6 +1332,7 @@ Switches readSwitches()
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
 #endif
     switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
+    switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
     switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
     switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
     switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
@@ -1979,6 +2030,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         }
     } else if (key == "tiles_per_wave" && value <= 65536) {
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
+    } else if (key == "union_split" && value <= 1) {
+        ctx->switches.unionSplit = static_cast<uint32_t>(value);
     } else if (key == "pipeline" && value <= 3) {
         ctx->switches.pipeline = static_cast<uint32_t>(value);
     } else if (key == "grid_policy" && value <= 1) {
@@ -2027,6 +2080,7 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         info->large_batch_kernel = ctx->bigBatchKernel.load(std::memory_order_relaxed);
         info->large_batch_persistent_ms = ctx->bigBatchMs[0];
         info->large_batch_one_tile_ms = ctx->bigBatchMs[1];
+        std::snprintf(info->union_kernel, sizeof(info->union_kernel), "%s", ctx->unionKernel);
         info->kernel_registers = static_cast<uint32_t>(plan.numRegs);
         info->register_waves_per_cu = plan.persistent ? plan.registerWavesPerCu : 0;
         info->lanes_per_word = ctx->lanesPerWord;

@@ -936,17 +936,31 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
     expected = [checker.rows_embedding(picks) for checker, picks in zip(checkers, rows)]
     ids = [torch.from_numpy(picks.view(np.int32)).cuda() for picks in rows]
     stream = torch.cuda.current_stream().cuda_stream
-    for persistent, pipeline in ((1, 3), (2, 1), (2, 2), (0, 0)):
+    # union_split: decode_union_split (two nibble-key models with row records of one size: the wavefront's word slots
+    # divided between the models) -- 1 = whenever the pair qualifies (others fall through to the forms below), 0 = never
+    for persistent, pipeline, split in ((1, 3, 1), (2, 1, 0), (2, 2, 0), (0, 0, 0), (1, 3, 0)):
         readers[0].set_option('persistent', persistent)
         readers[0].set_option('pipeline', pipeline)
+        readers[0].set_option('union_split', split)
         merged = torch.full((batch, 600), 3.0, dtype=torch.float32, device='cuda')
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 300], batch,
                                           merged.data_ptr(), 600, stream, False)
-        assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline)
+        assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline, split)
         mean = torch.full((batch, 300), 3.0, dtype=torch.float32, device='cuda')
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 0], batch,
                                           mean.data_ptr(), 300, stream, True)
-        assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (persistent, pipeline)
+        assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (persistent, pipeline, split)
+    # small and ragged batches through the split kernel (a tile is four words there)
+    readers[0].set_option('union_split', 1)
+    for small in (1, 3, 4, 5, 517):
+        merged = torch.full((small, 640), 3.0, dtype=torch.float32, device='cuda')
+        assert _memb.union_rows_to_device([r._impl for r in readers], [t[:small].contiguous().data_ptr() for t in ids], [320, 0], small,
+                                          merged.data_ptr(), 640, stream, False)
+        got = merged.cpu().numpy()
+        assert bits_equal(np.ascontiguousarray(got[:, 320:620]), expected[0][:small]), small
+        assert bits_equal(np.ascontiguousarray(got[:, 0:300]), expected[1][:small]), small
+        assert (got[:, 300:320] == 3.0).all() and (got[:, 620:] == 3.0).all()
+    readers[0].set_option('union_split', 1)
 
 
 def test_uniform_persistent_pipeline(native, make_model):

@@ -36,7 +36,7 @@ run_in_ms = float(os.environ.get('AB3_RUN_IN_MS', '20'))
 cases = os.environ.get('AB3_CASES', 'sorted,random,100k').split(',')
 placement = int(os.environ.get('AB3_PLACEMENT', '0'))
 out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
-DEFAULTS = {'tiles_per_wave': 0, 'nt_loads': int(os.environ.get('MEMB_HIP_NT_LOADS', '0')), 'waves_per_block': 0, 'blocks_per_cu': 0,
+DEFAULTS = {'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': 0, 'nt_loads': int(os.environ.get('MEMB_HIP_NT_LOADS', '0')), 'waves_per_block': 0, 'blocks_per_cu': 0,
             'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1')), 'pipeline': int(os.environ.get('MEMB_HIP_PIPELINE', '3')), 'grid_policy': int(os.environ.get('MEMB_HIP_GRID_POLICY', '0'))}
 
 print('package: %s   model: %d words, %d-bit   rounds %d x %d launches after %.0f ms run-in' % (

@@ -51,12 +51,17 @@ void copyRows(float* destination, size_t ld, const float* source, size_t dim, si
 // `fast`, per nibble, low nibble first) -> fp32 rows. The values are copies of the file's
 // centroids, exactly what the device-side gather stores; rows whose id is not in the file
 // become zeros (reference src/reader.cpp:41-47).
+// streaming: results far larger than the caches are written with non-temporal stores -- a plain store first reads the
+// line it is about to overwrite, and this loop is bound by the host's memory traffic (2.6 GB of rows + as much again read
+// for ownership on the 2.2 M-word dump).
 void expandKeyRows(
     const memb_hip_ctx* ctx, const uint8_t* keys, size_t keyRowBytes, const uint32_t* rows, float* destination, size_t ld,
-    size_t first, size_t last)
+    size_t first, size_t last, bool streaming = false)
 {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const size_t dim = ctx->dim;
     const float* codebook = ctx->hostCodebook.data();
+    streaming = streaming && dim % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(destination) % 16 == 0;
     for (size_t i = first; i < last; ++i) {
         float* out = destination + i * ld;
         if (rows[i] >= ctx->nRows) {
@@ -64,6 +69,20 @@ void expandKeyRows(
             continue;
         }
         const uint8_t* source = keys + i * keyRowBytes;
+        if (streaming) {
+            for (size_t k = 0; k < dim; k += 4) {
+                f32x4 value;
+                if (ctx->fast) {   // one byte = two weights = one pair of the 256-pair table
+                    const float* lo = codebook + 2 * size_t(source[k / 2]);
+                    const float* hi = codebook + 2 * size_t(source[k / 2 + 1]);
+                    value = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else {
+                    value = f32x4{codebook[source[k]], codebook[source[k + 1]], codebook[source[k + 2]], codebook[source[k + 3]]};
+                }
+                __builtin_nontemporal_store(value, reinterpret_cast<f32x4*>(out + k));
+            }
+            continue;
+        }
         if (ctx->fast) {
             const size_t pairs = dim / 2;
             for (size_t k = 0; k < pairs; ++k) {
@@ -78,6 +97,11 @@ void expandKeyRows(
             }
         }
     }
+#if defined(__x86_64__)
+    if (streaming) {
+        asm volatile("sfence" ::: "memory");   // the non-temporal stores are visible before the thread reports its share done
+    }
+#endif
 }
 
 // Device rows of `rowBytes` each -> the caller's host rows, through the pinned ring.
@@ -235,6 +259,8 @@ int decodeRowsAsKeys(
     float* destination, size_t ld)
 {
     const size_t rowBytes = keyRowBytes(ctx);
+    const bool streaming = ctx->switches.hostStreaming == 2 ||
+        (ctx->switches.hostStreaming == 1 && words * ctx->dim * sizeof(float) >= (size_t(64) << 20));
     int code = launchTrained(
         ctx, deviceRowIds, words, reinterpret_cast<float*>(deviceKeys), ctx->dim, 0, ctx->stream, Epilogue(), true);
     if (code != MEMB_HIP_OK) {
@@ -245,6 +271,6 @@ int decodeRowsAsKeys(
         [=](const void* chunk, size_t chunkFirst, size_t first, size_t last) {
             expandKeyRows(
                 ctx, static_cast<const uint8_t*>(chunk), rowBytes, hostRowIds + chunkFirst, destination + chunkFirst * ld,
-                ld, first, last);
+                ld, first, last, streaming);
         });
 }

@@ -130,6 +130,8 @@ struct Switches {
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
+    uint32_t hostStreaming = 1;    // MEMB_HIP_HOST_STREAMING: non-temporal stores when host threads expand results: 0 = never,
+                                   // 1 = results of 64 MB and more (default), 2 = always (tests)
     uint32_t copyThreads = 16;     // MEMB_HIP_COPY_THREADS
     bool verbose = false;          // MEMB_HIP_VERBOSE
 };
@@ -1345,6 +1347,7 @@ Switches readSwitches()
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
     switches.copyThreads = std::min<uint32_t>(envUint("MEMB_HIP_COPY_THREADS", 16), 64);
+    switches.hostStreaming = std::min<uint32_t>(envUint("MEMB_HIP_HOST_STREAMING", 1), 2);
     switches.verbose = envUint("MEMB_HIP_VERBOSE", 0) != 0;
     return switches;
 }

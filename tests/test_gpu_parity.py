@@ -872,6 +872,29 @@ def test_concurrent_callers(native, make_model):
     assert not failures
 
 
+@pytest.mark.parametrize('bits', [4, 6])
+def test_host_results_written_with_non_temporal_stores(native, make_model, monkeypatch, bits):
+    """Host buffers: the host threads that expand centroid indices into fp32 rows use non-temporal stores for results of
+    64 MB and more (MEMB_HIP_HOST_STREAMING=2: always) when every row is 16-byte aligned, plain stores otherwise --
+    the same bits either way, missing rows zero (reference src/reader.cpp:41-47)."""
+    path, words = make_model(6000, 300, 'trained', bits)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(bits)
+    rows = rng.integers(0, len(words), size=9001).astype(np.uint32)
+    rows[::37] = 0xFFFFFFFF
+    expected = checker.rows_embedding(rows)
+    for mode in ('2', '0'):
+        monkeypatch.setenv('MEMB_HIP_HOST_STREAMING', mode)
+        reader = native.Reader(path, device=0)
+        assert bits_equal(reader.rows_embedding(rows), expected), mode
+        wide = np.full((len(rows), 304), 7.0, dtype=np.float32)      # aligned rows inside a wider buffer
+        reader.rows_embedding_into(rows, wide, 4)
+        assert bits_equal(np.ascontiguousarray(wide[:, 4:]), expected) and (wide[:, :4] == 7.0).all(), mode
+        odd = np.full((len(rows), 301), 7.0, dtype=np.float32)       # rows that are not 16-byte aligned: plain stores
+        reader.rows_embedding_into(rows, odd, 1)
+        assert bits_equal(np.ascontiguousarray(odd[:, 1:]), expected) and (odd[:, 0] == 7.0).all(), mode
+
+
 @pytest.mark.parametrize('bits,distribution', [(4, 'normal'), (2, 'normal'), (6, 'student'), (8, 'student')])
 def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distribution):
     """decode_records_persistent (option 'pipeline': 1 = stream registers, 2 = LDS-DMA) against the general

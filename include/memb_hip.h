@@ -172,7 +172,7 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
  *                     that make the same number of rounds (equal tiles per wavefront)
  *   "persistent"      0 = one tile per wavefront always, 1 = by batch size (default), 2 = the persistent pipeline always
- *   "union_split"     1 (default) = a union of two nibble-key models whose row records have one size runs decode_union_split
+ *   "union_split"     1 (default) = a union of two nibble-key models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
  *   "autotune"        1 (default): with "persistent" = 1, the first batch of more than 16 tiles per resident wavefront (524 288 words on 256 CUs) a context
  *                     sees is decoded by both kernels in turn, 17 launches each (~20 ms), on the caller's stream, and the faster one serves

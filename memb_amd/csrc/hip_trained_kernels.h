@@ -1236,13 +1236,13 @@ __global__ void decode_trained_union(UnionParams u)
     outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
-// Two nibble-key models staged as row records of one size: the wavefront's lanes are SPLIT between the models -- the
+// Two nibble-key models staged as row records: the wavefront's lanes are SPLIT between the models -- the
 // lower half of its word slots decodes the tile's words for model 0, the upper half the same words for model 1, in ONE
 // pass of the decoder -- so a tile is wordsPerWave / 2 words, its LDS footprint that of the single-model kernel
 // (decode_trained_union needs slots and a symbol tile per model, which caps it at 20 wavefronts per CU), and the chain
 // of a wavefront is row ids -> regions -> one decode -> merged rows, as short as the single-model one-tile kernel's.
-// u.model[2] = model 0's geometry with nRows = 2^32 - 1 (rows are checked per lane against the lane's model here and
-// arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
+// u.model[2] = the slot geometry of the model with the larger row regions, with nRows = 2^32 - 1 (rows are checked per
+// lane against the lane's model here and arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
 template <bool AVERAGE>
 __global__ void decode_union_split(UnionParams u)
 {
@@ -1273,7 +1273,9 @@ __global__ void decode_union_split(UnionParams u)
         row = row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
     }
     // the regions of all eight (word, model) pairs: piece q of the slot image belongs to word slot q / loadPieces
-    const uint32_t start = row != MISSING ? row * both.recordPieces : 0u;   // absent words read row 0 and never emit it
+    // (regions of the lane's model; when the models' regions differ in size, `both` has the larger slot geometry and the
+    // smaller model's slots take a few pieces of the following row along, as every compact-layout load does)
+    const uint32_t start = row != MISSING ? row * (upper ? u.model[1].recordPieces : u.model[0].recordPieces) : 0u;   // absent words read row 0 and never emit it
     const uint32_t totalPieces = both.wordsPerWave * both.loadPieces;
     u32x4 pieces[RECORD_ROUNDS];
 #pragma unroll

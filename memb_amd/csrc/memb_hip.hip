@@ -114,7 +114,7 @@ struct Switches {
     uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
     uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 0 = one tile per wavefront always, 1 = by batch size (one tile per
                                    // wavefront while every tile finds a free wavefront slot), 2 = the persistent pipeline always
-    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of nibble-key models with equal row
+    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of nibble-key models with row
                                    // records: 0 = never, 1 = whenever the pair qualifies (every batch size: batch 32)
     bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
     uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
@@ -955,16 +955,20 @@ int launchTrainedUnion(
     // Against the forms below (batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
     bool split = count == 2 && allFast && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
         ((wordsPerWave / 2) * params.model[0].keyRowBytes) % 4 == 0;
+    // the slots take the geometry of the model with the larger row regions; the other model's loads then run up to as
+    // many pieces into the rows behind its own (its array ends with a guard of more than one region)
+    const size_t larger = count == 2 && ctxs[1]->slotDwords > ctxs[0]->slotDwords ? 1 : 0;
     for (size_t m = 0; m < count && split; ++m) {
-        split = ctxs[m]->recordPieces && ctxs[m]->recordPieces == first->recordPieces && ctxs[m]->slotDwords == first->slotDwords &&
-            wordsPerWave * (ctxs[m]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
+        split = ctxs[m]->recordPieces && ctxs[m]->recordPieces <= ctxs[larger]->recordPieces &&
+            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces &&
+            wordsPerWave * (ctxs[larger]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     }
     if (split) {
         const uint32_t half = wordsPerWave / 2;
-        params.model[2] = params.model[0];
+        params.model[2] = params.model[larger];
         params.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
         params.slotOffsetDwords[0] = 0;
-        params.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * first->slotDwords);
+        params.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * ctxs[larger]->slotDwords);
         params.keyTileOffsetDwords[1] = params.keyTileOffsetDwords[0] + half * params.model[0].keyRowBytes / 4;
         params.perWaveDwords = params.keyTileOffsetDwords[0] + roundUp4(params.model[0].keyTileDwords);
         kernel = average ? &decode_union_split<true> : &decode_union_split<false>;

@@ -969,6 +969,13 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 300], batch,
                                           merged.data_ptr(), 600, stream, False)
         assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline, split)
+        ran = readers[0].info()['union_kernel']   # what that launch was
+        if split and max(bits_a, bits_b) <= 4 and seed_b == 1234:
+            assert ran.startswith('decode_union_split<false>'), ran           # also with regions of different sizes (2-bit + 4-bit)
+        elif persistent == 0:
+            assert ran.startswith('decode_trained_union<'), ran
+        elif max(bits_a, bits_b) <= 6:
+            assert ran.startswith('decode_records_union_persistent<'), ran     # (the 8-bit model has no row records)
         mean = torch.full((batch, 300), 3.0, dtype=torch.float32, device='cuda')
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 0], batch,
                                           mean.data_ptr(), 300, stream, True)

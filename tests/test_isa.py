@@ -59,3 +59,12 @@ def test_shipped_library_has_no_measurement_switches(kernels):
 def test_no_kernel_spills(kernels):
     spilled = {name: facts['private_segment'] for name, facts in kernels.items() if facts['private_segment']}
     assert not spilled, spilled
+
+
+def test_kernels_that_live_on_occupancy_keep_their_registers(kernels):
+    # one tile per wavefront: these kernels hide their chain of loads behind other wavefronts, eight per SIMD
+    # (<= 64 VGPRs; MI355X_MICROARCH.md, register files) -- a rewrite that costs registers costs them that
+    import isa
+    for name, facts in kernels.items():
+        if 'decode_union_split<' in name or ('decode_trained<' in name and ', 2, true>' in name):
+            assert isa.waves_per_simd(facts['vgpr']) == 8, (name, facts['vgpr'])

@@ -45,6 +45,7 @@ while time.time()-start < seconds:
         a=memb_amd.Reader(models[0][0]); b=memb_amd.Reader(models[1][0])
         pool=models[0][1][:2000]+models[1][1][:2000]
         if rng.random()<0.5: a.set_option('pipeline', int(rng.integers(0,4)))
+        a.set_option('union_split', int(rng.integers(0,2))); a.set_option('persistent', int(rng.integers(0,3)))
         batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000,90000])))]
         for mode in ('concatenate','average'):
             u=memb_amd.ReadersUnion([a,b],mode)

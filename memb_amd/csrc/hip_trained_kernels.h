@@ -1236,14 +1236,15 @@ __global__ void decode_trained_union(UnionParams u)
     outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
-// Two nibble-key models staged as row records: the wavefront's lanes are SPLIT between the models -- the
+// Two models of one key format staged as row records: the wavefront's lanes are SPLIT between the models -- the
 // lower half of its word slots decodes the tile's words for model 0, the upper half the same words for model 1, in ONE
 // pass of the decoder -- so a tile is wordsPerWave / 2 words, its LDS footprint that of the single-model kernel
 // (decode_trained_union needs slots and a symbol tile per model, which caps it at 20 wavefronts per CU), and the chain
 // of a wavefront is row ids -> regions -> one decode -> merged rows, as short as the single-model one-tile kernel's.
 // u.model[2] = the slot geometry of the model with the larger row regions, with nRows = 2^32 - 1 (rows are checked per
 // lane against the lane's model here and arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
-template <bool AVERAGE>
+// FAST: nibble keys (8-byte table entries); else byte keys for both models, decoded through their 4-byte PACKED tables.
+template <bool HAS_SUB, bool FAST, bool AVERAGE>
 __global__ void decode_union_split(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1303,7 +1304,7 @@ __global__ void decode_union_split(UnionParams u)
     meta.packed3 = 0;
     recordSegmentBits(both, slots, role, meta);
     const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
-    decodeSegment<false, OUT_VEC4, true>(
+    decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
         both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
         upper ? u.model[1].rootBits : u.model[0].rootBits);
     // per model, bit (word * lanesPerWord): the model lacks the tile's word
@@ -1313,7 +1314,7 @@ __global__ void decode_union_split(UnionParams u)
     absent.set(0, upperShift < 64 ? lacking & ((1ull << upperShift) - 1) : lacking);
     absent.set(1, upperShift < 64 ? lacking >> upperShift : 0ull);
     waveLdsFence();
-    outputUnionTile<true, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+    outputUnionTile<FAST, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
 // The persistent form, for models staged as row records (the pipeline of decode_records_persistent, see

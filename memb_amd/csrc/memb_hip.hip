@@ -924,14 +924,14 @@ int launchTrainedUnion(
 
     // waves per block: most resident wavefronts per CU -- by LDS and by the kernel's registers --, blocks of
     // four on ties (as chooseGeometry)
-    auto chooseWaves = [&](uint32_t registerWaves, uint32_t* waves, uint32_t* ldsBytes) {
+    auto chooseWaves = [&](uint32_t sharedDwords, uint32_t perWaveDwords, uint32_t registerWaves, uint32_t* waves, uint32_t* ldsBytes) {
         double bestResident = -1;
         *waves = 0;
         for (uint32_t candidate : {4u, 8u, 2u, 1u}) {
             if (first->switches.waves && candidate != first->switches.waves) {
                 continue;
             }
-            const uint32_t bytes = 4u * (sharedDwords + candidate * params.perWaveDwords);
+            const uint32_t bytes = 4u * (sharedDwords + candidate * perWaveDwords);
             if (bytes > first->ldsLimit) {
                 continue;
             }
@@ -950,33 +950,54 @@ int launchTrainedUnion(
     uint32_t registerWaves = 32;
     int numRegs = 0;
 
-    // decode_union_split: two nibble-key models whose row records have one size -- the wavefront's word slots are
-    // divided between the models, a tile is half as many words, LDS per wavefront as in the single-model kernel.
-    // Against the forms below (batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
-    bool split = count == 2 && allFast && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
+    // decode_union_split: two models of one key format staged as row records -- the wavefront's word slots are divided
+    // between the models, a tile is half as many words, LDS per wavefront as in the single-model kernel.
+    // Against the forms below (nibble keys, batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
+    const bool noneFast = !ctxs[0]->fast && (count < 2 || !ctxs[1]->fast);
+    bool split = count == 2 && (allFast || noneFast) && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
         ((wordsPerWave / 2) * params.model[0].keyRowBytes) % 4 == 0;
     // the slots take the geometry of the model with the larger row regions; the other model's loads then run up to as
     // many pieces into the rows behind its own (its array ends with a guard of more than one region)
     const size_t larger = count == 2 && ctxs[1]->slotDwords > ctxs[0]->slotDwords ? 1 : 0;
     for (size_t m = 0; m < count && split; ++m) {
         split = ctxs[m]->recordPieces && ctxs[m]->recordPieces <= ctxs[larger]->recordPieces &&
-            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces &&
+            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces && (ctxs[m]->fast || ctxs[m]->table32) &&
             wordsPerWave * (ctxs[larger]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     }
     if (split) {
+        UnionParams sp = params;
+        uint32_t shared = sharedDwords;
+        bool packedSub = false;
+        if (noneFast) {
+            // byte keys: the single-model kernels' 4-byte table entries (decodeSegment<..., PACKED>)
+            shared = 0;
+            for (size_t m = 0; m < count; ++m) {
+                sp.model[m].table = ctxs[m]->table32;
+                sp.model[m].tableDwords = packedTableDwords(ctxs[m]);
+                sp.model[m].rootBits = ctxs[m]->byteTable.rootBits;
+                sp.tableOffsetDwords[m] = shared;
+                shared += sp.model[m].tableDwords;
+                packedSub = packedSub || ctxs[m]->byteTable.hasSubTables;
+            }
+            sp.codebookOffsetDwords = shared;
+            shared += static_cast<uint32_t>(count) * 512;
+            sp.sharedDwords = shared;
+        }
         const uint32_t half = wordsPerWave / 2;
-        params.model[2] = params.model[larger];
-        params.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
-        params.slotOffsetDwords[0] = 0;
-        params.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * ctxs[larger]->slotDwords);
-        params.keyTileOffsetDwords[1] = params.keyTileOffsetDwords[0] + half * params.model[0].keyRowBytes / 4;
-        params.perWaveDwords = params.keyTileOffsetDwords[0] + roundUp4(params.model[0].keyTileDwords);
-        kernel = average ? &decode_union_split<true> : &decode_union_split<false>;
+        sp.model[2] = sp.model[larger];
+        sp.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
+        sp.slotOffsetDwords[0] = 0;
+        sp.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * ctxs[larger]->slotDwords);
+        sp.keyTileOffsetDwords[1] = sp.keyTileOffsetDwords[0] + half * sp.model[0].keyRowBytes / 4;
+        sp.perWaveDwords = sp.keyTileOffsetDwords[0] + roundUp4(sp.model[0].keyTileDwords);
+        kernel = allFast ? (average ? &decode_union_split<false, true, true> : &decode_union_split<false, true, false>)
+            : packedSub ? (average ? &decode_union_split<true, false, true> : &decode_union_split<true, false, false>)
+                        : (average ? &decode_union_split<false, false, true> : &decode_union_split<false, false, false>);
         hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
         if (status != hipSuccess) {
             return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
         }
-        chooseWaves(registerWaves, &waves, &ldsBytes);
+        chooseWaves(shared, sp.perWaveDwords, registerWaves, &waves, &ldsBytes);
         if (waves) {
             const size_t splitTiles = (n + half - 1) / half;
             {
@@ -985,13 +1006,14 @@ int launchTrainedUnion(
                 status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
             }
             if (status == hipSuccess) {
-                hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((splitTiles + waves - 1) / waves)), dim3(waves * WAVE), ldsBytes, stream, params);
+                hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((splitTiles + waves - 1) / waves)), dim3(waves * WAVE), ldsBytes, stream, sp);
                 status = hipGetLastError();
             }
             if (status != hipSuccess) {
                 return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_union_split launch: ") + hipGetErrorString(status));
             }
-            std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_union_split<%s>", average ? "true" : "false");
+            std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_union_split<%s, %s, %s>",
+                          packedSub ? "true" : "false", allFast ? "true" : "false", average ? "true" : "false");
             return MEMB_HIP_OK;
         }
         // (does not fit: the forms below lay their areas out afresh)
@@ -1009,7 +1031,7 @@ int launchTrainedUnion(
         if (status != hipSuccess) {
             return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
         }
-        chooseWaves(registerWaves, &waves, &ldsBytes);
+        chooseWaves(sharedDwords, params.perWaveDwords, registerWaves, &waves, &ldsBytes);
         if (!waves && persistent) {
             persistent = false;   // the one-tile kernel's layout may still fit
         } else {

@@ -162,7 +162,7 @@ if any(c.endswith('union') for c in cases):
     # BASELINE.json configs[4]: concatenation of two 4-bit models, 500 000 words, a quarter missing per model;
     # the options of the FIRST reader choose the kernel
     from memb_amd import _memb
-    second_path, _ = synthetic.cached_model(1999995, 300, 'trained', 4, seed=4321)
+    second_path, _ = synthetic.cached_model(1999995, 300, 'trained', int(os.environ.get('AB3_UNION_BITS', '4')), seed=4321)
     second = memb_amd.Reader(second_path, device=0)
     second.info()
     rng = np.random.default_rng(17)

@@ -1236,14 +1236,15 @@ __global__ void decode_trained_union(UnionParams u)
     outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
 }
 
-// Two models of one key format staged as row records: the wavefront's lanes are SPLIT between the models -- the
+// Two models staged as row records: the wavefront's lanes are SPLIT between the models -- the
 // lower half of its word slots decodes the tile's words for model 0, the upper half the same words for model 1, in ONE
 // pass of the decoder -- so a tile is wordsPerWave / 2 words, its LDS footprint that of the single-model kernel
 // (decode_trained_union needs slots and a symbol tile per model, which caps it at 20 wavefronts per CU), and the chain
 // of a wavefront is row ids -> regions -> one decode -> merged rows, as short as the single-model one-tile kernel's.
 // u.model[2] = the slot geometry of the model with the larger row regions, with nRows = 2^32 - 1 (rows are checked per
 // lane against the lane's model here and arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
-// FAST: nibble keys (8-byte table entries); else byte keys for both models, decoded through their 4-byte PACKED tables.
+// FAST: nibble keys in both models (8-byte table entries); else byte keys for both (a nibble-key model through its
+// byte-key forms), decoded through 4-byte PACKED tables.
 template <bool HAS_SUB, bool FAST, bool AVERAGE>
 __global__ void decode_union_split(UnionParams u)
 {

@@ -950,26 +950,26 @@ int launchTrainedUnion(
     uint32_t registerWaves = 32;
     int numRegs = 0;
 
-    // decode_union_split: two models of one key format staged as row records -- the wavefront's word slots are divided
+    // decode_union_split: two models staged as row records -- the wavefront's word slots are divided
     // between the models, a tile is half as many words, LDS per wavefront as in the single-model kernel.
     // Against the forms below (nibble keys, batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
-    const bool noneFast = !ctxs[0]->fast && (count < 2 || !ctxs[1]->fast);
-    bool split = count == 2 && (allFast || noneFast) && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
+    bool split = count == 2 && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
         ((wordsPerWave / 2) * params.model[0].keyRowBytes) % 4 == 0;
     // the slots take the geometry of the model with the larger row regions; the other model's loads then run up to as
     // many pieces into the rows behind its own (its array ends with a guard of more than one region)
     const size_t larger = count == 2 && ctxs[1]->slotDwords > ctxs[0]->slotDwords ? 1 : 0;
     for (size_t m = 0; m < count && split; ++m) {
         split = ctxs[m]->recordPieces && ctxs[m]->recordPieces <= ctxs[larger]->recordPieces &&
-            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces && (ctxs[m]->fast || ctxs[m]->table32) &&
+            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces && (allFast || ctxs[m]->table32) &&
             wordsPerWave * (ctxs[larger]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     }
     if (split) {
         UnionParams sp = params;
         uint32_t shared = sharedDwords;
         bool packedSub = false;
-        if (noneFast) {
-            // byte keys: the single-model kernels' 4-byte table entries (decodeSegment<..., PACKED>)
+        if (!allFast) {
+            // byte keys (a nibble-key model beside a byte-key one included: its byte-key table and plain codebook):
+            // the single-model kernels' 4-byte table entries (decodeSegment<..., PACKED>)
             shared = 0;
             for (size_t m = 0; m < count; ++m) {
                 sp.model[m].table = ctxs[m]->table32;
@@ -1754,8 +1754,9 @@ int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         }
         code = copyToDevice(ctx->table, expanded.data(), expanded.size() * 4);
     }
-    if (code == MEMB_HIP_OK && !ctx->fast) {
-        // (setUpLds copies whole 16-byte pieces: the device copy is padded to packedTableDwords like the LDS image)
+    if (code == MEMB_HIP_OK) {
+        // (setUpLds copies whole 16-byte pieces: the device copy is padded to packedTableDwords like the LDS image;
+        // nibble-key models have it too: decode_union_split decodes them through it beside a byte-key partner)
         std::vector<uint32_t> padded(ctx->byteTable.entries);
         padded.resize(packedTableDwords(ctx), 0);
         code = deviceAlloc(ctx, &ctx->table32, padded.size() * 4);

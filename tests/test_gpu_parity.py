@@ -971,8 +971,8 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
         assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline, split)
         ran = readers[0].info()['union_kernel']   # what that launch was
         # (the 8-bit model's row regions are too long for a tile of eight to fit two 64-lane rounds of pieces)
-        if split and len(formats) == 1 and max(bits_a, bits_b) <= 6 and all(reader.info()['row_layout'] == 2 for reader in readers):
-            # one key format, row records: also with regions of different sizes (2-bit + 4-bit) and byte keys (6-bit + 6-bit)
+        if split and max(bits_a, bits_b) <= 6 and all(reader.info()['row_layout'] == 2 for reader in readers):
+            # row records: also with regions of different sizes (2-bit + 4-bit), byte keys (6-bit + 6-bit) and mixed key formats
             assert ran.startswith('decode_union_split<'), ran
         elif persistent == 0:
             assert ran.startswith('decode_trained_union<'), ran

@@ -401,7 +401,9 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
     import torch
     cases = [((20000, 300, 4, 1234), (15000, 300, 4, 99)),      # nibble keys
              ((20000, 300, 6, 1234), (15000, 300, 8, 99)),      # byte keys, the second with two-level tables
-             ((3000, 64, 2, 5), (3000, 64, 4, 6))]              # small dim, different codebooks
+             ((3000, 64, 2, 5), (3000, 64, 4, 6)),              # small dim, different codebooks
+             ((3000, 100, 4, 5), (2500, 100, 4, 6)),            # 25 pieces per half row
+             ((1500, 1024, 4, 5), (1500, 1024, 6, 6))]          # wide rows, mixed key formats
     for first, second in cases:
         path_a, words_a = make_model(first[0], first[1], 'trained', first[2], seed=first[3])
         path_b, words_b = make_model(second[0], second[1], 'trained', second[2], seed=second[3])

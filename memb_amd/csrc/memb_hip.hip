@@ -998,6 +998,9 @@ int launchTrainedUnion(
             return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
         }
         chooseWaves(shared, sp.perWaveDwords, registerWaves, &waves, &ldsBytes);
+        if (waves && (n + half - 1) / half / waves >= 0x7FFFFFFFull) {
+            waves = 0;   // (more blocks than a grid holds: the forms below have tiles twice as large)
+        }
         if (waves) {
             const size_t splitTiles = (n + half - 1) / half;
             {

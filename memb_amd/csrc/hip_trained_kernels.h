@@ -1228,7 +1228,7 @@ __global__ void decode_trained_union(UnionParams u)
         const TrainedParams& p = u.model[m];
         uint32_t* slots = waveLds + u.slotOffsetDwords[m];
         recordSegmentBits(p, slots, role, meta[m]);
-        decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+        decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
             p, reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots, waveLds + u.keyTileOffsetDwords[m], role, meta[m]);
         absent.set(m, __ballot(!(meta[m].row < p.nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
     }
@@ -1383,7 +1383,7 @@ __global__ void decode_records_union_persistent(UnionParams u)
             meta.packed3 = 0;
             recordSegmentBits(u.model[m], slots, role, meta);
             if (!(measureFlags(first) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
-                decodeSegment<HAS_SUB, OUT_VEC4, FAST>(
+                decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
                     u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
                     waveLds + u.keyTileOffsetDwords[m], role, meta);
             }

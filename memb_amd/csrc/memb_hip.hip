@@ -159,9 +159,8 @@ struct memb_hip_ctx {
     memb::DecodeTable byteTable;
     std::vector<memb::CodeInfo> codeLengths;   // kept to rebuild byteTable narrower when LDS is short
     uint32_t* table32 = nullptr;
-    // nibble-key models only: the table and the codebook in their BYTE-key forms as well (8-byte entries with the symbol
-    // replicated per byte, 256 plain centroids), so that a union with a byte-key model can run as one kernel
-    uint32_t* tableBytes = nullptr;
+    // nibble-key models only: the codebook in its BYTE-key form as well (256 plain centroids) -- with table32, which every
+    // model has, a union with a byte-key model can then run as one kernel
     float* codebookBytes = nullptr;
     uint32_t maxStreamBytes = 0;
     uint32_t slotDwords = 0;
@@ -842,11 +841,21 @@ int launchTrainedUnion(
             ld < colOffs[m] + ctx->dim) {
             return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the models differ in storage, device, dim or lane geometry");
         }
-        hasSub = hasSub || ctx->hostTable.hasSubTables;
         allFast = allFast && ctx->fast;
     }
+    for (size_t m = 0; m < count; ++m) {
+        // (byte keys decode through the 4-byte PACKED tables, whose first level is wider: hip_trained_kernels.h)
+        hasSub = hasSub || (allFast ? ctxs[m]->hostTable.hasSubTables : ctxs[m]->byteTable.hasSubTables);
+    }
+    if (!allFast) {
+        for (size_t m = 0; m < count; ++m) {
+            if (!ctxs[m]->table32) {
+                return fail(MEMB_HIP_UNSUPPORTED, "union kernel: a model has no byte-key table on the device");
+            }
+        }
+    }
     // Nibble keys (<= 16 centroids, codes <= 8 bits) only when every model has them; a mixed union decodes the
-    // nibble-key models through their byte-key tables (memb_hip_ctx::tableBytes): the same symbols, one per byte.
+    // nibble-key models through their byte-key tables (memb_hip_ctx::table32): the same symbols, one per byte.
     if (ld % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 || n > (size_t(1) << 37)) {
         return fail(MEMB_HIP_UNSUPPORTED, "union kernel: the output is not 16-byte aligned in every row");
     }
@@ -879,16 +888,22 @@ int launchTrainedUnion(
         p.segmentSymbols = ctx->segmentSymbols;
         p.keyRowBytes = allFast ? keyRowBytes(ctx) : roundUp4(ctx->dim);
         p.keyTileDwords = (wordsPerWave * p.keyRowBytes + 3) / 4 + 1;
-        if (!allFast && ctx->fast) {
-            p.table = ctx->tableBytes;
-            p.codebook = ctx->codebookBytes;
-            p.codebookDwords = 256;
+        if (!allFast) {
+            // byte keys: the single-model kernels' 4-byte table entries (decodeSegment<..., PACKED>); a nibble-key model
+            // beside a byte-key one goes through its own byte-key table and plain codebook
+            p.table = ctx->table32;
+            p.tableDwords = packedTableDwords(ctx);
+            p.rootBits = ctx->byteTable.rootBits;
+            if (ctx->fast) {
+                p.codebook = ctx->codebookBytes;
+                p.codebookDwords = 256;
+            }
         }
         p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * count * (ctx->dim / 4));
         p.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
         p.debugFlags = first->switches.debugFlags;   // (measurement builds: the first reader's switches for all)
         params.tableOffsetDwords[m] = sharedDwords;
-        sharedDwords += ctx->tableDwords;
+        sharedDwords += p.tableDwords;
     }
     params.codebookOffsetDwords = sharedDwords;
     sharedDwords += static_cast<uint32_t>(count) * 512;
@@ -960,29 +975,13 @@ int launchTrainedUnion(
     const size_t larger = count == 2 && ctxs[1]->slotDwords > ctxs[0]->slotDwords ? 1 : 0;
     for (size_t m = 0; m < count && split; ++m) {
         split = ctxs[m]->recordPieces && ctxs[m]->recordPieces <= ctxs[larger]->recordPieces &&
-            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces && (allFast || ctxs[m]->table32) &&
+            ctxs[larger]->recordPieces <= 2 * ctxs[m]->recordPieces &&
             wordsPerWave * (ctxs[larger]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     }
     if (split) {
         UnionParams sp = params;
-        uint32_t shared = sharedDwords;
-        bool packedSub = false;
-        if (!allFast) {
-            // byte keys (a nibble-key model beside a byte-key one included: its byte-key table and plain codebook):
-            // the single-model kernels' 4-byte table entries (decodeSegment<..., PACKED>)
-            shared = 0;
-            for (size_t m = 0; m < count; ++m) {
-                sp.model[m].table = ctxs[m]->table32;
-                sp.model[m].tableDwords = packedTableDwords(ctxs[m]);
-                sp.model[m].rootBits = ctxs[m]->byteTable.rootBits;
-                sp.tableOffsetDwords[m] = shared;
-                shared += sp.model[m].tableDwords;
-                packedSub = packedSub || ctxs[m]->byteTable.hasSubTables;
-            }
-            sp.codebookOffsetDwords = shared;
-            shared += static_cast<uint32_t>(count) * 512;
-            sp.sharedDwords = shared;
-        }
+        const uint32_t shared = sharedDwords;
+        const bool packedSub = !allFast && hasSub;
         const uint32_t half = wordsPerWave / 2;
         sp.model[2] = sp.model[larger];
         sp.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
@@ -1787,20 +1786,8 @@ int stageTables(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         code = copyToDevice(ctx->codebook, codebook.data(), 512 * 4);
         ctx->hostCodebook = codebook;
         if (code == MEMB_HIP_OK && ctx->fast) {
-            // the byte-key forms (see memb_hip_ctx::tableBytes): 2 KiB + 1 KiB
-            std::vector<uint32_t> byteForm(ctx->tableDwords, 0);
-            for (size_t i = 0; i < ctx->hostTable.entries.size(); ++i) {
-                const uint32_t entry = ctx->hostTable.entries[i];   // (no pointers: nibble-key models have one-level tables)
-                byteForm[2 * i] = entry & 0xff;
-                byteForm[2 * i + 1] = ((entry >> 8) & 0xff) * 0x01010101u;
-            }
-            code = deviceAlloc(ctx, &ctx->tableBytes, byteForm.size() * 4);
-            if (code == MEMB_HIP_OK) {
-                code = copyToDevice(ctx->tableBytes, byteForm.data(), byteForm.size() * 4);
-            }
-            if (code == MEMB_HIP_OK) {
-                code = deviceAlloc(ctx, &ctx->codebookBytes, 256 * 4);
-            }
+            // the byte-key form of the codebook (see memb_hip_ctx::codebookBytes): 1 KiB
+            code = deviceAlloc(ctx, &ctx->codebookBytes, 256 * 4);
             if (code == MEMB_HIP_OK) {
                 code = copyToDevice(ctx->codebookBytes, centroids.data(), 256 * 4);
             }

@@ -4,6 +4,7 @@
  * entry point and prints them. Compiled and run by tests/test_cabi.py (GPU).
  *   cc -std=c99 -I include tests/cabi/client.c -L memb_amd -lmemb_hip -Wl,-rpath,memb_amd -o client
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include "memb_hip.h"
@@ -59,6 +60,34 @@ int main(void)
         return 4;
     }
     printf("error: %s\n", memb_hip_last_error());
+    {
+        /* memb_hip_ctx_get_info fills no more than the caller's struct_size: a client built against an older, shorter
+           struct (here: up to large_batch_kernel) must find the bytes behind it untouched */
+        union { memb_hip_ctx_info info; unsigned char bytes[sizeof(memb_hip_ctx_info)]; } whole, older;
+        const size_t old_size = offsetof(memb_hip_ctx_info, large_batch_kernel);
+        size_t k;
+        memset(&whole, 0, sizeof whole);
+        whole.info.struct_size = sizeof(memb_hip_ctx_info);
+        if (memb_hip_ctx_get_info(ctx, &whole.info) != MEMB_HIP_OK || whole.info.struct_size != sizeof(memb_hip_ctx_info) ||
+            memb_hip_abi_version() != MEMB_HIP_ABI_VERSION) {
+            printf("get_info failed: %s\n", memb_hip_last_error());
+            return 5;
+        }
+        memset(&older, 0xAB, sizeof older);
+        older.info.struct_size = (uint32_t)old_size;
+        older.info.batch_words = 0;
+        if (memb_hip_ctx_get_info(ctx, &older.info) != MEMB_HIP_OK || older.info.struct_size != old_size) {
+            printf("get_info with an older struct failed: %s\n", memb_hip_last_error());
+            return 6;
+        }
+        for (k = old_size; k < sizeof older; ++k) {
+            if (older.bytes[k] != 0xAB) {
+                printf("get_info wrote behind the caller's struct_size (byte %u)\n", (unsigned)k);
+                return 7;
+            }
+        }
+        printf("info: kernel %s, union_kernel '%s'\n", whole.info.kernel, whole.info.union_kernel);
+    }
     memb_hip_ctx_destroy(ctx);
     return 0;
 }

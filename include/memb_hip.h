@@ -105,7 +105,8 @@ typedef struct memb_hip_full_desc {
 /*
  * Version of this interface: bumped whenever a struct of this header changes size or layout,
  * or an entry point changes meaning. 3 = round 3 (memb_hip_ctx_info gained struct_size;
- * memb_hip_ctx_set_option and the builder entry points were added).
+ * memb_hip_ctx_set_option and the builder entry points were added). Entry points added since
+ * (memb_hip_encoder_rows) leave it alone: nothing an older client binds changed.
  */
 #define MEMB_HIP_ABI_VERSION 3
 int memb_hip_abi_version(void);
@@ -282,6 +283,9 @@ void memb_hip_encoder_destroy(memb_hip_encoder* encoder);
 int memb_hip_encoder_add_rows(memb_hip_encoder* encoder, const float* rows, size_t n_rows);
 /* counts[256]: how often each symbol occurred so far */
 int memb_hip_encoder_counts(memb_hip_encoder* encoder, uint64_t* counts);
+/* rows taken so far (whole add_rows calls that succeeded): what pack will lay out; a caller that keeps
+ * the words checks it against its own count before it writes a file */
+int memb_hip_encoder_rows(memb_hip_encoder* encoder, uint64_t* n_rows);
 /*
  * codes[256] / lengths[256]: the prefix code of every symbol (length 0 = symbol never occurs), at most 16 bits.
  * stream_bytes[rows added]: length of every word's byte-aligned stream; total_bytes: their sum.

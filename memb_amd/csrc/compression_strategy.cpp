@@ -451,6 +451,7 @@ public:
 
     void add(const std::string& word, const float* source, size_t dim) override
     {
+        refuseAfterFailure();
         words_.push_back(word);
         dim_ = dim;
         values_.insert(values_.end(), source, source + dim);
@@ -461,6 +462,7 @@ public:
 
     void addMany(const std::string* words, const float* matrix, size_t count, size_t dim) override
     {
+        refuseAfterFailure();
         if (count == 0) {
             return;
         }
@@ -480,6 +482,7 @@ public:
 
     wire::BufferBuilder::Ref finalize() override
     {
+        refuseAfterFailure();
         const size_t wordCount = words_.size();
         if (wordCount == 0) {
             throw std::runtime_error("Nothing to encode");
@@ -505,7 +508,18 @@ public:
                 startEncoder();   // fewer words than the k-means sample: nothing has gone to the device yet
             }
             lap("k-means fit (if not done while adding)");
+        }
+        if (device_ >= 0) {   // (startEncoder hands models it cannot take to the host path)
             pendingDeviceRows(true);
+            // every word must have its row on the device: pack lays streams out by row number, and a word
+            // without one would be given its neighbour's stream
+            uint64_t deviceRows = 0;
+            deviceCall(memb_hip_encoder_rows(encoder_, &deviceRows));
+            if (deviceRows != wordCount) {
+                failed_ = "memb builder on the HIP device: " + std::to_string(deviceRows) + " rows on the device for " +
+                    std::to_string(wordCount) + " words";
+                throw std::runtime_error(failed_);
+            }
             std::vector<uint64_t> counts(256, 0);
             deviceCall(memb_hip_encoder_counts(encoder_, counts.data()));
             lap("device: last rows + histogram");
@@ -702,10 +716,21 @@ private:
         return codebook;
     }
 
-    static void deviceCall(int code)
+    // A device call that fails leaves words registered whose rows never reached the device (the caller may
+    // catch the exception and go on: tools/converter does, block by block). From then on the compressor
+    // refuses everything, so no file with words and streams out of step can be written.
+    void deviceCall(int code)
     {
         if (code != MEMB_HIP_OK) {
-            throw std::runtime_error(std::string("memb builder on the HIP device: ") + memb_hip_last_error());
+            failed_ = std::string("memb builder on the HIP device: ") + memb_hip_last_error();
+            throw std::runtime_error(failed_);
+        }
+    }
+
+    void refuseAfterFailure() const
+    {
+        if (!failed_.empty()) {
+            throw std::runtime_error("memb builder: an earlier device call failed, the builder cannot be used further (" + failed_ + ")");
         }
     }
 
@@ -713,6 +738,16 @@ private:
     {
         fitClusterizer();
         const std::vector<float>& splits = clusterizer_.splits();
+        // The device quantiser searches sorted, finite split points. A sample with NaN or infinite weights can
+        // leave the fit with others; the host path takes whatever the fit produced, so such a model is written
+        // there -- same bytes as a host builder's, which is what `device` promises. Nothing has left for the
+        // device at this point: values_ still holds every row.
+        for (size_t i = 0; i < splits.size(); ++i) {
+            if (!(splits[i] == splits[i]) || (i && splits[i] < splits[i - 1])) {
+                device_ = -1;
+                return;
+            }
+        }
         deviceCall(memb_hip_encoder_create(
             &encoder_, device_, static_cast<uint32_t>(dim_), splits.data(), static_cast<uint32_t>(splits.size())));
     }
@@ -726,6 +761,9 @@ private:
                 return;
             }
             startEncoder();
+            if (device_ < 0) {
+                return;   // (the host path from here on; the rows stay in values_)
+            }
             all = true;
         }
         const size_t waiting = dim_ ? values_.size() / dim_ : 0;
@@ -761,6 +799,7 @@ private:
     KMeansClusterizer clusterizer_;
     int device_ = -1;
     memb_hip_encoder* encoder_ = nullptr;
+    std::string failed_;          // non-empty: a device call failed (deviceCall)
     size_t dim_ = 0;
     std::vector<std::string> words_;
     std::vector<float> values_;   // host path: every row; device path: rows that have not gone to the device yet

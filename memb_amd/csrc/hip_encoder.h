@@ -246,6 +246,19 @@ int encoder_counts_checked(memb_hip_encoder* encoder, uint64_t* counts)
     return MEMB_HIP_OK;
 }
 
+int encoder_rows_checked(memb_hip_encoder* encoder, uint64_t* rows)
+{
+    if (!encoder || !rows) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    std::lock_guard<std::mutex> lock(encoder->mutex);
+    if (encoder->broken) {
+        return fail(MEMB_HIP_ERR_DEVICE, "encoder: an earlier block failed on the device; the encoder cannot be used further");
+    }
+    *rows = encoder->rows;
+    return MEMB_HIP_OK;
+}
+
 // Code table in, per-word stream lengths out; the packed streams stay on the device until fetched.
 int encoder_pack_checked(
     memb_hip_encoder* encoder, const uint16_t* codes, const uint8_t* lengths, uint32_t* streamBytes, uint64_t* totalBytes)
@@ -302,6 +315,8 @@ int encoder_pack_checked(
     };
     auto check = [&](hipError_t status, const char* what) {
         if (status != hipSuccess) {
+            // (copies out of `table` / `offsets` below may still be reading those host vectors)
+            (void)hipStreamSynchronize(encoder->stream);
             release();
             return fail(MEMB_HIP_ERR_DEVICE, std::string("encoder: ") + what + ": " + hipGetErrorString(status));
         }

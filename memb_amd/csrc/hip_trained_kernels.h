@@ -309,7 +309,8 @@ __device__ __forceinline__ void decodeSegment(
     const uint32_t* slot = slots + role.word * p.slotDwords;
     uint8_t* keyBytes = reinterpret_cast<uint8_t*>(keyTile);
     uint32_t lastWindow = p.slotDwords - 3;
-    const uint32_t rootShift = 32 - (rootBits ? rootBits : p.rootBits);
+    const uint32_t root = rootBits ? rootBits : p.rootBits;   // ONE width for both levels: the sub-table index
+    const uint32_t rootShift = 32 - root;                    // starts where the lane's own first level ended
     uint32_t bitPos = meta.segmentBits;   // streams start on a slot boundary
     if (p.recordPieces) {
         // row records: the slot begins with the row's record (read by recordSegmentBits), the bitstream follows it
@@ -359,7 +360,7 @@ __device__ __forceinline__ void decodeSegment(
                         const uint32_t subBits = entry & 0xff;
                         const uint32_t base = (entry & ~memb::TABLE_POINTER_FLAG) >> 8;
                         const uint32_t subIndex =
-                            static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
+                            static_cast<uint32_t>((window << root) >> 32) >> (32 - subBits);
                         entry = table32[base + subIndex];
                     }
                 }
@@ -380,7 +381,7 @@ __device__ __forceinline__ void decodeSegment(
                     const uint32_t subBits = entry.x & 0xff;
                     const uint32_t base = (entry.x & ~memb::TABLE_POINTER_FLAG) >> 8;
                     const uint32_t subIndex =
-                        static_cast<uint32_t>((window << p.rootBits) >> 32) >> (32 - subBits);
+                        static_cast<uint32_t>((window << root) >> 32) >> (32 - subBits);
                     entry = tableLds[base + subIndex];
                 }
             }

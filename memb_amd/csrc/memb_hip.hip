@@ -2434,6 +2434,11 @@ int memb_hip_encoder_counts(memb_hip_encoder* encoder, uint64_t* counts)
     return guarded([&] { return encoder_counts_checked(encoder, counts); });
 }
 
+int memb_hip_encoder_rows(memb_hip_encoder* encoder, uint64_t* n_rows)
+{
+    return guarded([&] { return encoder_rows_checked(encoder, n_rows); });
+}
+
 int memb_hip_encoder_pack(
     memb_hip_encoder* encoder, const uint16_t* codes, const uint8_t* lengths, uint32_t* stream_bytes, uint64_t* total_bytes)
 {

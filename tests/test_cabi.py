@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
         'memb_hip_decode_rows_device', 'memb_hip_decode_rows_device_ex', 'memb_hip_decode_rows_union_device', 'memb_hip_sync', 'memb_hip_algorithmic_bytes', 'memb_hip_last_error',
         'memb_hip_abi_version', 'memb_hip_ctx_set_option',
         'memb_hip_encoder_create', 'memb_hip_encoder_destroy', 'memb_hip_encoder_add_rows', 'memb_hip_encoder_counts',
-        'memb_hip_encoder_pack', 'memb_hip_encoder_fetch',
+        'memb_hip_encoder_pack', 'memb_hip_encoder_fetch', 'memb_hip_encoder_rows',
     ])
 
 

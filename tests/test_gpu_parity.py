@@ -997,6 +997,45 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
     readers[0].set_option('union_split', 1)
 
 
+def test_union_split_with_first_levels_of_different_widths(native, make_model):
+    """decode_union_split hands every lane the first-level width of ITS model's table; the second-level index
+    must start where that first level ended. Two byte-key models with sub-tables and different widths
+    (`max_direct_decode_bits` 5 beside 8, 4 beside 7, and in either order, so both are once the model whose
+    slot geometry the kernel runs on) against the checker."""
+    import torch
+    from memb_amd import _memb
+    path_a, words_a = make_model(20000, 300, 'trained', 6, seed=1234, distribution='student')
+    path_b, words_b = make_model(15000, 300, 'trained', 6, seed=5, distribution='student')
+    checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+    rng = np.random.default_rng(610)
+    batch = 30011
+    rows = []
+    for count in (20000, 15000):
+        picks = rng.integers(0, count, size=batch).astype(np.uint32)
+        picks[rng.random(batch) < 0.1] = 0xFFFFFFFF
+        rows.append(picks)
+    expected = [checker.rows_embedding(picks) for checker, picks in zip(checkers, rows)]
+    ids = [torch.from_numpy(picks.view(np.int32)).cuda() for picks in rows]
+    stream = torch.cuda.current_stream().cuda_stream
+    for bits_a, bits_b in ((5, 8), (8, 5), (4, 7), (7, 4)):   # (the codes of these models are 9-11 bits long)
+        readers = [native.Reader(path_a, device=0, max_direct_decode_bits=bits_a),
+                   native.Reader(path_b, device=0, max_direct_decode_bits=bits_b)]
+        widths = [reader.info()['root_bits'] for reader in readers]
+        assert widths[0] != widths[1], widths
+        assert all(reader.info()['max_code_bits'] > width for reader, width in zip(readers, widths))   # sub-tables in both
+        for order in ((0, 1), (1, 0)):
+            pair = [readers[k] for k in order]
+            merged = torch.full((batch, 600), 3.0, dtype=torch.float32, device='cuda')
+            assert _memb.union_rows_to_device([r._impl for r in pair], [ids[k].data_ptr() for k in order], [0, 300], batch,
+                                              merged.data_ptr(), 600, stream, False)
+            assert pair[0].info()['union_kernel'].startswith('decode_union_split<true, false'), pair[0].info()['union_kernel']
+            assert bits_equal(merged.cpu().numpy(), np.concatenate([expected[k] for k in order], axis=1)), (bits_a, bits_b, order)
+            mean = torch.full((batch, 300), 3.0, dtype=torch.float32, device='cuda')
+            assert _memb.union_rows_to_device([r._impl for r in pair], [ids[k].data_ptr() for k in order], [0, 0], batch,
+                                              mean.data_ptr(), 300, stream, True)
+            assert bits_equal(mean.cpu().numpy(), np.mean([expected[k] for k in order], axis=0)), (bits_a, bits_b, order)
+
+
 def test_uniform_persistent_pipeline(native, make_model):
     """dequant_uniform_persistent (row records fetched by LDS-DMA; batches of more than one tile per resident
     wavefront) against the checker: dense, strided, accumulate / divide epilogue, unaligned output (which takes the

@@ -74,6 +74,28 @@ def test_device_writer_word_by_word_and_special_values(native, tmp_path):
             write(native, str(tmp_path / 'du.bin'), small_words, small, storage, 8, 0)
 
 
+@pytest.mark.parametrize('poison', ['nan', 'inf', 'both'])
+def test_sample_with_nan_or_inf_is_written_like_the_host_writer(native, tmp_path, poison):
+    """NaN / infinite weights INSIDE the k-means sample (the first 10 000 words) can leave the fit with centroids,
+    and so split points, that are not sorted numbers. The host writer takes what the fit produced; a device
+    builder hands such a model to the host path (the device quantiser searches sorted split points) -- the same
+    bytes either way, which is what `device` promises."""
+    from memb_amd import synthetic
+    count, dim = 12000, 16
+    words = synthetic.make_words(count)
+    vectors = synthetic.make_vectors(count, dim, seed=17)
+    if poison in ('nan', 'both'):
+        vectors[5, 3] = np.nan
+        vectors[4000, 0] = np.nan
+    if poison in ('inf', 'both'):
+        vectors[17, 1] = np.inf
+        vectors[9000, 2] = -np.inf
+    for blocks, single in ((1, False), (5, False)):
+        host = write(native, str(tmp_path / 'host.bin'), words, vectors, 'trained', 4, None, blocks=blocks)
+        device = write(native, str(tmp_path / 'device.bin'), words, vectors, 'trained', 4, 0, blocks=blocks)
+        assert host == device, (poison, blocks)
+
+
 def test_duplicate_in_a_block_leaves_the_words_before_it_added(native, tmp_path):
     from memb_amd import synthetic
     words = synthetic.make_words(12000)
@@ -172,6 +194,71 @@ def test_encoder_entry_points_against_numpy(native, dim, n_splits, rows):
             stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 1
     finally:
         library.memb_hip_encoder_destroy(encoder)
+
+
+def test_pack_streams_against_the_reference_bitstream(native):
+    """pack_streams (HuffmanEncoder::encode + BitStream::push, reference src/huffman_encoder.cpp:88-97,
+    src/bit_stream.h:18-34) against the REFERENCE's own BitStream (oracle/_ref) on canonical codes assigned by the
+    reference's createCanonicalPrefixCodes (src/prefix_code.cpp) -- including the reference's known answer
+    (src/bit_stream_tests.cpp:35-41) as one row."""
+    import oracle
+    from conftest import golden_json
+    if not oracle.reference_available():
+        pytest.skip('oracle/_ref is not built')
+    reference = oracle.Codec('reference')
+    library = encoder_library(native)
+
+    def device_streams(dim, splits, values, codes, lengths):
+        rows = len(values)
+        encoder = ctypes.c_void_p()
+        assert library.memb_hip_encoder_create(
+            ctypes.byref(encoder), 0, dim, splits.ctypes.data_as(ctypes.c_void_p), len(splits)) == 0, library.memb_hip_last_error()
+        try:
+            assert library.memb_hip_encoder_add_rows(encoder, values.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(rows)) == 0
+            taken = ctypes.c_uint64(0)
+            assert library.memb_hip_encoder_rows(encoder, ctypes.byref(taken)) == 0 and taken.value == rows
+            counts = np.zeros(256, dtype=np.uint64)
+            assert library.memb_hip_encoder_counts(encoder, counts.ctypes.data_as(ctypes.c_void_p)) == 0
+            if codes is None:   # the code the writer would build from this histogram, numbered by the reference
+                keys, size_offsets = native._memb._huffman_description([int(c) for c in counts])
+                code_lengths = [next(k for k, bound in enumerate(size_offsets) if i < bound) for i in range(len(keys))]
+                codes, lengths = reference.canonical_codes(keys, code_lengths)
+            stream_bytes = np.zeros(rows, dtype=np.uint32)
+            total = ctypes.c_uint64(0)
+            codes16 = np.ascontiguousarray(codes, dtype=np.uint16)
+            lengths8 = np.ascontiguousarray(lengths, dtype=np.uint8)
+            assert library.memb_hip_encoder_pack(
+                encoder, codes16.ctypes.data_as(ctypes.c_void_p), lengths8.ctypes.data_as(ctypes.c_void_p),
+                stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 0, library.memb_hip_last_error()
+            packed = np.zeros(max(total.value, 1), dtype=np.uint8)
+            assert library.memb_hip_encoder_fetch(encoder, packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(total.value)) == 0
+            edges = np.concatenate([[0], np.cumsum(stream_bytes.astype(np.int64))])
+            return [packed[a:b].tobytes() for a, b in zip(edges[:-1], edges[1:])], codes, lengths
+        finally:
+            library.memb_hip_encoder_destroy(encoder)
+
+    # the known answer: five symbols 0..4 with the test's five codes, one row
+    known = golden_json('bit_stream.json')
+    codes = np.zeros(256, dtype=np.uint16)
+    lengths = np.zeros(256, dtype=np.uint32)
+    for symbol, (code, bits) in enumerate(known['codes']):
+        codes[symbol], lengths[symbol] = code, bits
+    splits = np.array([0.5, 1.5, 2.5, 3.5], dtype=np.float32)
+    values = np.arange(5, dtype=np.float32).reshape(1, 5)
+    streams, _, _ = device_streams(5, splits, values, codes, lengths)
+    assert streams[0].hex() == known['bytes']
+    assert reference.bitstream_pack(codes[:5], lengths[:5]).tobytes().hex() == known['bytes']
+
+    # histograms as the writer meets them: 16 and 64 centroids, normal and heavy-tailed weights, odd dims
+    for dim, n_splits, rows, heavy in ((300, 15, 700, False), (300, 63, 500, True), (7, 15, 1500, True), (129, 254, 300, False)):
+        rng = np.random.default_rng(dim + n_splits)
+        splits = np.sort(rng.standard_normal(n_splits).astype(np.float32))
+        values = (rng.standard_t(3, size=(rows, dim)) if heavy else rng.standard_normal((rows, dim))).astype(np.float32)
+        streams, codes, lengths = device_streams(dim, splits, values, None, None)
+        assert max(lengths) <= 16
+        symbols = np.searchsorted(splits, values, side='left').astype(np.uint8)
+        for row in range(rows):
+            assert streams[row] == reference.bitstream_pack(codes[symbols[row]], lengths[symbols[row]]).tobytes(), (dim, n_splits, row)
 
 
 def test_encoder_refusals(native):

@@ -139,6 +139,47 @@ def test_bit_packer_known_answer(native):
     assert native._memb._bit_pack([tuple(c) for c in known['codes']]).hex() == known['bytes']
 
 
+def test_host_bit_packer_against_the_reference_bitstream(native):
+    """The host writer's packer against the reference's own BitStream::push (src/bit_stream.h:18-34, compiled into
+    oracle/_ref) on canonical codes the reference's createCanonicalPrefixCodes (src/prefix_code.cpp) assigned."""
+    if not oracle.reference_available():
+        pytest.skip('oracle/_ref is not built')
+    reference = oracle.Codec('reference')
+    rng = np.random.default_rng(23)
+    for trial in range(30):
+        counts = [0] * 256
+        for key in rng.permutation(255)[:int(rng.integers(2, 255))]:
+            counts[int(key)] = int(rng.integers(1, 10 ** int(rng.integers(1, 7))))
+        keys, size_offsets = native._memb._huffman_description(counts)
+        lengths = [next(k for k, bound in enumerate(size_offsets) if i < bound) for i in range(len(keys))]
+        if max(lengths) > 16:
+            continue
+        codes, bits = reference.canonical_codes(keys, lengths)
+        message = np.array(keys, dtype=np.uint8)[rng.integers(0, len(keys), size=int(rng.integers(0, 700)))]
+        ours = native._memb._bit_pack([(int(codes[s]), int(bits[s])) for s in message])
+        assert bytes(ours) == reference.bitstream_pack(codes[message], bits[message]).tobytes()
+
+
+def test_a_failed_device_call_disables_the_builder(native):
+    """A Builder whose device cannot be reached must not go on with words registered and no rows behind them
+    (a caller may catch the exception of one block and add the next: tools/converter does): every later call
+    refuses, nothing is written."""
+    if native.hip_device_count() > 0:
+        pytest.skip('a HIP device is present')
+    from memb_amd import synthetic
+    words = synthetic.make_words(10500)
+    vectors = synthetic.make_vectors(10500, 4, seed=1)
+    builder = native.Builder(4, 'trained', 4, device=0)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        builder.add_words(words[:10200], vectors[:10200])   # the k-means sample is complete: the encoder starts
+    with pytest.raises(RuntimeError, match='cannot be used further'):
+        builder.add_words(words[10200:], vectors[10200:])
+    with pytest.raises(RuntimeError, match='cannot be used further'):
+        builder.add_word('one-more', vectors[0])
+    with pytest.raises(RuntimeError, match='cannot be used further'):
+        builder.save(os.devnull)
+
+
 def test_encoder_description_and_device_table_decode_like_reference(native):
     """Builder's Huffman description -> (a) accepted by the reference decoder,
     (b) the product's own lookup table (memb_amd/csrc/codec.h) resolves every

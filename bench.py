@@ -72,6 +72,7 @@ def parse_args():
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-configs', action='store_true',
                         help='skip the per-configuration array and the strong-scaling leg (profiling runs: only the timed kernel)')
+    parser.add_argument('--no-ceilings', action='store_true', help='skip roofline.box_ceilings (tools/perf/ceilings.hip patterns)')
     parser.add_argument('--small', action='store_true', help='shrink every model to 50 000 words (plumbing rehearsal)')
     parser.add_argument('--host-writer', action='store_true',
                         help='write the synthetic models with the host writer (default: memb_amd.Builder(device=...), same bytes)')
@@ -203,6 +204,82 @@ class Timer:
         end.record()
         torch.cuda.synchronize()
         return begin.elapsed_time(end) / count
+
+
+CEILING_PATTERNS = (
+    # (pattern number of tools/perf/ceilings.hip, key, what it is)
+    (0, 'linear_fill', 'one 16-byte store per thread, wavefront exits: the best write pattern of this part'),
+    (1, 'tile_fill', 'one 9600-byte tile (8 rows) per wavefront, then exit: the stores of decode_trained, nothing else'),
+    (2, 'tile_fill_sequential_records', 'tile_fill + the tile\'s eight 160-byte row records read first, consecutive rows (a key-order dump); stored values depend on the loaded bytes'),
+    (3, 'tile_fill_random_records', 'tile_fill + eight 160-byte records at random rows (two 128-byte lines each)'),
+    (4, 'persistent_tile_fill', '16 resident wavefronts per CU walk the tiles, stores only: decode_trained_persistent\'s stores'),
+    (5, 'persistent_tile_fill_sequential_records', 'persistent_tile_fill + sequential records, next tile\'s loads in flight during the stores'),
+    (6, 'persistent_tile_fill_random_records', 'persistent_tile_fill + random records, same prefetch'),
+)
+
+
+def ceilings_library():
+    """tools/perf/libmemb_ceilings.so (measurement only; built by build_native.py), or None."""
+    path = os.path.join(REPO, 'tools', 'perf', 'libmemb_ceilings.so')
+    if not os.path.exists(path):
+        return None
+    library = ctypes.CDLL(path)
+    library.memb_ceiling_launch.restype = ctypes.c_int
+    library.memb_ceiling_launch.argtypes = [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return library
+
+
+def box_ceilings(torch, timer, out, words, launches=20, union=None, patterns=None):
+    """What THIS box does with the decoder's memory pattern and no decoder (tools/perf/ceilings.hip): the
+    2.635 GB of a 2.2 M-word dump written as a linear fill, as the decoder's tiles, and as tiles behind the
+    reads a decoder of 160-byte row records makes -- same output buffer, same 20 ms run-in, per-launch HIP
+    events on the launch stream (median). `union` = (merged output, words): the 500 000 x 600 union shape.
+    None where the library is not built."""
+    library = ceilings_library()
+    if library is None:
+        return None
+    device = out.device
+    units = torch.cuda.get_device_properties(device).multi_processor_count
+    rows = int(words)
+    generator = torch.Generator(device=device)
+    generator.manual_seed(29)
+    records = torch.randint(0, 2 ** 31 - 1, (rows, 40), dtype=torch.int32, device=device, generator=generator)   # 160 B per row
+    ids = torch.randperm(rows, device=device, generator=generator).to(torch.int32)
+    stream = torch.cuda.current_stream().cuda_stream
+    result = {'what': 'this box, the decoder\'s memory pattern without a decoder (tools/perf/ceilings.hip): {} rows x 300 floats into the '
+                      'bench output buffer, 160-byte row records, run in for 20 ms, median of {} launches (HIP events)'.format(rows, launches)}
+    out_bytes = 4.0 * rows * 300
+
+    def run(pattern, target, count, first_ids, records2=None, ids2=None):
+        def call():
+            status = library.memb_ceiling_launch(
+                pattern, target.data_ptr(), count, records.data_ptr(), records2.data_ptr() if records2 is not None else None, rows,
+                first_ids.data_ptr(), ids2.data_ptr() if ids2 is not None else None, stream, units)
+            if status != 0:
+                raise RuntimeError('memb_ceiling_launch({}) failed: hipError {}'.format(pattern, status))
+        times = timer.launches(call, launches)
+        return times[len(times) // 2]
+
+    for pattern, key, what in CEILING_PATTERNS:
+        if patterns is not None and pattern not in patterns:
+            continue
+        ms = run(pattern, out, rows, ids)
+        reads = 0.0 if pattern in (0, 1, 4) else 160.0 * rows
+        result[key] = {'what': what, 'ms': ms, 'bytes_moved_GBps': (out_bytes + reads) / (ms * 1e-3) / 1e9}
+    if union is not None and (patterns is None or 7 in patterns):
+        merged, batch = union
+        ids_a = torch.randint(0, rows, (batch,), dtype=torch.int32, device=device, generator=generator)
+        ids_b = torch.randint(0, rows, (batch,), dtype=torch.int32, device=device, generator=generator)
+        ids_a[torch.rand(batch, device=device, generator=generator) < 0.25] = -1
+        ids_b[torch.rand(batch, device=device, generator=generator) < 0.25] = -1
+        records2 = torch.randint(0, 2 ** 31 - 1, (rows, 40), dtype=torch.int32, device=device, generator=generator)
+        ms = run(7, merged, batch, ids_a, records2, ids_b)
+        result['union_tile_fill_random_records'] = {
+            'what': 'the union shape: {} merged rows of 600 floats, a tile = 4 rows, eight 160-byte records at random rows of two arrays, 25 % of them absent (not loaded)'.format(batch),
+            'ms': ms, 'bytes_moved_GBps': (4.0 * batch * 600 + 160.0 * 2 * 0.75 * batch) / (ms * 1e-3) / 1e9}
+    return result
 
 
 def algorithmic_bytes(library, reader, rows_host):
@@ -877,6 +954,13 @@ def main():
     if cpu_legs:
         host_api = host_api_timings(reader, path, rows_host)
 
+    # the box's own ceilings for this memory pattern (no decoder): same buffer, same run-in
+    ceilings = None
+    if special is None and batch is None and not args.no_ceilings:
+        merged = torch.empty((min(500000, n), 2 * dim), dtype=torch.float32, device='cuda') if dim == 300 else None
+        ceilings = box_ceilings(torch, timer, out, n, union=(merged, merged.shape[0]) if merged is not None else None) if dim == 300 else None
+        del merged
+
     configs = None
     if world_size == 1 and not args.no_configs:
         del out, rows
@@ -947,6 +1031,7 @@ def main():
                 'GBps': 4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3) / 1e9,
                 'kernel_hbm_bytes_rate_vs_fill': ((traffic or nbytes) / (kernel_avg_ms * 1e-3)) / (4.0 * n * dim / (fill_ms[len(fill_ms) // 2] * 1e-3)),
             },
+            'box_ceilings': ceilings,
             'rank': 0,
         },
         'cpu_baseline': baseline,

@@ -25,6 +25,8 @@ EXTENSION = os.path.join(PACKAGE_DIR, '_memb' + sysconfig.get_config_var('EXT_SU
 ORACLE_LIBRARY = os.path.join(ORACLE_DIR, 'libmemb_oracle.so')
 UNIFORM_EXPR_LIBRARY = os.path.join(ORACLE_DIR, 'libmemb_uniform_expr.so')
 REFERENCE_LIBRARY = os.path.join(ORACLE_DIR, '_ref', 'libmemb_ref.so')
+CEILINGS_SOURCE = os.path.join(REPO_DIR, 'tools', 'perf', 'ceilings.hip')
+CEILINGS_LIBRARY = os.path.join(REPO_DIR, 'tools', 'perf', 'libmemb_ceilings.so')
 
 GPU_ARCH = 'gfx950'
 
@@ -125,11 +127,23 @@ def build_reference_oracle(force=False):
     return REFERENCE_LIBRARY
 
 
+def build_ceilings(force=False):
+    """tools/perf/ceilings.hip: the decoder's memory patterns without a decoder (bench.py's
+    roofline.box_ceilings). Measurement code: nothing in memb_amd/ loads it."""
+    if not os.path.exists(CEILINGS_SOURCE):
+        return None
+    if force or _newer(CEILINGS_LIBRARY, [CEILINGS_SOURCE]):
+        _run([_hipcc(), '--offload-arch=' + GPU_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+              '-o', CEILINGS_LIBRARY, CEILINGS_SOURCE])
+    return CEILINGS_LIBRARY
+
+
 def build_all(force=False):
     build_hip_library(force)
     build_extension(force)
     build_oracle(force)
     build_reference_oracle(force)
+    build_ceilings(force)
 
 
 if __name__ == '__main__':

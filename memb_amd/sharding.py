@@ -40,14 +40,19 @@ _host_groups = {}
 def host_group(group=None, force_new=False):
     '''A gloo (host memory, TCP / shared memory) group with the ranks of `group`: the lookup path has no
     exchange step, so nothing of it may enter RCCL -- also when the job's default group is `nccl`.
-    Creating the group is collective: every rank of `group` must make its first gather_rows call.'''
+    Creating the group is collective over the ranks of `group` only (`use_local_synchronization`; ranks
+    outside a sub-group neither call nor wait): all of them must reach their first gather_rows call, or
+    call host_group(group) themselves at a point they all pass. Groups are remembered by their ranks.'''
     import torch.distributed as dist
     if dist.get_backend(group) == 'gloo' and not force_new:
         return group
-    key = id(group) if group is not None else None
-    if key not in _host_groups:
-        ranks = dist.get_process_group_ranks(group) if group is not None else None
-        _host_groups[key] = dist.new_group(ranks=ranks, backend='gloo')
+    ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else None
+    key = ranks if ranks is not None and len(ranks) != dist.get_world_size() else None
+    if key not in _host_groups or force_new:
+        if key is None:
+            _host_groups[key] = dist.new_group(backend='gloo')
+        else:
+            _host_groups[key] = dist.new_group(ranks=list(ranks), backend='gloo', use_local_synchronization=True)
     return _host_groups[key]
 
 

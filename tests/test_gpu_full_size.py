@@ -61,6 +61,70 @@ def test_full_vocabulary_dump(native, full_model):
     assert not bool(shuffled[~valid].any())
 
 
+def expected_kernel_class(tiles, resident):
+    """The kernel a dense batch of `tiles` tiles runs with default options (memb_hip.hip planTrained; DESIGN.md
+    section 5 table "kernel by batch size"): resident = 16 wavefronts per CU."""
+    if tiles <= 2 * resident:
+        return ('decode_trained<',)
+    if tiles <= 4 * resident:
+        return ('decode_records_persistent<',)
+    if tiles <= 16 * resident:
+        return ('decode_trained<',)
+    return ('decode_trained<', 'decode_trained_persistent<')   # settled per context by timing
+
+
+def test_default_path_of_every_batch_size_class(native, full_model):
+    """BASELINE.json configs[1] exactly as bench.py and a caller run it -- 100 000 uniformly random rows of the 2.2 M-word
+    4-bit model, 1 % misses, seed 11, DEFAULT options -- and batches on both sides of every edge of the kernel-by-batch-size
+    rule (tiles = 2R - 1, 2R, 2R + 1, 4R, 4R + 1, 16R, 16R + 1; R = 16 wavefronts x CUs), each bit-compared with the
+    checker and with the kernel the context reports for that size. Reference: src/reader.cpp:59-86,
+    src/trained_compression.cpp:113-140."""
+    import torch
+    path, count = full_model
+    reader = native.Reader(path)          # default device, default options
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    assert reader.host_rows_decoded == 0
+    words_per_tile = 64 // reader.info()['lanes_per_word']
+    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+
+    def check(rows, label):
+        tiles = (len(rows) + words_per_tile - 1) // words_per_tile
+        kernel = reader.info(len(rows))['kernel']
+        assert kernel.startswith(expected_kernel_class(tiles, resident)), (label, len(rows), kernel)
+        ids = torch.from_numpy(rows.view(np.int32)).cuda()
+        out = torch.full((len(rows), 300), 7.0, dtype=torch.float32, device='cuda')
+        reader.rows_embedding_device(ids, out=out)
+        torch.cuda.synchronize()
+        assert reader.info(len(rows))['kernel'].startswith(expected_kernel_class(tiles, resident)), label
+        assert bits_equal(out.cpu().numpy(), checker.rows_embedding(rows)), (label, len(rows), kernel)
+        return kernel
+
+    # configs[1]: bench.py's batch_rows(count, 100000)
+    rng = np.random.default_rng(11)
+    rows = rng.integers(0, count, size=100000).astype(np.uint32)
+    rows[rng.integers(0, 100000, size=1000)] = 0xFFFFFFFF
+    kernel = check(rows, 'configs[1]')
+    if count == FULL_VOCAB and resident == 16 * 256:
+        assert kernel.startswith('decode_records_persistent<'), kernel   # 12 500 tiles on 256 CUs: between 2R and 4R
+
+    rng = np.random.default_rng(12)
+    seen = set()
+    for multiple in (2, 4, 16):
+        for delta in (-1, 0, 1):
+            if multiple != 2 and delta == -1:
+                continue
+            tiles = multiple * resident + delta
+            batch = tiles * words_per_tile - (3 if delta == 1 else 0)   # (a ragged last tile on the far side)
+            if batch > 4 * count:
+                continue
+            rows = rng.integers(0, count, size=batch).astype(np.uint32)
+            rows[rng.integers(0, batch, size=batch // 100)] = 0xFFFFFFFF
+            rows[:batch // 4] = np.arange(batch // 4, dtype=np.uint32) % count   # a key-order run as well
+            seen.add(check(rows, '{}R{:+d}'.format(multiple, delta)).split('<')[0])
+    assert {'decode_trained', 'decode_records_persistent'} <= seen, seen
+    assert reader.host_rows_decoded == 0
+
+
 def test_full_vocabulary_through_the_word_api(native, full_model):
     # reader[keys()] -- the reference's to_keyed_vectors call (python/memb/reader.py:27-28):
     # word search overlapped with decode and the pinned-ring copy, against the device-resident result

@@ -95,6 +95,50 @@ def test_eight_rank_shard_and_gather_over_a_separate_gloo_group(native, tmp_path
     run_two_ranks(tmp_path, use_hip=False, count=1003, port=29577, ranks=8, force_host_group=True)
 
 
+SUBGROUP_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, {repo!r})
+    import memb_amd.sharding as sharding
+
+    dist.init_process_group('gloo')
+    rank = dist.get_rank()
+    sub = dist.new_group(ranks=[0, 2])          # (collective over the whole job, as torch requires)
+    if rank in (0, 2):
+        # a host group for the sub-group's ranks only: rank 1 neither calls nor is waited for
+        hosts = sharding.host_group(sub, force_new=True)
+        assert dist.get_backend(hosts) == 'gloo' and dist.get_process_group_ranks(hosts) == [0, 2]
+        assert sharding.host_group(sub, force_new=False) is sub          # already gloo: used as it is
+        assert sharding._host_groups[(0, 2)] is hosts                     # remembered by its ranks, not by id()
+        sharding.host_group = lambda group=None, force_new=False: hosts   # what an nccl job's gather would use
+        me = dist.get_rank(sub)
+        start, stop = sharding.shard_range(11, me, 2)
+        local = np.arange(start, stop, dtype=np.float32)[:, None] * np.ones((1, 3), dtype=np.float32)
+        full = sharding.gather_rows(local, 11, group=sub, dst=1)          # dst = rank 1 of the sub-group = global 2
+        if rank == 2:
+            assert np.array_equal(full[:, 0], np.arange(11, dtype=np.float32))
+            open({out!r}, 'w').write('ok')
+        else:
+            assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_host_group_of_a_sub_group_is_created_by_its_ranks_only(native, tmp_path):
+    out = str(tmp_path / 'sub.txt')
+    script = tmp_path / 'sub_worker.py'
+    script.write_text(SUBGROUP_WORKER.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    result = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=3',
+         '--master-addr', '127.0.0.1', '--master-port', '29579', str(script)],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert result.returncode == 0, result.stdout[-3000:]
+    assert open(out).read() == 'ok'
+
+
 @pytest.mark.gpu
 def test_two_rank_shard_through_the_hip_path(native, tmp_path):
     # two processes, each decoding its slice on the GPU (above the 512-word small-batch path and below it)

@@ -287,7 +287,8 @@ int memb_hip_encoder_counts(memb_hip_encoder* encoder, uint64_t* counts);
  * the words checks it against its own count before it writes a file */
 int memb_hip_encoder_rows(memb_hip_encoder* encoder, uint64_t* n_rows);
 /*
- * codes[256] / lengths[256]: the prefix code of every symbol (length 0 = symbol never occurs), at most 16 bits.
+ * codes[256] / lengths[256]: the prefix code of every symbol (length 0 = symbol never occurs), at most 16 bits;
+ * of a code value the low `length` bits are written (BitStream::push, reference src/bit_stream.h:29).
  * stream_bytes[rows added]: length of every word's byte-aligned stream; total_bytes: their sum.
  */
 int memb_hip_encoder_pack(

@@ -275,10 +275,13 @@ int encoder_pack_checked(
     uint32_t longest = 0;
     std::vector<uint32_t> table(256, 0);
     for (int symbol = 0; symbol < 256; ++symbol) {
-        if (lengths[symbol] > 16 || (lengths[symbol] < 16 && (codes[symbol] >> lengths[symbol]) != 0)) {
-            return fail(MEMB_HIP_ERR_INVALID, "encoder: a code does not fit its length (at most 16 bits)");
+        if (lengths[symbol] > 16) {
+            return fail(MEMB_HIP_ERR_INVALID, "encoder: codes have at most 16 bits");
         }
-        table[symbol] = codes[symbol] | (static_cast<uint32_t>(lengths[symbol]) << 16);
+        // the low `length` bits of the code, as BitStream::push takes them (reference src/bit_stream.h:29; its
+        // known answer pushes the value 7 with a length of 2: src/bit_stream_tests.cpp:35-41) and as the host writer does
+        const uint32_t code = codes[symbol] & ((1u << lengths[symbol]) - 1u);
+        table[symbol] = code | (static_cast<uint32_t>(lengths[symbol]) << 16);
         longest = std::max<uint32_t>(longest, lengths[symbol]);
     }
     *totalBytes = 0;

@@ -593,11 +593,12 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
     result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
     result.keyTile = result.slots + slotSets * p.wordsPerWave * p.slotDwords;
 
-    for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
+    const bool copy = !(measureFlags(p) & 0x4000);   // (measurement builds, bit 14: no table / codebook copy)
+    for (uint32_t i = threadIdx.x; copy && i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
     }
     if (MODE != OUT_INDEX && MODE != OUT_KEYS) {
-        for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
+        for (uint32_t i = threadIdx.x; copy && i < p.codebookDwords; i += blockDim.x) {
             codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
         }
     }
@@ -662,12 +663,16 @@ __global__ void decode_trained(TrainedParams p)
     waveLdsFence();
 
     recordSegmentBits(p, mem.slots, role, meta);
-    decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
+    if (MODE == OUT_INDEX || !(measureFlags(p) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
+        decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
+    }
     if (MODE == OUT_INDEX) {
         return;
     }
     waveLdsFence();
-    outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+    if (!(measureFlags(p) & 2)) {
+        outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+    }
 }
 
 // Persistent kernel: every wavefront walks tiles wave, wave + W, wave + 2W, ...
@@ -995,15 +1000,16 @@ struct UnionParams {
 template <int COUNT>
 __device__ __forceinline__ void setUpUnionLds(const UnionParams& u, uint32_t* lds)
 {
+    const bool copy = !(measureFlags(u.model[0]) & 0x4000);   // (measurement builds, bit 14: no table / codebook copy)
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
         const TrainedParams& p = u.model[m];
         uint32_t* tableLds = lds + u.tableOffsetDwords[m];
-        for (uint32_t i = threadIdx.x; i < p.tableDwords / 4; i += blockDim.x) {
+        for (uint32_t i = threadIdx.x; copy && i < p.tableDwords / 4; i += blockDim.x) {
             reinterpret_cast<uint4*>(tableLds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
         }
         uint32_t* codebookLds = lds + u.codebookOffsetDwords + m * 512;
-        for (uint32_t i = threadIdx.x; i < p.codebookDwords; i += blockDim.x) {
+        for (uint32_t i = threadIdx.x; copy && i < p.codebookDwords; i += blockDim.x) {
             codebookLds[i] = reinterpret_cast<const uint32_t*>(p.codebook)[i];
         }
     }
@@ -1269,7 +1275,8 @@ __global__ void decode_union_split(UnionParams u)
     uint32_t* slots = waveLds + u.slotOffsetDwords[0];
 
     uint32_t row = MISSING;
-    if (!role.spare && word < tileWords) {
+    const uint32_t measure = measureFlags(u.model[0]);   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
+    if (!role.spare && word < tileWords && !(measure & 4)) {
         const uint32_t* ids = upper ? u.model[1].rows : u.model[0].rows;
         const unsigned long long index = tileBase + word;
         row = ids ? ids[index] : static_cast<uint32_t>(index);
@@ -1288,7 +1295,7 @@ __global__ void decode_union_split(UnionParams u)
         const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
         const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
         const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
-        if (static_cast<uint32_t>(round) * WAVE < totalPieces) {
+        if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
             const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
             pieces[round] = loadPiece<ONE_TILE_NT_LOADS>(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
         }
@@ -1306,9 +1313,11 @@ __global__ void decode_union_split(UnionParams u)
     meta.packed3 = 0;
     recordSegmentBits(both, slots, role, meta);
     const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
-    decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
-        both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
-        upper ? u.model[1].rootBits : u.model[0].rootBits);
+    if (!(measure & 1)) {
+        decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
+            both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
+            upper ? u.model[1].rootBits : u.model[0].rootBits);
+    }
     // per model, bit (word * lanesPerWord): the model lacks the tile's word
     const unsigned long long lacking = __ballot(row == MISSING && !role.spare && role.segment == 0 && word < tileWords);
     AbsentMasks absent;
@@ -1316,7 +1325,9 @@ __global__ void decode_union_split(UnionParams u)
     absent.set(0, upperShift < 64 ? lacking & ((1ull << upperShift) - 1) : lacking);
     absent.set(1, upperShift < 64 ? lacking >> upperShift : 0ull);
     waveLdsFence();
-    outputUnionTile<FAST, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+    if (!(measure & 2)) {
+        outputUnionTile<FAST, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+    }
 }
 
 // The persistent form, for models staged as row records (the pipeline of decode_records_persistent, see

@@ -125,6 +125,37 @@ def test_default_path_of_every_batch_size_class(native, full_model):
     assert reader.host_rows_decoded == 0
 
 
+def test_full_dump_of_a_byte_key_4bit_model(native):
+    """Off the headline's happy path (bench.py `glove840b-300d-4bit-fullvocab-bytekeys`): the same shape with seed 99, whose
+    4-bit code has a 9-bit word -- so no nibble keys: 4-byte table entries, one symbol per byte of the tile. The whole
+    dump against the checker in slices, then shuffled rows with misses against the dump."""
+    import torch
+    from memb_amd import synthetic
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    os.environ.setdefault('MEMB_SYNTH_DEVICE', '0')    # (written on the device: the same bytes, tests/test_gpu_writer.py)
+    path, _ = synthetic.cached_model(count, 300, 'trained', 4, seed=99)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    info = reader.info(count)
+    assert info['max_code_bits'] > 8
+    assert info['kernel'].rstrip('>').split(',')[2].strip() == 'false', info['kernel']   # not the nibble-key instantiation
+    rows = torch.arange(count, dtype=torch.int32, device='cuda')
+    out = reader.rows_embedding_device(rows)
+    torch.cuda.synchronize()
+    step = 200000
+    for start in range(0, count, step):
+        stop = min(count, start + step)
+        assert bits_equal(out[start:stop].cpu().numpy(), checker.rows_embedding(np.arange(start, stop, dtype=np.uint32))), (start, stop)
+    assert torch.unique(out).numel() <= 16
+    generator = torch.Generator(device='cuda').manual_seed(12)
+    perm = torch.randperm(count, device='cuda', generator=generator)[:600000].to(torch.int32)
+    perm[::777] = -1
+    shuffled = reader.rows_embedding_device(perm)
+    valid = perm >= 0
+    assert torch.equal(shuffled[valid].view(torch.int32), out[perm[valid].long()].view(torch.int32))
+    assert not bool(shuffled[~valid].any())
+
+
 def test_full_vocabulary_through_the_word_api(native, full_model):
     # reader[keys()] -- the reference's to_keyed_vectors call (python/memb/reader.py:27-28):
     # word search overlapped with decode and the pinned-ring copy, against the device-resident result

@@ -185,13 +185,21 @@ def test_encoder_entry_points_against_numpy(native, dim, n_splits, rows):
         # refusals
         assert library.memb_hip_encoder_fetch(encoder, packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(max(total.value, 1) - 1)) == (1 if total.value else 0)
         assert library.memb_hip_encoder_add_rows(encoder, values.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(1)) == 1   # after pack
-        bad = codes.copy()
-        bad[used[0]] = 0xFFFF
         lengths_bad = lengths.copy()
-        lengths_bad[used[0]] = 3
+        lengths_bad[used[0]] = 17
         assert library.memb_hip_encoder_pack(
-            encoder, bad.ctypes.data_as(ctypes.c_void_p), lengths_bad.ctypes.data_as(ctypes.c_void_p),
+            encoder, codes.ctypes.data_as(ctypes.c_void_p), lengths_bad.ctypes.data_as(ctypes.c_void_p),
             stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 1
+        if len(used) > 1:
+            # a code value wider than its length: the low bits count, as in BitStream::push (reference src/bit_stream.h:29)
+            wide = codes.copy()
+            wide[used[-1]] |= 0xFFF0
+            assert library.memb_hip_encoder_pack(
+                encoder, wide.ctypes.data_as(ctypes.c_void_p), lengths.ctypes.data_as(ctypes.c_void_p),
+                stream_bytes.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)) == 0
+            again = np.zeros(max(total.value, 1), dtype=np.uint8)
+            assert library.memb_hip_encoder_fetch(encoder, again.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(total.value)) == 0
+            assert again[:total.value].tobytes() == b''.join(streams)
     finally:
         library.memb_hip_encoder_destroy(encoder)
 

@@ -39,9 +39,11 @@ out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
 DEFAULTS = {'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': 0, 'nt_loads': int(os.environ.get('MEMB_HIP_NT_LOADS', '0')), 'waves_per_block': 0, 'blocks_per_cu': 0,
             'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1')), 'pipeline': int(os.environ.get('MEMB_HIP_PIPELINE', '3')), 'grid_policy': int(os.environ.get('MEMB_HIP_GRID_POLICY', '0'))}
 
-print('package: %s   model: %d words, %d-bit   rounds %d x %d launches after %.0f ms run-in' % (
-    os.path.dirname(memb_amd.__file__), n, bits, rounds, reps, run_in_ms), flush=True)
-path, _ = synthetic.cached_model(n, 300, 'trained', bits)
+print('package: %s   model: %d words, %d-bit seed %s %s   rounds %d x %d launches after %.0f ms run-in' % (
+    os.path.dirname(memb_amd.__file__), n, bits, os.environ.get('AB3_SEED', '1234'), os.environ.get('AB3_DIST', 'normal'), rounds, reps, run_in_ms), flush=True)
+seed = int(os.environ.get('AB3_SEED', '1234'))                 # 99: a 4-bit model with a 9-bit code (byte keys)
+distribution = os.environ.get('AB3_DIST', 'normal')           # or 'student'
+path, _ = synthetic.cached_model(n, 300, 'trained', bits, seed=seed, distribution=distribution)
 out = torch.empty((n, 300), dtype=torch.float32, device='cuda')
 rows = torch.arange(n, dtype=torch.int32, device='cuda')
 generator = torch.Generator(device='cuda')

@@ -124,7 +124,7 @@ def spawn_ranks(args):
     import socket
     import build_native
     build_native.build_all()
-    rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
+    rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') in ('1', 'cpu')
     available = kfd_gpu_count()
     # refuse only what is certain: no compute driver at all, or a readable topology with fewer GPUs than asked for
     # (a topology this user cannot read counts nothing: the ranks then find out for themselves)
@@ -153,6 +153,61 @@ def spawn_ranks(args):
 # --------------------------------------------------------------------------------------------
 # helpers
 # --------------------------------------------------------------------------------------------
+
+def install_host_stand_ins(torch, memb_amd):
+    """MEMB_BENCH_REHEARSAL=cpu: the multi-rank PLUMBING of this script on a machine without a GPU (8 ranks in
+    the CPU test suite: launcher, rendezvous, barriers, the max-over-ranks reduce, all_gather_object of the
+    per-rank summaries, the strong-scaling split, the JSON line). Everything that would touch the device is
+    replaced by a host stand-in -- wall-clock `events`, tensors in host memory, a Reader on the product's host
+    path (device='cpu', the reference's own serial / threaded decode restated) -- so the numbers such a run
+    prints are NOT measurements of anything; the line says so in `rehearsal`. Never set by the driver."""
+    import numpy as np
+
+    class Event:
+        def __init__(self, enable_timing=True):
+            self.at = 0.0
+
+        def record(self):
+            self.at = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return max((other.at - self.at) * 1e3, 1e-6)
+
+    class Stream:
+        cuda_stream = 0
+
+    torch.cuda.Event = Event
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: Stream()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    def on_host(function):
+        def wrapped(*args, **kwargs):
+            if str(kwargs.get('device', '')).startswith('cuda'):
+                kwargs['device'] = 'cpu'
+            kwargs.pop('pin_memory', None)
+            return function(*args, **kwargs)
+        return wrapped
+
+    for name in ('empty', 'zeros', 'full', 'tensor', 'arange'):
+        setattr(torch, name, on_host(getattr(torch, name)))
+
+    product_reader = memb_amd.Reader
+
+    class HostReader(product_reader):
+        def __init__(self, filename, num_threads=0, device=None, **kwargs):
+            super().__init__(filename, num_threads, device='cpu', **kwargs)
+
+        def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0):
+            ids = np.ascontiguousarray(rows.numpy()).view(np.uint32)
+            if out is None:
+                out = torch.empty((len(ids), self.dim), dtype=torch.float32)
+            self.rows_embedding_into(ids, out.numpy(), col_off)
+            return out
+
+    memb_amd.Reader = HostReader
+
 
 class Timer:
     """Per-launch device time from HIP events on torch's current stream (the stream the
@@ -310,6 +365,8 @@ def algorithmic_bytes(library, reader, rows_host):
     """per word the row id, the index entry, the compressed payload and the fp32 row."""
     import numpy as np
     rows_host = np.ascontiguousarray(rows_host, dtype=np.uint32)
+    if os.environ.get('MEMB_BENCH_REHEARSAL') == 'cpu':
+        return int(len(rows_host)) * (8 + 4 * reader.dim)   # (no device context to ask; the rehearsal's numbers mean nothing)
     total = ctypes.c_uint64(0)
     status = library.memb_hip_algorithmic_bytes(
         ctypes.c_void_p(reader._impl.context_handle()), rows_host.ctypes.data_as(ctypes.c_void_p),
@@ -867,12 +924,19 @@ def main():
     distributed = world_size > 1
     # Rehearsal of the multi-rank plumbing on a one-GPU box: MEMB_BENCH_REHEARSAL=1 puts every rank on
     # cuda:0 and uses gloo (RCCL refuses two ranks on one device). Never set by the driver.
-    rehearsal = distributed and os.environ.get('MEMB_BENCH_REHEARSAL') == '1'
+    cpu_rehearsal = os.environ.get('MEMB_BENCH_REHEARSAL') == 'cpu'   # no GPU at all: install_host_stand_ins
+    rehearsal = distributed and os.environ.get('MEMB_BENCH_REHEARSAL') in ('1', 'cpu')
+    if cpu_rehearsal:
+        import memb_amd
+        install_host_stand_ins(torch, memb_amd)
+        args.host_writer = args.no_ceilings = True
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # The process group carries barriers, one MAX all-reduce of the elapsed time and the gather of the per-rank
+        # summaries -- nothing of the data path (tests/test_bench_contract.py greps this file for any other collective).
         if rehearsal:
             dist.init_process_group('gloo')
         else:
@@ -1127,6 +1191,8 @@ def main():
         'cpu_baseline': baseline,
         'parity_vs_cpu_checker': parity,
         'ranks_seen': len(per_rank),
+        'rehearsal': ('cpu: host stand-ins for the device (install_host_stand_ins) -- plumbing only, no number in this line is a measurement' if cpu_rehearsal
+                      else 'every rank on cuda:0, gloo rendezvous' if rehearsal else None),
         'launcher': json.loads(os.environ['MEMB_BENCH_LAUNCHER']) if os.environ.get('MEMB_BENCH_LAUNCHER') else
                     {'started_by': 'torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ else 'python bench.py'},
         'per_rank': per_rank,

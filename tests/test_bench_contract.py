@@ -41,6 +41,59 @@ def test_launcher_parent_never_touches_the_gpu(native, tmp_path):
     assert command[command.index('--master-addr') + 1] == '127.0.0.1'
 
 
+def test_eight_rank_plumbing_on_the_cpu(native, tmp_path):
+    """`python bench.py --gpus 8` the way the driver's scaling run starts it, minus the GPUs: eight ranks started by
+    the script itself, gloo rendezvous, host stand-ins for everything that would touch a device
+    (MEMB_BENCH_REHEARSAL=cpu: bench.install_host_stand_ins). What it pins is the plumbing -- every rank reports,
+    the strong-scaling split covers the vocabulary once, the line keeps its contract -- not a single number."""
+    line = run_bench(['--gpus', '8', '--small', '--steps', '2', '--warmup', '1'], tmp_path,
+                     MEMB_BENCH_REHEARSAL='cpu', OMP_NUM_THREADS='1')
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    assert line['rehearsal'].startswith('cpu')
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['scaling'] == 'weak'
+    assert [entry['rank'] for entry in line['per_rank']] == list(range(8))
+    assert all(entry['batch'] == 50000 for entry in line['per_rank'])          # weak scaling: a full batch per rank
+    assert line['launcher']['parent_mapped_hip_runtime'] is False and line['launcher']['parent_imported_torch'] is False
+    assert line['parity_vs_cpu_checker'].startswith('bit-exact')
+    strong = line['strong_scaling']
+    assert strong['scaling'] == 'strong' and strong['ranks_seen'] == 8 and strong['n_gpus'] == 8
+    spans = [entry['rows'] for entry in strong['per_rank']]
+    assert spans[0][0] == 0 and spans[-1][1] == 50000
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))                  # disjoint and gap-free: [0, n) once
+    assert all(stop - start == 6250 for start, stop in spans)                   # ceil(50000 / 8), src/reader.cpp:65
+    assert all(entry['parity'].startswith('bit-exact') for entry in strong['per_rank'])
+    assert strong['host_gather']['parity_rank0'].startswith('bit-exact')
+
+    strong_main = run_bench(['--gpus', '8', '--small', '--steps', '2', '--warmup', '1', '--scaling', 'strong'],
+                            tmp_path, MEMB_BENCH_REHEARSAL='cpu', OMP_NUM_THREADS='1')
+    assert strong_main['scaling'] == 'strong' and strong_main['ranks_seen'] == 8
+    assert sum(entry['batch'] for entry in strong_main['per_rank']) == 50000
+
+
+def test_the_process_group_never_carries_data(native):
+    """north_star: "no RCCL collective needed, only a host-side gather". Every call bench.py makes on
+    torch.distributed: the rendezvous, barriers, ONE kind of reduction (MAX, of an elapsed time) and the gather of the
+    per-rank summary dictionaries. No all_gather / all_to_all / broadcast / send of tensors -- also not in the package."""
+    import re
+    allowed = {'init_process_group', 'destroy_process_group', 'barrier', 'all_reduce', 'all_gather_object', 'ReduceOp'}
+    source = open(os.path.join(REPO, 'bench.py')).read()
+    calls = set(re.findall(r'\bdist\.([A-Za-z_]+)', source))
+    assert calls <= allowed, calls - allowed
+    assert calls >= {'init_process_group', 'barrier', 'all_reduce', 'all_gather_object'}
+    reductions = re.findall(r'dist\.all_reduce\(([^\n]*)\)', source)
+    assert reductions and all('ReduceOp.MAX' in arguments for arguments in reductions), reductions
+    # the package: sharding.gather_rows is the one place with a collective, and it runs on a gloo (host) group
+    for name in os.listdir(os.path.join(REPO, 'memb_amd')):
+        if name.endswith('.py'):
+            text = open(os.path.join(REPO, 'memb_amd', name)).read()
+            used = set(re.findall(r'\bdist\.([a-z_]+)\(', text))
+            if name == 'sharding.py':
+                assert used <= {'get_backend', 'get_process_group_ranks', 'get_world_size', 'new_group', 'get_rank', 'get_global_rank', 'gather'}, used
+            else:
+                assert not used, (name, used)
+
+
 def test_gpus_are_counted_from_the_kfd_topology(tmp_path):
     sys.path.insert(0, REPO)
     import bench

@@ -51,6 +51,8 @@ struct TrainedParams {
     uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
     uint32_t debugFlags;      // measurement builds only (MEMB_HIP_MEASURE; see measureFlags below)
     uint32_t slotSets;        // sets of bitstream slots per wavefront in LDS: 1, or 2 (decode_records_persistent with LDS-DMA)
+    uint32_t tilesPerWave;    // decode_trained / decode_union_split: tiles a wavefront decodes one after the other (>= 1):
+                              // the block's copy of table and codebook into LDS is paid once for all of them
     uint32_t accumulate;      // epilogue: add to what the output already holds ...
     float divisor;            // ... and / or divide by this (0 = no division)
 };
@@ -610,68 +612,66 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
 // plain. (The persistent kernel has both forms, chosen per launch: memb_hip_ctx_set_option "nt_loads".)
 constexpr bool ONE_TILE_NT_LOADS = false;
 
-// One-shot kernel: one tile per wavefront. Used to build the segment index
-// (OUT_INDEX) and for tiles too wide for the persistent kernel's registers.
+// One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
+// keeps the memory system busy. Also builds the segment index (OUT_INDEX).
+// A wavefront decodes p.tilesPerWave tiles one after the other -- tiles wave, wave + W, ... of its block's run of
+// W * tilesPerWave tiles (W = wavefronts per block), so at every step the block's wavefronts write W adjacent tiles --
+// and the block copies table and codebook into LDS once for all of them; the row ids of the next tile are loaded while
+// this one is decoded.
 template <bool HAS_SUB, int MODE, bool FAST>
 __global__ void decode_trained(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr bool PACKED = !FAST && MODE != OUT_INDEX;   // byte keys; the index pass keeps the 8-byte table
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const unsigned long long tile =
-        static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    const unsigned long long tileBase = tile * p.wordsPerWave;
-    const LaneRole role = laneRole(p, lane);
-    // (Measurement builds, bit 18: the wavefront's dependent hops -- row ids, index records, the first rounds of
-    // bitstream pieces -- issued BEFORE the block copies table and codebook into LDS, which none of them needs.
-    // Measured: 0.2-10 % SLOWER on every model and batch size -- 100 k rows +8..10 %, the 4-bit dump +4.6 % --
-    // so the loads stay behind the copy. profiles/r03_experiments.txt, batch 14.)
-    const bool early = (measureFlags(p) & 0x40000) != 0;
-    const bool rowEarly = (measureFlags(p) & 0x100000) != 0;   // (bit 20: only the row ids before the copy)
-    WordMeta meta;
+    uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wavesPerBlock = blockDim.x / WAVE;
+    unsigned long long tile =
+        static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
-    StreamRegisters first;
-    uint32_t tileRow = 0;
-    if (early || rowEarly) {
-        tileRow = loadTileRow(p, tile, role);
-    }
-    if (early) {
-        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
-        unpackMeta(p, role, meta);
-        issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, 0, first);
-    }
     const WaveLds mem = setUpLds<MODE>(p, lds);
-    if (tileBase >= p.n) {
+    if (tile * p.wordsPerWave >= p.n) {
         return;
     }
-    if (!early) {
-        if (!rowEarly) {
-            tileRow = loadTileRow(p, tile, role);
+    uint32_t tileRow = loadTileRow(p, tile, laneRole(p, lane));
+#pragma nounroll
+    for (uint32_t step = 0; step < p.tilesPerWave; ++step, tile += wavesPerBlock) {
+        const unsigned long long tileBase = tile * p.wordsPerWave;
+        if (tileBase >= p.n) {
+            break;
         }
-        meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
+        // Everything a lane derives from its number -- word, segment, the pieces it copies and stores -- is worked out
+        // afresh per tile, as a wavefront with one tile did: hoisted out of the loop those values cost 50 vector
+        // registers and half the resident wavefronts (103 against 52: tools/perf/isa.py).
+        asm volatile("" : "+v"(lane));
+        const LaneRole role = laneRole(p, lane);
+        WordMeta meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
         unpackMeta(p, role, meta);
+        StreamRegisters first = {};   // (defined on every path: otherwise the values are carried around the loop)
         issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, 0, first);
-    }
-    const uint32_t tileWords =
-        static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-    writeStreams(p, mem.slots, lane, 0, first);
-    for (uint32_t round = STREAM_REGISTERS; round < rounds; round += STREAM_REGISTERS) {
-        StreamRegisters v;
-        issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, round, v);
-        writeStreams(p, mem.slots, lane, round, v);
-    }
-    waveLdsFence();
+        if (step + 1 < p.tilesPerWave) {
+            tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
+        }
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+        writeStreams(p, mem.slots, lane, 0, first);
+        for (uint32_t round = STREAM_REGISTERS; round < rounds; round += STREAM_REGISTERS) {
+            StreamRegisters v = {};
+            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, round, v);
+            writeStreams(p, mem.slots, lane, round, v);
+        }
+        waveLdsFence();
 
-    recordSegmentBits(p, mem.slots, role, meta);
-    if (MODE == OUT_INDEX || !(measureFlags(p) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
-        decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
-    }
-    if (MODE == OUT_INDEX) {
-        return;
-    }
-    waveLdsFence();
-    if (!(measureFlags(p) & 2)) {
-        outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+        recordSegmentBits(p, mem.slots, role, meta);
+        if (MODE == OUT_INDEX || !(measureFlags(p) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
+            decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
+        }
+        if (MODE != OUT_INDEX) {
+            waveLdsFence();
+            if (!(measureFlags(p) & 2)) {
+                outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+            }
+        }
+        waveLdsFence();   // (the next tile's streams and symbols go where this one's were)
     }
 }
 
@@ -1256,77 +1256,99 @@ template <bool HAS_SUB, bool FAST, bool AVERAGE>
 __global__ void decode_union_split(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t wavesPerBlock = blockDim.x / WAVE;
     const TrainedParams& both = u.model[2];
     setUpUnionLds<2>(u, lds);
 
     const uint32_t half = both.wordsPerWave / 2;   // words of a tile
-    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
-    const unsigned long long tileBase = tile * half;
-    if (tileBase >= both.n) {
+    // both.tilesPerWave tiles one after the other (tiles wave, wave + W, ... of the block's run), as decode_trained
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * both.tilesPerWave) + wave;
+    if (tile * half >= both.n) {
         return;
     }
-    const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(half), both.n - tileBase));
-    const LaneRole role = laneRole(both, lane);
-    const bool upper = role.word >= half;           // the lane's model
-    const uint32_t word = role.word - (upper ? half : 0u);
     uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
     uint32_t* slots = waveLds + u.slotOffsetDwords[0];
-
-    uint32_t row = MISSING;
     const uint32_t measure = measureFlags(u.model[0]);   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
-    if (!role.spare && word < tileWords && !(measure & 4)) {
-        const uint32_t* ids = upper ? u.model[1].rows : u.model[0].rows;
-        const unsigned long long index = tileBase + word;
-        row = ids ? ids[index] : static_cast<uint32_t>(index);
-        row = row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
-    }
-    // the regions of all eight (word, model) pairs: piece q of the slot image belongs to word slot q / loadPieces
-    // (regions of the lane's model; when the models' regions differ in size, `both` has the larger slot geometry and the
-    // smaller model's slots take a few pieces of the following row along, as every compact-layout load does)
-    const uint32_t start = row != MISSING ? row * (upper ? u.model[1].recordPieces : u.model[0].recordPieces) : 0u;   // absent words read row 0 and never emit it
     const uint32_t totalPieces = both.wordsPerWave * both.loadPieces;
-    u32x4 pieces[RECORD_ROUNDS];
-#pragma unroll
-    for (int round = 0; round < RECORD_ROUNDS; ++round) {
-        pieces[round] = u32x4{0, 0, 0, 0};
-        // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
-        const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
-        const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
-        const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
-        if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
-            const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
-            pieces[round] = loadPiece<ONE_TILE_NT_LOADS>(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
-        }
-    }
-#pragma unroll
-    for (int round = 0; round < RECORD_ROUNDS; ++round) {
-        writeStream(both, slots, lane, round, pieces[round]);
-    }
-    waveLdsFence();
 
-    WordMeta meta;
-    meta.row = row;
-    meta.start = 0;
-    meta.packed2 = 0;
-    meta.packed3 = 0;
-    recordSegmentBits(both, slots, role, meta);
-    const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
-    if (!(measure & 1)) {
-        decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
-            both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
-            upper ? u.model[1].rootBits : u.model[0].rootBits);
-    }
-    // per model, bit (word * lanesPerWord): the model lacks the tile's word
-    const unsigned long long lacking = __ballot(row == MISSING && !role.spare && role.segment == 0 && word < tileWords);
-    AbsentMasks absent;
-    const uint32_t upperShift = half * both.lanesPerWord;   // 32 with eight lanes per word
-    absent.set(0, upperShift < 64 ? lacking & ((1ull << upperShift) - 1) : lacking);
-    absent.set(1, upperShift < 64 ? lacking >> upperShift : 0ull);
-    waveLdsFence();
-    if (!(measure & 2)) {
-        outputUnionTile<FAST, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+    // the lane's row of tile `ofTile`: checked against the lane's model, MISSING for absent words and past the batch
+    auto loadRow = [&](unsigned long long ofTile, uint32_t ofLane) -> uint32_t {
+        const LaneRole role = laneRole(both, ofLane);
+        const bool upper = role.word >= half;
+        const unsigned long long index = ofTile * half + (role.word - (upper ? half : 0u));
+        uint32_t row = MISSING;
+        if (!role.spare && index < both.n && !(measure & 4)) {
+            const uint32_t* ids = upper ? u.model[1].rows : u.model[0].rows;
+            row = ids ? ids[index] : static_cast<uint32_t>(index);
+            row = row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
+        }
+        return row;
+    };
+    uint32_t row = loadRow(tile, lane);
+#pragma nounroll
+    for (uint32_t step = 0; step < both.tilesPerWave; ++step, tile += wavesPerBlock) {
+        const unsigned long long tileBase = tile * half;
+        if (tileBase >= both.n) {
+            break;
+        }
+        // (what a lane derives from its number is worked out per tile, not kept across the loop: see decode_trained)
+        asm volatile("" : "+v"(lane));
+        const LaneRole role = laneRole(both, lane);
+        const bool upper = role.word >= half;           // the lane's model
+        const uint32_t word = role.word - (upper ? half : 0u);
+        const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(half), both.n - tileBase));
+        // the regions of all eight (word, model) pairs: piece q of the slot image belongs to word slot q / loadPieces
+        // (regions of the lane's model; when the models' regions differ in size, `both` has the larger slot geometry and the
+        // smaller model's slots take a few pieces of the following row along, as every compact-layout load does)
+        const uint32_t start = row != MISSING ? row * (upper ? u.model[1].recordPieces : u.model[0].recordPieces) : 0u;   // absent words read row 0 and never emit it
+        u32x4 pieces[RECORD_ROUNDS];
+#pragma unroll
+        for (int round = 0; round < RECORD_ROUNDS; ++round) {
+            pieces[round] = u32x4{0, 0, 0, 0};
+            // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
+            const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
+            const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
+            const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
+            if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
+                const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
+                pieces[round] = loadPiece<ONE_TILE_NT_LOADS>(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
+            }
+        }
+        const uint32_t rowNow = row;
+        if (step + 1 < both.tilesPerWave) {
+            row = loadRow(tile + wavesPerBlock, lane);   // in flight while this tile is decoded
+        }
+#pragma unroll
+        for (int round = 0; round < RECORD_ROUNDS; ++round) {
+            writeStream(both, slots, lane, round, pieces[round]);
+        }
+        waveLdsFence();
+
+        WordMeta meta;
+        meta.row = rowNow;
+        meta.start = 0;
+        meta.packed2 = 0;
+        meta.packed3 = 0;
+        recordSegmentBits(both, slots, role, meta);
+        const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
+        if (!(measure & 1)) {
+            decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
+                both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
+                upper ? u.model[1].rootBits : u.model[0].rootBits);
+        }
+        // per model, bit (word * lanesPerWord): the model lacks the tile's word
+        const unsigned long long lacking = __ballot(rowNow == MISSING && !role.spare && role.segment == 0 && word < tileWords);
+        AbsentMasks absent;
+        const uint32_t upperShift = half * both.lanesPerWord;   // 32 with eight lanes per word
+        absent.set(0, upperShift < 64 ? lacking & ((1ull << upperShift) - 1) : lacking);
+        absent.set(1, upperShift < 64 ? lacking >> upperShift : 0ull);
+        waveLdsFence();
+        if (!(measure & 2)) {
+            outputUnionTile<FAST, 2, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
+        }
+        waveLdsFence();   // (the next tile's regions and symbols go where this one's were)
     }
 }
 

@@ -518,6 +518,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
     params.slotDwords = ctx->slotDwords;
     params.slotMagic = magicFor(params.loadPieces, 64ull * params.loadPieces * 5);
     params.debugFlags = ctx->switches.debugFlags;
+    params.tilesPerWave = 1;
     return params;
 }
 
@@ -525,6 +526,13 @@ struct Epilogue {
     uint32_t accumulate = 0;
     float divisor = 0.f;
 };
+
+// Tiles a wavefront of the one-tile kernels (decode_trained, decode_union_split) decodes one after the other.
+uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles)
+{
+    (void)tiles;
+    return std::max<uint32_t>(1, std::min<uint32_t>(ctx->switches.tilesPerWave, 64));
+}
 
 // Which kernel a batch of this output shape runs, and with what launch geometry.
 struct TrainedPlan {
@@ -758,9 +766,14 @@ int launchTrained(
         }
     }
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
-    const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
+    uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;
     hipError_t status;
+    if (!persistent) {
+        params.tilesPerWave = oneTileSteps(ctx, tiles);
+        const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
+        blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
+    }
     if (persistent) {
         status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
     } else {
@@ -1002,13 +1015,15 @@ int launchTrainedUnion(
         }
         if (waves) {
             const size_t splitTiles = (n + half - 1) / half;
+            sp.model[2].tilesPerWave = oneTileSteps(first, splitTiles);
+            const size_t perBlock = size_t(waves) * sp.model[2].tilesPerWave;
             {
                 std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
                 KernelFacts* facts = nullptr;
                 status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
             }
             if (status == hipSuccess) {
-                hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((splitTiles + waves - 1) / waves)), dim3(waves * WAVE), ldsBytes, stream, sp);
+                hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((splitTiles + perBlock - 1) / perBlock)), dim3(waves * WAVE), ldsBytes, stream, sp);
                 status = hipGetLastError();
             }
             if (status != hipSuccess) {

@@ -625,8 +625,17 @@ __global__ void decode_trained(TrainedParams p)
     constexpr bool PACKED = !FAST && MODE != OUT_INDEX;   // byte keys; the index pass keeps the 8-byte table
     uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
+    uint32_t block = blockIdx.x;
+#ifdef MEMB_HIP_MEASURE
+    if (measureFlags(p) & 0x8000) {
+        // (measurement, bit 15: blocks are dealt round-robin over the 8 XCDs -- give every XCD ONE contiguous run of the
+        // batch instead of every eighth block of it)
+        const uint32_t xcd = block % 8, index = block / 8, whole = gridDim.x / 8, extra = gridDim.x % 8;
+        block = xcd * whole + min(xcd, extra) + index;
+    }
+#endif
     unsigned long long tile =
-        static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
+        static_cast<unsigned long long>(block) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     const WaveLds mem = setUpLds<MODE>(p, lds);
     if (tile * p.wordsPerWave >= p.n) {

@@ -291,7 +291,7 @@ CEILING_PATTERNS = (
     (1, 'tile_fill', 'one 9600-byte tile (8 rows) per wavefront, then exit: the stores of decode_trained, nothing else'),
     (2, 'tile_fill_sequential_records', 'tile_fill + the tile\'s eight 160-byte row records read first, consecutive rows (a key-order dump); stored values depend on the loaded bytes'),
     (3, 'tile_fill_random_records', 'tile_fill + eight 160-byte records at random rows (two 128-byte lines each)'),
-    (4, 'persistent_tile_fill', '16 resident wavefronts per CU walk the tiles, stores only: decode_trained_persistent\'s stores'),
+    (4, 'persistent_tile_fill', '16 resident wavefronts per CU walk the tiles, stores only: the store pattern of a persistent kernel (decode_records_persistent; rounds 1-3: the general pipeline)'),
     (5, 'persistent_tile_fill_sequential_records', 'persistent_tile_fill + sequential records, next tile\'s loads in flight during the stores'),
     (6, 'persistent_tile_fill_random_records', 'persistent_tile_fill + random records, same prefetch'),
 )
@@ -553,9 +553,7 @@ def measure_config(name, what, reader, path, rows_host, timer, library, torch, n
         'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         'parity': parity,
     }
-    if info.get('large_batch_kernel', -1) >= 0:
-        result['large_batch_timing'] = {'chosen': 'one tile per wavefront' if info['large_batch_kernel'] else 'persistent',
-                                        'persistent_ms': info['large_batch_persistent_ms'], 'one_tile_ms': info['large_batch_one_tile_ms']}
+    result['launch'] = {'waves_per_block': info.get('waves_per_block'), 'tiles_per_wavefront': info.get('tiles_per_wavefront')}
     del rows, out
     return result
 
@@ -1051,7 +1049,7 @@ def main():
         elapsed = float(slowest.item())
     kernel_ms = sorted(starts[i].elapsed_time(stops[i]) for i in range(args.steps))
     if special is None:
-        info = reader.info(n)   # (the kernel large batches run is settled by the first one: memb_hip_ctx_set_option "autotune")
+        info = reader.info(n)   # (kernel and launch geometry are chosen by batch size: a static rule, memb_hip.hip planTrained)
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
     kernel_min_ms, kernel_median_ms = kernel_ms[0], kernel_ms[len(kernel_ms) // 2]
     kernel_timing = 'HIP event pair around every launch of the timed region: average (kernel_min_ms, kernel_median_ms: of the same list)'
@@ -1166,13 +1164,9 @@ def main():
             'frac': achieved_gbps / HBM_PEAK_GBPS,
             'traffic': traffic,
             'traffic_source': traffic_source,
-            'kernel': (special['kernel_of']() if 'kernel_of' in special else special['kernel']) if special else info.get('kernel', 'decode_trained_persistent'),
+            'kernel': (special['kernel_of']() if 'kernel_of' in special else special['kernel']) if special else info.get('kernel', 'decode_trained'),
             'kernel_avg_ms': kernel_avg_ms,
             'kernel_timing': kernel_timing,
-            'large_batch_timing': None if info.get('large_batch_kernel', -1) < 0 else {
-                'what': 'the first large batch of a context is decoded by both kernels for large batches, alternating, and the faster one is kept (DESIGN.md section 5)',
-                'chosen': 'one tile per wavefront' if info['large_batch_kernel'] else 'persistent',
-                'persistent_ms': info['large_batch_persistent_ms'], 'one_tile_ms': info['large_batch_one_tile_ms']},
             'kernel_min_ms': kernel_min_ms,
             'kernel_median_ms': kernel_median_ms,
             'kernel_ms_in_launch_order': [round(starts[i].elapsed_time(stops[i]), 4) for i in range(args.steps)],
@@ -1200,7 +1194,7 @@ def main():
         'configs': configs,
         'host_api': host_api,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
-        'geometry': {k: info.get(k) for k in ('waves_per_block', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
+        'geometry': {k: info.get(k) for k in ('waves_per_block', 'tiles_per_wavefront', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
                                               'max_code_bits', 'max_stream_bytes', 'device_bytes', 'row_layout', 'row_bytes')},
         'model_build_s': build_seconds,
         'model_writer': 'host (memb_amd.Builder)' if args.host_writer else 'device (memb_amd.Builder(device={}): memb_hip_encoder_*)'.format(local_rank),

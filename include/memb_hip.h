@@ -105,10 +105,12 @@ typedef struct memb_hip_full_desc {
 /*
  * Version of this interface: bumped whenever a struct of this header changes size or layout,
  * or an entry point changes meaning. 3 = round 3 (memb_hip_ctx_info gained struct_size;
- * memb_hip_ctx_set_option and the builder entry points were added). Entry points added since
- * (memb_hip_encoder_rows) leave it alone: nothing an older client binds changed.
+ * memb_hip_ctx_set_option and the builder entry points were added). 4 = round 4 (memb_hip_ctx_info: the
+ * three large_batch_* fields of the per-context kernel timing are gone with it, tiles_per_wavefront
+ * takes their place; options nt_loads, blocks_per_cu, autotune, pipeline, grid_policy no longer exist;
+ * memb_hip_encoder_rows was added).
  */
-#define MEMB_HIP_ABI_VERSION 3
+#define MEMB_HIP_ABI_VERSION 4
 int memb_hip_abi_version(void);
 
 /*
@@ -140,9 +142,8 @@ typedef struct memb_hip_ctx_info {
     uint32_t register_waves_per_cu;   /* ... and the wavefronts per CU those registers allow (32 = no limit from registers) */
     uint64_t batch_words;        /* IN: the batch size `kernel` and the geometry fields are reported for (the kernel is chosen
                                     by batch size); 0 = a large batch */
-    int32_t large_batch_kernel;  /* trained: -1 = not timed yet, 0 = the persistent pipeline, 1 = one tile per wavefront ("autotune") */
-    float large_batch_persistent_ms;   /* ... and what the timing read, per launch */
-    float large_batch_one_tile_ms;
+    uint32_t tiles_per_wavefront;   /* trained, decode_trained: tiles a wavefront decodes one after the other behind one copy
+                                       of table and codebook into LDS (1, or 2 for tables of 16 KiB and more) */
     char union_kernel[96];       /* the kernel the last memb_hip_decode_rows_union_device call with this context as its FIRST
                                     model launched ("" = none yet, or the call returned MEMB_HIP_UNSUPPORTED) */
 } memb_hip_ctx_info;
@@ -163,22 +164,14 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
 /*
  * Tuning knobs of a live context (results never depend on them). Unknown names and values
  * out of range return MEMB_HIP_ERR_INVALID and change nothing.
- *   "nt_loads"        0 / 1   non-temporal loads of bitstreams and index records (persistent kernel)
- *   "waves_per_block" 0 = choose, or 1, 2, 4, 8
- *   "blocks_per_cu"   0 = as many as fit, else a cap on the persistent kernel's resident blocks per CU
- *   "pipeline"        persistent kernel of row-record models: 0 = the general one, 1 = decode_records_persistent with
- *                     stream registers, 2 = the same fed by LDS-DMA (global_load_lds), 3 = by batch size (default)
- *   "tiles_per_wave"  0 = persistent kernels occupy the resident wavefront slots and walk all tiles (default); K = a grid of
- *                     tiles / K wavefronts that walk about K tiles each and exit
- *   "grid_policy"     0 = the persistent kernel takes every resident wavefront slot, 1 = the fewest wavefronts
- *                     that make the same number of rounds (equal tiles per wavefront)
- *   "persistent"      0 = one tile per wavefront always, 1 = by batch size (default), 2 = the persistent pipeline always
- *   "union_split"     1 (default) = a union of two nibble-key models staged as row records runs decode_union_split
+ *   "waves_per_block" 0 = choose (four; eight for dumps of nibble-key models), or 1, 2, 4, 8 (16: measurements)
+ *   "persistent"      1 (default) = the kernel by batch size: decode_trained (one tile per wavefront at a time), except
+ *                     decode_records_persistent for two to four tiles per 16 wavefronts per CU (65 000 - 131 000 words on 256 CUs);
+ *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
+ *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
+ *                     decodes K tiles one after the other behind one copy of the tables into LDS
+ *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
- *   "autotune"        1 (default): with "persistent" = 1, the first batch of more than 16 tiles per resident wavefront (524 288 words on 256 CUs) a context
- *                     sees is decoded by both kernels in turn, 17 launches each (~20 ms), on the caller's stream, and the faster one serves
- *                     large batches from then on (that one call waits for the device; results are the same bits);
- *                     0 = off (persistent kernel); 2 = forget the measurement
  *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)
  * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug",
  * the measurement switches of hip_trained_kernels.h; the shipped library refuses it.

@@ -115,9 +115,7 @@ py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
     result["row_bytes"] = info.row_bytes;
     result["kernel_registers"] = info.kernel_registers;
     result["register_waves_per_cu"] = info.register_waves_per_cu;
-    result["large_batch_kernel"] = info.large_batch_kernel;
-    result["large_batch_persistent_ms"] = info.large_batch_persistent_ms;
-    result["large_batch_one_tile_ms"] = info.large_batch_one_tile_ms;
+    result["tiles_per_wavefront"] = info.tiles_per_wavefront;
     result["union_kernel"] = std::string(info.union_kernel);
     return result;
 }

@@ -1,4 +1,5 @@
-// decode_trained / decode_trained_persistent / repack_streams: canonical-Huffman bitstream decode + codebook gather.
+// decode_trained / decode_records_persistent / decode_union_split / decode_trained_union / repack_streams:
+// canonical-Huffman bitstream decode + codebook gather.
 //
 // Device code of libmemb_hip.so (gfx950 / CDNA4). Included by memb_hip.hip only,
 // inside its anonymous namespace; see that file for the overview.
@@ -38,7 +39,6 @@ struct TrainedParams {
     uint32_t dim;
     uint32_t slotDwords;      // LDS dwords reserved per bitstream, multiple of 4
     uint32_t slotMagic;       // fastDivide magic for loadPieces
-    uint32_t dmaMagic;        // fastDivide magic for slotDwords / 4 (LDS-DMA: pieces of the slot image)
     uint32_t lanesPerWord;    // G
     uint32_t laneMagic;       // fastDivide magic for G
     uint32_t wordsPerWave;    // 64 / G
@@ -50,17 +50,18 @@ struct TrainedParams {
     uint32_t indexSegmentSymbols;
     uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
     uint32_t debugFlags;      // measurement builds only (MEMB_HIP_MEASURE; see measureFlags below)
-    uint32_t slotSets;        // sets of bitstream slots per wavefront in LDS: 1, or 2 (decode_records_persistent with LDS-DMA)
     uint32_t tilesPerWave;    // decode_trained / decode_union_split: tiles a wavefront decodes one after the other (>= 1):
                               // the block's copy of table and codebook into LDS is paid once for all of them
     uint32_t accumulate;      // epilogue: add to what the output already holds ...
     float divisor;            // ... and / or divide by this (0 = no division)
 };
 
-// Measurement switches (skip the decode, skip the output, store policies ...; the list is in front of
-// storeOutput16). They exist in builds with -DMEMB_HIP_MEASURE only (tools/perf/build_measure.py): the
-// shipped library folds every one of these branches away, so no environment variable or option can make
-// it write anything but the decoded rows.
+// Measurement switches, TrainedParams::debugFlags (option `debug` / MEMB_HIP_DEBUG): bit 0 skip the decode, bit 1 skip
+// the output, bit 2 skip the row id / index / bitstream loads (the decoder then chews on whatever LDS holds: output values
+// are garbage, the access pattern is kept), bit 13 (0x2000) store constants instead of gathering centroids from LDS,
+// bit 14 (0x4000) no copy of table and codebook into LDS. They exist in builds with -DMEMB_HIP_MEASURE only
+// (tools/perf/build_measure.py): the shipped library folds every one of these branches away, so no environment
+// variable or option can make it write anything but the decoded rows.
 __device__ __forceinline__ uint32_t measureFlags(const TrainedParams& p)
 {
 #ifdef MEMB_HIP_MEASURE
@@ -71,18 +72,12 @@ __device__ __forceinline__ uint32_t measureFlags(const TrainedParams& p)
 #endif
 }
 
-// One 16-byte piece of a row's bitstream (or an index record). NT: non-temporal (`global_load_dwordx4 ... nt`).
-// A template argument, not a run-time select: `flag ? *p : __builtin_nontemporal_load(p)` is merged by
-// LLVM into ONE plain load (round 2 shipped exactly that and believed it was measuring nt loads);
-// tests/test_isa.py counts the nt loads in the compiled kernels.
-template <bool NT>
+// One 16-byte piece of a row's bitstream (or an index record): a plain load. (Non-temporal loads were built as a
+// template argument in round 3 and measured on one allocation: -0.5 % on the key-order dump, +0.7 % shuffled, +28..48 %
+// on 100 000 rows, whose streams then no longer survive between launches in L2 / Infinity Cache -- removed in round 4.)
 __device__ __forceinline__ u32x4 loadPiece(const u32x4* source)
 {
-    if constexpr (NT) {
-        return __builtin_nontemporal_load(source);
-    } else {
-        return *source;
-    }
+    return *source;
 }
 
 // OUT_KEYS: no codebook gather -- `out` receives the symbol tile itself, dense rows of
@@ -102,7 +97,7 @@ struct TableEntry {
     uint32_t y;
 };
 
-// ---- building blocks shared by the one-shot and the persistent kernel ----
+// ---- building blocks shared by the kernels ----
 
 struct LaneRole {
     uint32_t word;      // word of the tile this lane works on
@@ -142,7 +137,6 @@ struct WordMeta {
 };
 
 // Issues the loads only; the values may be used after unpackMeta.
-template <bool NT>
 __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_t row, const LaneRole& role)
 {
     WordMeta meta;
@@ -160,7 +154,7 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     }
     if (row < p.nRows && p.rowMeta) {
         const u32x4* source = reinterpret_cast<const u32x4*>(p.rowMeta) + row;
-        const u32x4 record = loadPiece<NT>(source);
+        const u32x4 record = loadPiece(source);
         meta.start = record.x;
         meta.segmentBits = record.y;
         meta.packed2 = record.z;
@@ -219,7 +213,6 @@ struct StreamRegisters {
 // rows' streams, which is harmless; the array ends with a guard of one slot).
 // Absent words read the start of the array and never emit what they decode;
 // lanes past the tile's last piece re-read its last piece.
-template <bool NT>
 __device__ __forceinline__ void issueStreamLoad(
     const TrainedParams& p, uint32_t sourceStart, uint32_t lane, uint32_t round, u32x4& destination)
 {
@@ -231,19 +224,18 @@ __device__ __forceinline__ void issueStreamLoad(
         const uint32_t piece = q - w * piecesPerWord;
         const uint32_t wordStart = __shfl(sourceStart, w * p.lanesPerWord);
         const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
-        destination = loadPiece<NT>(source);
+        destination = loadPiece(source);
     }
 }
 
-template <bool NT>
 __device__ __forceinline__ void issueStreamLoads(
     const TrainedParams& p, const WordMeta& meta, uint32_t lane, uint32_t firstRound, StreamRegisters& v)
 {
     const uint32_t sourceStart = meta.row < p.nRows ? meta.start : 0u;
-    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 0, v.r0);
-    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 1, v.r1);
-    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 2, v.r2);
-    issueStreamLoad<NT>(p, sourceStart, lane, firstRound + 3, v.r3);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 0, v.r0);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 1, v.r1);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 2, v.r2);
+    issueStreamLoad(p, sourceStart, lane, firstRound + 3, v.r3);
 }
 
 // Into the LDS slots (already big-endian dwords, so the decoder extracts bits with plain shifts).
@@ -413,43 +405,11 @@ __device__ __forceinline__ void decodeSegment(
     }
 }
 
-// Measurement switches carried in TrainedParams::debugFlags (MEMB_HIP_DEBUG):
-//   bit 0 skip decode, bit 1 skip output, bit 2 skip the row id / rowMeta / bitstream loads (the
-//   decoder then chews on whatever LDS holds: output values are garbage, the access pattern is kept),
-//   bits 4..6 cache policy of the output stores as a mask (16 = sc0, 32 = sc1, 64 = nt),
-//   bit 7 that policy only for tiles whose rows are consecutive, bits 10..12 the mask of the other tiles,
-//   bit 8 plain instead of non-temporal bitstream and rowMeta loads.
-__device__ __forceinline__ void storeOutput16(float* destination, const float4& value, uint32_t policy)
-{
-    if (policy == 0) {
-        *reinterpret_cast<float4*>(destination) = value;
-        return;
-    }
-    u32x4 bits;
-    bits.x = __float_as_uint(value.x);
-    bits.y = __float_as_uint(value.y);
-    bits.z = __float_as_uint(value.z);
-    bits.w = __float_as_uint(value.w);
-    // (the s_nop keeps the next instruction from overwriting the data registers before the store has read them)
-#define MEMB_HIP_STORE16(BITS) \
-    asm volatile("global_store_dwordx4 %0, %1, off " BITS "\n\ts_nop 1" : : "v"(destination), "v"(bits) : "memory")
-    switch (policy) {
-        case 1: MEMB_HIP_STORE16("sc0"); break;
-        case 2: MEMB_HIP_STORE16("sc1"); break;
-        case 3: MEMB_HIP_STORE16("sc0 sc1"); break;
-        case 4: MEMB_HIP_STORE16("nt"); break;
-        case 5: MEMB_HIP_STORE16("sc0 nt"); break;
-        case 6: MEMB_HIP_STORE16("sc1 nt"); break;
-        default: MEMB_HIP_STORE16("sc0 sc1 nt"); break;
-    }
-#undef MEMB_HIP_STORE16
-}
-
 // Symbol tile -> fp32 rows: codebook gather and row-contiguous stores.
 template <int MODE, bool FAST>
 __device__ __forceinline__ void outputTile(
     const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
-    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present, bool sequentialTile = false)
+    uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
 {
     if (MODE == OUT_KEYS) {
         // rows of a tile are dense in LDS and in the output; absent words carry whatever was
@@ -487,10 +447,6 @@ __device__ __forceinline__ void outputTile(
         absent = __ballot(!present && !role.spare && role.segment == 0 && role.word < tileWords);
     }
     const bool checkWords = FAST && absent != 0;
-    uint32_t storePolicy = (measureFlags(p) >> 4) & 7;   // wave-uniform
-    if (measureFlags(p) & 0x80) {
-        storePolicy = sequentialTile ? storePolicy : (measureFlags(p) >> 10) & 7;
-    }
 
     if (MODE == OUT_FLAT || MODE == OUT_VEC4) {
         // Piece q = 4 consecutive floats; the symbol tile is linear in q for both layouts
@@ -544,7 +500,7 @@ __device__ __forceinline__ void outputTile(
                     if (hasEpilogue) {   // off the common path
                         f[u] = epilogue4(f[u], destination, p.accumulate, p.divisor);
                     }
-                    storeOutput16(destination, f[u], storePolicy);
+                    *reinterpret_cast<float4*>(destination) = f[u];
                 }
             }
         }
@@ -587,13 +543,12 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
 {
     const uint32_t wave = threadIdx.x / WAVE;
     uint32_t* codebookLds = lds + p.tableDwords;
-    const uint32_t slotSets = p.slotSets ? p.slotSets : 1u;
-    const uint32_t perWave = slotSets * p.wordsPerWave * p.slotDwords + p.keyTileDwords;
+    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
     WaveLds result;
     result.table = reinterpret_cast<const TableEntry*>(lds);
     result.codebook = codebookLds;
     result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
-    result.keyTile = result.slots + slotSets * p.wordsPerWave * p.slotDwords;
+    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
 
     const bool copy = !(measureFlags(p) & 0x4000);   // (measurement builds, bit 14: no table / codebook copy)
     for (uint32_t i = threadIdx.x; copy && i < p.tableDwords / 4; i += blockDim.x) {
@@ -608,10 +563,6 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
     return result;
 }
 
-// Stream loads of the kernels that process one tile per wavefront (decode_trained, decode_trained_union):
-// plain. (The persistent kernel has both forms, chosen per launch: memb_hip_ctx_set_option "nt_loads".)
-constexpr bool ONE_TILE_NT_LOADS = false;
-
 // One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
 // keeps the memory system busy. Also builds the segment index (OUT_INDEX).
 // A wavefront decodes p.tilesPerWave tiles one after the other -- tiles wave, wave + W, ... of its block's run of
@@ -625,17 +576,10 @@ __global__ void decode_trained(TrainedParams p)
     constexpr bool PACKED = !FAST && MODE != OUT_INDEX;   // byte keys; the index pass keeps the 8-byte table
     uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
-    uint32_t block = blockIdx.x;
-#ifdef MEMB_HIP_MEASURE
-    if (measureFlags(p) & 0x8000) {
-        // (measurement, bit 15: blocks are dealt round-robin over the 8 XCDs -- give every XCD ONE contiguous run of the
-        // batch instead of every eighth block of it)
-        const uint32_t xcd = block % 8, index = block / 8, whole = gridDim.x / 8, extra = gridDim.x % 8;
-        block = xcd * whole + min(xcd, extra) + index;
-    }
-#endif
+    // (Round 4, batch 4: giving every XCD one contiguous run of the batch instead of every eighth block: +3.2 % on the
+    // key-order dump, +-0 shuffled -- blocks stay dealt out as the dispatcher deals them.)
     unsigned long long tile =
-        static_cast<unsigned long long>(block) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
+        static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     const WaveLds mem = setUpLds<MODE>(p, lds);
     if (tile * p.wordsPerWave >= p.n) {
@@ -653,10 +597,10 @@ __global__ void decode_trained(TrainedParams p)
         // registers and half the resident wavefronts (103 against 52: tools/perf/isa.py).
         asm volatile("" : "+v"(lane));
         const LaneRole role = laneRole(p, lane);
-        WordMeta meta = loadWordMeta<ONE_TILE_NT_LOADS>(p, tileRow, role);
+        WordMeta meta = loadWordMeta(p, tileRow, role);
         unpackMeta(p, role, meta);
         StreamRegisters first = {};   // (defined on every path: otherwise the values are carried around the loop)
-        issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, 0, first);
+        issueStreamLoads(p, meta, lane, 0, first);
         if (step + 1 < p.tilesPerWave) {
             tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
         }
@@ -665,7 +609,7 @@ __global__ void decode_trained(TrainedParams p)
         writeStreams(p, mem.slots, lane, 0, first);
         for (uint32_t round = STREAM_REGISTERS; round < rounds; round += STREAM_REGISTERS) {
             StreamRegisters v = {};
-            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta, lane, round, v);
+            issueStreamLoads(p, meta, lane, round, v);
             writeStreams(p, mem.slots, lane, round, v);
         }
         waveLdsFence();
@@ -684,200 +628,31 @@ __global__ void decode_trained(TrainedParams p)
     }
 }
 
-// Persistent kernel: every wavefront walks tiles wave, wave + W, wave + 2W, ...
-// and keeps three tiles' worth of loads in flight, so that no decode waits for
-// global memory: while tile t is decoded, the bitstream bytes of tile t + 1 sit
-// in registers, the offsets / segment positions of tile t + 2 and the row ids
-// of tile t + 3 are on their way. Each of those hops depends on the previous
-// one (row id -> offset -> stream bytes); issued back to back they are what a
-// one-tile wavefront spends most of its life waiting for.
-#ifdef MEMB_HIP_BOUNDS_WAVES   // measurement builds: register budget for more resident wavefronts
-#define MEMB_HIP_PERSISTENT_BOUNDS __launch_bounds__(MEMB_HIP_BOUNDS_THREADS, MEMB_HIP_BOUNDS_WAVES)
-#else
-#define MEMB_HIP_PERSISTENT_BOUNDS
-#endif
-
-template <bool HAS_SUB, int MODE, bool FAST, bool NT>
-__global__ void MEMB_HIP_PERSISTENT_BOUNDS decode_trained_persistent(TrainedParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr bool PACKED = !FAST;
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
-    const LaneRole role = laneRole(p, lane);
-    // The row ids of the first four tiles before anything else: they depend on nothing, and the copy of
-    // table and codebook into LDS then hides the first of the pipeline's dependent hops (a batch of a few
-    // tiles per wavefront -- 100 000 words -- is mostly prologue).
-    const bool rowsFirst = !(measureFlags(p) & 0x80000);   // (measurement builds, bit 19: the row ids behind the copy)
-    uint32_t row0 = 0, row1 = 0, row2 = 0, rowLoading = 0;
-    if (rowsFirst) {
-        row0 = loadTileRow(p, tile, role);
-        row1 = loadTileRow(p, tile + stride, role);
-        row2 = loadTileRow(p, tile + 2 * stride, role);
-        rowLoading = loadTileRow(p, tile + 3 * stride, role);
-    }
-    const WaveLds mem = setUpLds<MODE>(p, lds);
-    if (!rowsFirst) {
-        row0 = loadTileRow(p, tile, role);
-        row1 = loadTileRow(p, tile + stride, role);
-        row2 = loadTileRow(p, tile + 2 * stride, role);
-        rowLoading = loadTileRow(p, tile + 3 * stride, role);
-    }
-    // Measurement (debugFlags bit 3): the wavefronts of a block meet at a barrier before every
-    // output phase, so that the block's adjacent tiles reach memory together; every wavefront of
-    // the block then makes the same number of rounds (idle ones past the end of the batch).
-    const bool syncOutput = (measureFlags(p) & 8) != 0;
-    unsigned long long blockTile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE);
-    if (syncOutput ? blockTile >= tiles : tile >= tiles) {
-        return;
-    }
-#ifdef MEMB_HIP_MEASURE
-    // Measurement (bits 14..17): a staggered start. Every wavefront begins at the same moment and walks its
-    // tiles in rounds of about the same length, so decode and store phases of the whole chip may stay in step;
-    // bits 14..15: delay unit (1, 2, 4, 8 x ~0.4 us), bit 16: by wavefront of the block, bit 17: by block.
-    if (measureFlags(p) & 0x30000) {
-        const uint32_t unit = 1u << ((measureFlags(p) >> 14) & 3);
-        uint32_t steps = 0;
-        if (measureFlags(p) & 0x10000) {
-            steps += threadIdx.x / WAVE;
-        }
-        if (measureFlags(p) & 0x20000) {
-            steps += blockIdx.x % 4 * (blockDim.x / WAVE);
-        }
-        for (uint32_t i = 0; i < steps * unit; ++i) {
-            __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles = ~0.43 us at 2.4 GHz
-        }
-    }
-#endif
-
-    // prologue: fill the pipeline (these hops are dependent and exposed, once per wavefront)
-    WordMeta meta0 = loadWordMeta<NT>(p, row0, role);
-    WordMeta meta1 = loadWordMeta<NT>(p, row1, role);
-    WordMeta metaLoading = loadWordMeta<NT>(p, row2, role);
-    unpackMeta(p, role, meta0);
-    unpackMeta(p, role, meta1);
-    StreamRegisters streams;
-    issueStreamLoads<NT>(p, meta0, lane, 0, streams);
-    writeStreams(p, mem.slots, lane, 0, streams);
-    issueStreamLoads<NT>(p, meta1, lane, 0, streams);
-    waveLdsFence();
-    recordSegmentBits(p, mem.slots, role, meta0);
-
-    // Invariant at the top, for the current tile t:
-    //   LDS slots hold the bitstreams of t;
-    //   in flight since the end of the previous round: `streams` = stream bytes of t + 1,
-    //   `metaLoading` = offsets of t + 2, `rowLoading` = row ids of t + 3.
-    // In-flight registers are touched at ONE point per round, right after the
-    // decode (which gave them a whole decode to land) and before this round's
-    // stores are issued, so that the wait there is only for loads; the new
-    // loads are the last memory instructions of the round.
-    for (; syncOutput ? blockTile < tiles : tile < tiles; tile += stride, blockTile += stride) {
-        const bool live = tile < tiles;
-        const unsigned long long tileBase = tile * p.wordsPerWave;
-        const uint32_t tileWords =
-            live ? static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase)) : 0u;
-
-        if (live && !(measureFlags(p) & 1)) {
-            decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta0);
-        }
-        waveLdsFence();
-
-        // consume point
-        writeStreams(p, mem.slots, lane, 0, streams);   // bitstreams of t + 1 replace those of t
-        // (copies pinned here: left to the register allocator they move to the loop
-        // header, and the wait for the loads moves with them)
-        WordMeta meta2;
-        uint32_t row3;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.row) : "v"(metaLoading.row));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.start) : "v"(metaLoading.start));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.segmentBits) : "v"(metaLoading.segmentBits));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed2) : "v"(metaLoading.packed2));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(meta2.packed3) : "v"(metaLoading.packed3));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(row3) : "v"(rowLoading));
-        unpackMeta(p, role, meta2);
-        __builtin_amdgcn_sched_barrier(0);
-
-        if (syncOutput) {
-            __syncthreads();
-        }
-        if (live && !(measureFlags(p) & 2)) {
-            // rows of the tile consecutive (a dump in key order, or a run of one)?
-            const uint32_t firstRow = __shfl(meta0.row, 0);
-            const bool sequentialTile = __all(role.spare || meta0.row == firstRow + role.word);
-            outputTile<MODE, FAST>(
-                p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta0.row < p.nRows, sequentialTile);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // next round of loads; each uses what the previous round fetched
-        issueStreamLoads<NT>(p, meta2, lane, 0, streams);          // stream bytes of t + 2
-        metaLoading = loadWordMeta<NT>(p, row3, role);              // offsets of t + 3
-        rowLoading = loadTileRow(p, tile + 4 * stride, role);   // row ids of t + 4
-        meta0 = meta1;
-        meta1 = meta2;
-        waveLdsFence();
-        recordSegmentBits(p, mem.slots, role, meta0);   // the slots hold the next tile since the consume point
-    }
-}
-
 // ---------------------------------------------------------------------------
-// decode_records_persistent: the persistent pipeline for the ROW-RECORD layout only
+// decode_records_persistent: a software pipeline for batches of two to four tiles per resident wavefront
 // ---------------------------------------------------------------------------
-// Every model of the benchmark is staged as row records (TrainedParams::recordPieces): a row's address is
-// arithmetic and its segment offsets arrive with its bitstream, so the pipeline needs no index stage and a
-// tile in flight is its row ids -- nothing else. The general kernel above carries three index records of
-// five registers each and four stream registers whatever the layout (117 VGPRs: 4 wavefronts per SIMD);
-// this one keeps the row ids of three tiles and either
-//   DMA = false  two stream registers (a tile of at most 128 pieces), or
-//   DMA = true   no stream registers at all: the next tile's row regions go from HBM straight into a second
-//                set of LDS slots (`global_load_lds_dwordx4`: each lane names its 16 source bytes, the
-//                wavefront's 1 KiB lands contiguously, so lane q of a round fetches piece q of the slot image),
-// which is what lets twice as many wavefronts stay resident (tools/perf/isa.py prints the registers).
-// Timeline of a round, same as the general kernel: decode tile t out of LDS | wait for the loads issued one
-// decode ago (tile t + 1's streams, tile t + 2's row ids) | store tile t | issue the loads of tile t + 2
-// (row ids of t + 3).
+// The one kernel besides decode_trained that a single model runs (memb_hip.hip: planTrained): batches of 65 000 to
+// 131 000 words on 256 CUs -- BASELINE.json configs[1] -- where every wavefront has two or three tiles and a
+// wavefront with one tile spends its life in the three dependent hops row id -> row region -> decode. Row-record
+// layout only (TrainedParams::recordPieces): a row's address is arithmetic and its segment offsets arrive with its
+// bitstream, so a tile in flight is its row ids and two stream registers (a tile of at most 128 pieces).
+// Timeline of a round: decode tile t out of LDS | wait for the loads issued one decode ago (tile t + 1's regions,
+// tile t + 2's row ids) | store tile t | issue the loads of tile t + 2 (row ids of t + 3). 82 VGPRs: 20 wavefronts
+// per CU. Measured against one tile per wavefront on 100 000 random rows (round 4, batches 1 and 3, two boxes):
+// 4-bit -4.3..-6 %, 6-bit -8..-9 %, 2-bit -1.5 %; everywhere else the one-tile kernel wins or ties.
+// (Rounds 1-3 also had a general persistent pipeline for every layout, an LDS-DMA form of this one and a persistent
+// union: none of them won a BASELINE configuration by 3 % in round 4's table -- DESIGN.md section 5 -- and they are gone.)
 constexpr int RECORD_ROUNDS = 2;   // 64-lane rounds per tile: 8 words x (160-byte region + padding piece) = 88 pieces
 
-template <bool NT>
 __device__ __forceinline__ void issueRecordLoads(
     const TrainedParams& p, uint32_t row, uint32_t lane, u32x4& first, u32x4& second)
 {
     const uint32_t start = row < p.nRows ? row * p.recordPieces : 0u;   // absent words read row 0 and never emit it
-    issueStreamLoad<NT>(p, start, lane, 0, first);
-    issueStreamLoad<NT>(p, start, lane, 1, second);
+    issueStreamLoad(p, start, lane, 0, first);
+    issueStreamLoad(p, start, lane, 1, second);
 }
 
-// LDS-DMA form: piece q of the slot image = 16 bytes of word q / slotPieces; the image is exactly what
-// writeStreams lays out (slots of slotDwords, an odd number of pieces), its padding pieces re-read piece 0
-// of their word (same line as a neighbouring lane's request: no extra traffic).
-__device__ __forceinline__ void issueRecordDma(
-    const TrainedParams& p, uint32_t row, uint32_t lane, uint32_t* slots)
-{
-    const uint32_t start = row < p.nRows ? row * p.recordPieces : 0u;
-    const uint32_t slotPieces = p.slotDwords / 4;
-    const uint32_t totalPieces = p.wordsPerWave * slotPieces;
-#pragma unroll
-    for (int round = 0; round < RECORD_ROUNDS; ++round) {
-        const uint32_t q = round * WAVE + lane;
-        // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
-        const uint32_t w = fastDivide(min(q, totalPieces - 1), p.dmaMagic, slotPieces);
-        const uint32_t wordStart = __shfl(start, w * p.lanesPerWord);
-        if (q < totalPieces) {
-            uint32_t piece = q - w * slotPieces;
-            piece = piece < p.recordPieces ? piece : 0u;
-            const u32x4* source = reinterpret_cast<const u32x4*>(p.streams) + (static_cast<unsigned long long>(wordStart) + piece);
-            // (C-style casts: generic -> global / LDS address spaces)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)source,
-                (__attribute__((address_space(3))) void*)(slots + round * WAVE * 4), 16, 0, 0);
-        }
-    }
-}
-
-template <bool HAS_SUB, int MODE, bool FAST, bool DMA>
+template <bool HAS_SUB, int MODE, bool FAST>
 __global__ void decode_records_persistent(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -887,40 +662,23 @@ __global__ void decode_records_persistent(TrainedParams p)
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
     const LaneRole role = laneRole(p, lane);
-    // row ids before the table copy, which hides their latency (measurement builds, bit 19: behind it)
-    const bool rowsFirst = !(measureFlags(p) & 0x80000);
-    uint32_t rowCurrent = 0, rowNext = 0, rowLoading = 0;
-    if (rowsFirst) {
-        rowCurrent = loadTileRow(p, tile, role);
-        rowNext = loadTileRow(p, tile + stride, role);
-        rowLoading = loadTileRow(p, tile + 2 * stride, role);
-    }
+    // row ids before the table copy, which hides their latency
+    uint32_t rowCurrent = loadTileRow(p, tile, role);
+    uint32_t rowNext = loadTileRow(p, tile + stride, role);
+    uint32_t rowLoading = loadTileRow(p, tile + 2 * stride, role);
     const WaveLds mem = setUpLds<MODE>(p, lds);
     if (tile >= tiles) {
         return;
     }
-    if (!rowsFirst) {
-        rowCurrent = loadTileRow(p, tile, role);
-        rowNext = loadTileRow(p, tile + stride, role);
-        rowLoading = loadTileRow(p, tile + 2 * stride, role);
-    }
-    const uint32_t setDwords = p.wordsPerWave * p.slotDwords;
-    uint32_t* slots = mem.slots;                        // the set being decoded
-    uint32_t* otherSlots = mem.slots + setDwords;       // DMA: the set being filled
-    u32x4 stream0 = {0, 0, 0, 0};                       // !DMA: the next tile's pieces (a tile of at most 64 pieces
+    uint32_t* slots = mem.slots;
+    u32x4 stream0 = {0, 0, 0, 0};                       // the next tile's pieces (a tile of at most 64 pieces
     u32x4 stream1 = {0, 0, 0, 0};                       // never loads the second one)
 
     // prologue
-    if (DMA) {
-        issueRecordDma(p, rowCurrent, lane, slots);
-        issueRecordDma(p, rowNext, lane, otherSlots);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        issueRecordLoads<false>(p, rowCurrent, lane, stream0, stream1);
-        writeStream(p, slots, lane, 0, stream0);
-        writeStream(p, slots, lane, 1, stream1);
-        issueRecordLoads<false>(p, rowNext, lane, stream0, stream1);
-    }
+    issueRecordLoads(p, rowCurrent, lane, stream0, stream1);
+    writeStream(p, slots, lane, 0, stream0);
+    writeStream(p, slots, lane, 1, stream1);
+    issueRecordLoads(p, rowNext, lane, stream0, stream1);
     waveLdsFence();
 
     for (; tile < tiles; tile += stride) {
@@ -938,19 +696,12 @@ __global__ void decode_records_persistent(TrainedParams p)
         }
         waveLdsFence();
 
-        // consume point: everything issued one decode ago
+        // consume point: everything issued one decode ago. (In-flight registers are touched HERE and nowhere else in a
+        // round: a loop-carried copy of a load result is otherwise hoisted to the loop header and drags a vmcnt(0) with it.)
         uint32_t rowAfterNext;
-        if (DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the other set holds tile t + 1 now
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
-            uint32_t* swap = slots;
-            slots = otherSlots;
-            otherSlots = swap;
-        } else {
-            writeStream(p, slots, lane, 0, stream0);
-            writeStream(p, slots, lane, 1, stream1);
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
-        }
+        writeStream(p, slots, lane, 0, stream0);
+        writeStream(p, slots, lane, 1, stream1);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
         __builtin_amdgcn_sched_barrier(0);
 
         if (!(measureFlags(p) & 2)) {
@@ -959,18 +710,11 @@ __global__ void decode_records_persistent(TrainedParams p)
         __builtin_amdgcn_sched_barrier(0);
 
         // the loads of tile t + 2 (its row ids landed a round ago) and the row ids of tile t + 3
-        if (DMA) {
-            issueRecordDma(p, rowAfterNext, lane, otherSlots);   // the set tile t was decoded from
-        } else {
-            issueRecordLoads<false>(p, rowAfterNext, lane, stream0, stream1);
-        }
+        issueRecordLoads(p, rowAfterNext, lane, stream0, stream1);
         rowLoading = loadTileRow(p, tile + 3 * stride, role);
         rowCurrent = rowNext;
         rowNext = rowAfterNext;
         waveLdsFence();
-    }
-    if (DMA) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be landing when the block's LDS is handed on
     }
 }
 
@@ -1222,7 +966,7 @@ __global__ void decode_trained_union(UnionParams u)
     }
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
-        meta[m] = loadWordMeta<ONE_TILE_NT_LOADS>(u.model[m], rows[m], role);
+        meta[m] = loadWordMeta(u.model[m], rows[m], role);
     }
 #pragma unroll
     for (int m = 0; m < COUNT; ++m) {
@@ -1232,7 +976,7 @@ __global__ void decode_trained_union(UnionParams u)
         const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
         for (uint32_t round = 0; round < rounds; round += STREAM_REGISTERS) {
             StreamRegisters v;
-            issueStreamLoads<ONE_TILE_NT_LOADS>(p, meta[m], lane, round, v);
+            issueStreamLoads(p, meta[m], lane, round, v);
             writeStreams(p, slots, lane, round, v);
         }
     }
@@ -1322,7 +1066,7 @@ __global__ void decode_union_split(UnionParams u)
             const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
             if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
                 const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
-                pieces[round] = loadPiece<ONE_TILE_NT_LOADS>(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
+                pieces[round] = loadPiece(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
             }
         }
         const uint32_t rowNow = row;
@@ -1359,116 +1103,6 @@ __global__ void decode_union_split(UnionParams u)
         }
         waveLdsFence();   // (the next tile's regions and symbols go where this one's were)
     }
-}
-
-// The persistent form, for models staged as row records (the pipeline of decode_records_persistent, see
-// there). The unit of the pipeline is (tile, model): a wavefront decodes its tile for model 0, then for
-// model 1, ... -- each into that model's symbol tile, all out of ONE set of bitstream slots (two with
-// LDS-DMA) -- and writes the merged rows after the last model; while unit k is decoded, the row regions of
-// unit k + 1 are in registers (or landing in the other slot set) and the row ids of units k + 2 and k + 3
-// are on their way. The loop body is unrolled over the models, so which model a pipeline stage serves is
-// a compile-time fact.
-template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE, bool DMA>
-__global__ void decode_records_union_persistent(UnionParams u)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const TrainedParams& first = u.model[0];
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
-    const unsigned long long tiles = (first.n + first.wordsPerWave - 1) / first.wordsPerWave;
-    const LaneRole role = laneRole(first, lane);
-
-    // unit k of this wavefront: model k % COUNT of tile `tile + (k / COUNT) * stride`
-    #define UNION_MODEL(k) u.model[(k) % COUNT]
-    #define UNION_TILE(base, k) ((base) + static_cast<unsigned long long>((k) / COUNT) * stride)
-
-    // row ids of the first three units before the copy of tables and codebooks, which hides their latency
-    uint32_t rowCurrent = loadTileRow(UNION_MODEL(0), UNION_TILE(tile, 0), role);
-    uint32_t rowNext = loadTileRow(UNION_MODEL(1), UNION_TILE(tile, 1), role);
-    uint32_t rowLoading = loadTileRow(UNION_MODEL(2), UNION_TILE(tile, 2), role);
-    setUpUnionLds<COUNT>(u, lds);
-    if (tile >= tiles) {
-        return;
-    }
-    uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
-    uint32_t* slots = waveLds + u.slotOffsetDwords[0];          // the set being decoded
-    uint32_t* otherSlots = waveLds + u.slotOffsetDwords[1];     // DMA: the set being filled
-    u32x4 stream0 = {0, 0, 0, 0};                                // !DMA: the next unit's pieces
-    u32x4 stream1 = {0, 0, 0, 0};
-
-    if (DMA) {
-        issueRecordDma(UNION_MODEL(0), rowCurrent, lane, slots);
-        issueRecordDma(UNION_MODEL(1), rowNext, lane, otherSlots);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        issueRecordLoads<false>(UNION_MODEL(0), rowCurrent, lane, stream0, stream1);
-        writeStream(UNION_MODEL(0), slots, lane, 0, stream0);
-        writeStream(UNION_MODEL(0), slots, lane, 1, stream1);
-        issueRecordLoads<false>(UNION_MODEL(1), rowNext, lane, stream0, stream1);
-    }
-    waveLdsFence();
-
-    AbsentMasks absent;
-    for (; tile < tiles; tile += stride) {
-        const unsigned long long tileBase = tile * first.wordsPerWave;
-        const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(first.wordsPerWave), first.n - tileBase));
-#pragma unroll
-        for (int m = 0; m < COUNT; ++m) {
-            // invariant: `slots` hold the row regions of unit (tile, m); unit + 1 in registers / landing in the
-            // other set, the row ids of unit + 2 landed, those of unit + 3 in flight
-            WordMeta meta;
-            meta.row = rowCurrent;
-            meta.start = 0;
-            meta.packed2 = 0;
-            meta.packed3 = 0;
-            recordSegmentBits(u.model[m], slots, role, meta);
-            if (!(measureFlags(first) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
-                decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
-                    u.model[m], reinterpret_cast<const TableEntry*>(lds + u.tableOffsetDwords[m]), slots,
-                    waveLds + u.keyTileOffsetDwords[m], role, meta);
-            }
-            absent.set(m, __ballot(!(rowCurrent < u.model[m].nRows) && !role.spare && role.segment == 0 && role.word < tileWords));
-            waveLdsFence();
-
-            // consume point: everything issued one decode ago
-            uint32_t rowAfterNext;
-            if (DMA) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                uint32_t* swap = slots;
-                slots = otherSlots;
-                otherSlots = swap;
-            } else {
-                writeStream(UNION_MODEL(m + 1), slots, lane, 0, stream0);
-                writeStream(UNION_MODEL(m + 1), slots, lane, 1, stream1);
-            }
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfterNext) : "v"(rowLoading));
-            __builtin_amdgcn_sched_barrier(0);
-
-            if (m == COUNT - 1 && !(measureFlags(first) & 2)) {
-                // (the symbol tiles are read here and rewritten by the next units' decodes: same wavefront, in order)
-                outputUnionTile<FAST, COUNT, AVERAGE>(u, lds, waveLds, tileBase, tileWords, lane, absent);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-
-            if (DMA) {
-                issueRecordDma(UNION_MODEL(m + 2), rowAfterNext, lane, otherSlots);
-            } else {
-                issueRecordLoads<false>(UNION_MODEL(m + 2), rowAfterNext, lane, stream0, stream1);
-            }
-            rowLoading = loadTileRow(UNION_MODEL(m + 3), UNION_TILE(tile, m + 3), role);
-            rowCurrent = rowNext;
-            rowNext = rowAfterNext;
-            waveLdsFence();
-        }
-    }
-    if (DMA) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be landing when the block's LDS is handed on
-    }
-    #undef UNION_MODEL
-    #undef UNION_TILE
 }
 
 // Staging: streamStarts + segmentIndex -> rowMeta records (see TrainedParams::rowMeta). One thread per row.

@@ -22,8 +22,10 @@
 // written out row contiguous, 16 bytes per lane, so every store instruction
 // covers whole 16-byte-aligned runs of output rows. G lanes per word divide
 // the LDS needed per lane in flight by G, which is what bounds occupancy.
-// The production kernel is the persistent, software-pipelined form of this
-// (decode_trained_persistent, hip_trained_kernels.h); DESIGN.md section 5 has the
+// One tile per wavefront at a time and short-lived blocks: the hardware's dispatch keeps the
+// memory system busier than any persistent pipeline did (rounds 1-3 built three; round 4
+// measured them out: planTrained below). The one pipeline left, decode_records_persistent,
+// serves batches of two to four tiles per 16 wavefronts per CU. DESIGN.md section 5 has the
 // measurements behind every choice.
 //
 // Files: hip_device_common.h, hip_trained_kernels.h, hip_rowwise_kernels.h -- device
@@ -54,7 +56,6 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr uint32_t MISSING = MEMB_HIP_MISSING_ROW;
-constexpr uint64_t BIG_BATCH_RESIDENT_MULTIPLE = 16;   // batches of more tiles than this x 16 wavefronts per CU: kernel chosen by timing
 constexpr uint32_t ZERO_KEY = 255;  // codebook slot that always holds 0.0f: at most 255 centroids exist
                                     // (reference src/trained_compression.cpp:29)
 
@@ -112,21 +113,12 @@ uint32_t envUint(const char* name, uint32_t fallback)
 struct Switches {
     uint32_t waves = 0;            // MEMB_HIP_WAVES: force the wavefronts per block (0 = choose)
     uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
-    uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 0 = one tile per wavefront always, 1 = by batch size (one tile per
-                                   // wavefront while every tile finds a free wavefront slot), 2 = the persistent pipeline always
-    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of nibble-key models with row
-                                   // records: 0 = never, 1 = whenever the pair qualifies (every batch size: batch 32)
-    bool ntLoads = false;          // MEMB_HIP_NT_LOADS: non-temporal loads of bitstreams and index records (persistent kernel)
-    uint32_t blocksPerCu = 0;      // MEMB_HIP_BLOCKS_PER_CU: cap on the persistent kernel's resident blocks per CU (0 = all that fit)
-    uint32_t pipeline = 3;         // MEMB_HIP_PIPELINE: persistent kernel of row-record models: 0 = the general one,
-                                   // 1 = decode_records_persistent with stream registers, 2 = with LDS-DMA, 3 = by batch size
-    uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: 0 = persistent kernels take the resident wavefront slots and walk all
-                                   // tiles; K = a grid of tiles / K wavefronts, each walks ~K tiles and exits (short-lived wavefronts
-                                   // with a pipeline: between one tile per wavefront and the persistent form)
-    bool autotune = true;          // MEMB_HIP_AUTOTUNE: the first large batch times both kernels for large batches (launchTrained)
-    uint32_t gridPolicy = 0;       // MEMB_HIP_GRID_POLICY: 0 = every resident wavefront slot; 1 = the fewest wavefronts that
-                                   // make the same number of rounds, so that all of them walk the same number of tiles
-                                   // (measured: 0 is 0.5-1 % faster on every batch kind, 2.7 % on the union: profiles/r03_experiments.txt)
+    uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 1 = the kernel by batch size (planTrained); 0 = one tile per wavefront
+                                   // always, 2 = decode_records_persistent whenever the layout allows (tests, measurements)
+    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of models with row records:
+                                   // 0 = never, 1 = whenever the pair qualifies
+    uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: tiles a wavefront of the one-tile kernels decodes one after the
+                                   // other: 0 = by rule (oneTileSteps), K = K (measurements)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -169,9 +161,6 @@ struct memb_hip_ctx {
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
     char unionKernel[96] = {0};            // what the last union launch with this context as its first model ran
-    float bigBatchMs[2] = {0.f, 0.f};      // what that timing read: persistent, one tile per wavefront (ms per launch)
-    std::atomic<int> bigBatchKernel{-1};   // batches of more than 16 tiles per resident wavefront: -1 = not timed yet,
-                                         // 0 = the persistent pipeline, 1 = one tile per wavefront (launchTrained)
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
     uint32_t segmentSymbols = 0;         // S: symbols per lane, multiple of 4
     std::vector<uint32_t> streamBytes;   // per row, host side (reporting only)
@@ -254,35 +243,34 @@ uint32_t packedTableDwords(const memb_hip_ctx* ctx)
 }
 
 // withKeys: a lookup kernel (symbol tiles; byte-key models then use the PACKED layout); without: the index pass
-uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys, uint32_t slotSets = 1)
+uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t wordsPerWave, bool withKeys)
 {
-    uint32_t perWave = slotSets * wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
+    uint32_t perWave = wordsPerWave * ctx->slotDwords + (withKeys ? keyTileDwords(ctx, wordsPerWave) : 0);
     if (withKeys && !ctx->fast) {
         return 4u * (packedTableDwords(ctx) + codebookDwords(ctx) + waves * perWave);
     }
     return 4u * (ctx->tableDwords + codebookDwords(ctx) + waves * perWave);
 }
 
-// Waves per block: as many resident wavefronts per CU as LDS allows (the
-// decode is a chain of dependent LDS lookups, so occupancy is what hides it);
-// on ties blocks of four wavefronts (measured against eight on one allocation,
-// A/A floor 0.5 %: key-order dump -1.3 %, shuffled -0.9 %, 100 k rows -1.2 %,
-// two-model union -3.4 %; profiles/r03_experiments.txt), then larger ones.
-// slotSets: sets of bitstream slots per wavefront (2 for the LDS-DMA pipeline). registerWavesPerCu: how many
-// wavefronts of the kernel about to be launched its registers let a CU hold (32 when unknown): a block size
-// whose LDS would allow more resident wavefronts than the registers do gains nothing by it.
+// Waves per block: as many resident wavefronts per CU as LDS allows (the decode is a chain of dependent LDS
+// lookups, so occupancy is what hides it); on ties blocks of four wavefronts, then larger ones. `preferred`
+// (planTrained: eight for the dumps of nibble-key models) wins a tie instead; MEMB_HIP_WAVES / option
+// waves_per_block forces a size. registerWavesPerCu: how many wavefronts of the kernel about to be launched its
+// registers let a CU hold (32 when unknown): a block size whose LDS would allow more resident wavefronts than the
+// registers do gains nothing by it.
 TrainedGeometry chooseGeometry(
-    const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out, uint32_t slotSets = 1,
-    uint32_t registerWavesPerCu = 32)
+    const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out,
+    uint32_t registerWavesPerCu = 32, uint32_t preferred = 4)
 {
     TrainedGeometry best{};
     double bestWaves = -1;
-    const uint32_t forcedWaves = ctx->switches.waves;
-    for (uint32_t waves : {4u, 8u, 2u, 1u}) {
+    const uint32_t forcedWaves = ctx->switches.waves;   // (1, 2, 4, 8 or, measurements only, 16)
+    const uint32_t order[5] = {forcedWaves ? forcedWaves : preferred, 4u, 8u, 2u, 1u};
+    for (uint32_t waves : order) {
         if (forcedWaves && waves != forcedWaves) {
             continue;
         }
-        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true, slotSets);
+        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true);
         if (ldsBytes > ctx->ldsLimit) {
             continue;
         }
@@ -332,43 +320,28 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
 
 typedef void (*TrainedKernel)(TrainedParams);
 
-// Which persistent kernel serves a context: pipeline 0 = decode_trained_persistent (any layout),
-// 1 = decode_records_persistent with stream registers, 2 = the same with LDS-DMA (row records only).
-template <bool HAS_SUB, int MODE, bool FAST>
-TrainedKernel persistentKernelOf(uint32_t pipeline, bool ntLoads)
-{
-    switch (pipeline) {
-        case 1:
-            return &decode_records_persistent<HAS_SUB, MODE, FAST, false>;
-        case 2:
-            return &decode_records_persistent<HAS_SUB, MODE, FAST, true>;
-        default:
-            return ntLoads ? &decode_trained_persistent<HAS_SUB, MODE, FAST, true>
-                           : &decode_trained_persistent<HAS_SUB, MODE, FAST, false>;
-    }
-}
-
+// decode_records_persistent as instantiated for a context and an output mode.
 template <int MODE>
-TrainedKernel persistentKernelOfMode(const memb_hip_ctx* ctx, uint32_t pipeline)
+TrainedKernel recordsKernelOfMode(const memb_hip_ctx* ctx)
 {
     if (ctx->fast) {
-        return persistentKernelOf<false, MODE, true>(pipeline, ctx->switches.ntLoads);
+        return &decode_records_persistent<false, MODE, true>;
     }
-    return ctx->byteTable.hasSubTables ? persistentKernelOf<true, MODE, false>(pipeline, ctx->switches.ntLoads)
-                                       : persistentKernelOf<false, MODE, false>(pipeline, ctx->switches.ntLoads);
+    return ctx->byteTable.hasSubTables ? &decode_records_persistent<true, MODE, false>
+                                       : &decode_records_persistent<false, MODE, false>;
 }
 
-TrainedKernel persistentKernel(const memb_hip_ctx* ctx, int mode, uint32_t pipeline)
+TrainedKernel recordsKernel(const memb_hip_ctx* ctx, int mode)
 {
     switch (mode) {
         case OUT_FLAT:
-            return persistentKernelOfMode<OUT_FLAT>(ctx, pipeline);
+            return recordsKernelOfMode<OUT_FLAT>(ctx);
         case OUT_VEC4:
-            return persistentKernelOfMode<OUT_VEC4>(ctx, pipeline);
+            return recordsKernelOfMode<OUT_VEC4>(ctx);
         case OUT_KEYS:
-            return persistentKernelOfMode<OUT_KEYS>(ctx, pipeline);
+            return recordsKernelOfMode<OUT_KEYS>(ctx);
         default:
-            return persistentKernelOfMode<OUT_SCALAR>(ctx, pipeline);
+            return recordsKernelOfMode<OUT_SCALAR>(ctx);
     }
 }
 
@@ -455,23 +428,8 @@ hipError_t launchPersistentGeneric(
         }
     }
     // as many blocks as are resident at once; each wavefront strides over the tiles
-    uint32_t perCu = static_cast<uint32_t>(blocksPerCu);
-    if (ctx->switches.blocksPerCu) {
-        perCu = std::min(perCu, ctx->switches.blocksPerCu);
-    }
-    const uint32_t resident = perCu * ctx->cuCount;
-    uint32_t blocks = std::min(tileBlocks, resident);
-    if (ctx->switches.gridPolicy == 1 && tileBlocks > resident) {
-        // Wavefront w walks tiles w, w + W, w + 2 W, ...: with every slot taken, a batch of 3.05 tiles per slot
-        // leaves a few wavefronts a fourth tile to do alone at the end. The same number of rounds with fewer
-        // wavefronts gives all of them the same work (to within one tile). (Measured: no gain; kept as an option.)
-        const uint32_t rounds = (tileBlocks + resident - 1) / resident;
-        blocks = (tileBlocks + rounds - 1) / rounds;
-    }
-    if (ctx->switches.tilesPerWave) {
-        blocks = std::max(blocks, (tileBlocks + ctx->switches.tilesPerWave - 1) / ctx->switches.tilesPerWave);
-    }
-    launch(blocks);
+    const uint32_t resident = static_cast<uint32_t>(blocksPerCu) * ctx->cuCount;
+    launch(std::min(tileBlocks, resident));
     return hipGetLastError();
 }
 
@@ -527,204 +485,101 @@ struct Epilogue {
     float divisor = 0.f;
 };
 
-// Tiles a wavefront of the one-tile kernels (decode_trained, decode_union_split) decodes one after the other.
-uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles)
+// Tiles a wavefront of the one-tile kernels (decode_trained, decode_union_split) decodes one after the other, behind
+// ONE copy of table(s) and codebook(s) into LDS per block. Measured (round 4, batches 2-4; `copyBytes` = what a block
+// copies): the copy is 2.8 % of a 4-bit dump (4 KiB) and more than it gains back there (T = 2: -0.9 % / +1.9 % key order
+// / shuffled, T = 4: +3.6 %), 8.6 % of the split union (8 KiB for 4 tiles of 4 words: T = 2..4 -4 % at 250 k words, -7 %
+// at 500 k, -9 % at 1 M; +8 % at 100 k, where the grid gets too small), and what made the 8-bit model (33 KiB) the last
+// customer of the general persistent kernel (T = 2: dumps +0.1..0.3 % against it, 500 k rows -1.5 %).
+uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyBytes, bool unionSplit)
 {
-    (void)tiles;
-    return std::max<uint32_t>(1, std::min<uint32_t>(ctx->switches.tilesPerWave, 64));
+    if (ctx->switches.tilesPerWave) {
+        return std::min<uint32_t>(ctx->switches.tilesPerWave, 64);
+    }
+    const uint64_t slots = uint64_t(ctx->cuCount) * 32;   // resident wavefronts of the one-tile kernels
+    if (unionSplit) {
+        return tiles >= 6 * slots ? 2u : 1u;
+    }
+    return copyBytes >= 16 * 1024 && tiles >= 2 * slots ? 2u : 1u;
 }
 
 // Which kernel a batch of this output shape runs, and with what launch geometry.
 struct TrainedPlan {
-    bool persistent = false;
-    uint32_t pipeline = 0;               // 0 general, 1 records + stream registers, 2 records + LDS-DMA
+    bool persistent = false;             // decode_records_persistent (else decode_trained)
     TrainedGeometry geometry{};
     TrainedKernel kernel = nullptr;      // persistent only
     uint32_t registerWavesPerCu = 32;    // persistent only: what the kernel's registers allow
     int numRegs = 0;
 };
 
+constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below (times the CUs)
+
 // (the context's device is current)
-// Which kernel by batch size (n words), measured on one allocation per model against an A/A floor of 0.5 %
-// (profiles/r03_experiments.txt, batches 4 and 5; 2-, 4- and 6-bit models; t = tiles, R = the general persistent
-// kernel's resident wavefronts, 16 per CU):
-//   t <= 2 R       one tile per wavefront (decode_trained: 52 VGPRs, up to 32 wavefronts per CU, nothing to pipeline):
-//                  10 000 words -17..-19 % against the persistent kernel, 35 000-65 000 words -3..-7 % against
-//                  decode_records_persistent (batch 29)
-//   2 R < t <= 4 R decode_records_persistent (row records only; 82 VGPRs, 20 wavefronts per CU, a prologue of one hop):
-//                  80 000-130 000 words 0..-8 % against one tile per wavefront, -3..-10 % against the general kernel
-//   4 R < t <= 16 R one tile per wavefront again: 160 000-500 000 words -3..-17 % against both persistent kernels (the
-//                  outputs of these batches no longer fit the 256 MB Infinity Cache, and the hardware's dispatch
-//                  balances the wavefronts over a memory system that has become the bound)
-//   above          decode_trained_persistent at 16 wavefronts per CU (every step of occupancy above that costs the
-//                  dumps 1-15 %: 20 / 24 / 28 wavefronts +3 / +4 / +13 %, every step below it more) or one tile per
-//                  wavefront, settled per context by timing
-// (the context's device is current)
-//   The "above" class: on 2- and 6-bit models the one-tile kernel beats the
-//   persistent one by 2-14 % on every box and in every row order, on the 4-bit model it loses the key-order dump by
-//   3-6 % on four boxes of seven, wins it by 3-4 % on two, and wins shuffled rows by 2-4 % -- so the first large batch a
-//   context sees runs both on that very batch (same bits either way) and keeps the faster: ctx->bigBatchKernel.
-// force: -1 = by the rules above, 0 = one tile per wavefront, 1 = persistent
+// Which kernel by batch size (n words): a STATIC rule. t = tiles of the batch, R = 16 x CUs. Round 4 measured every
+// kernel of rounds 1-3 on every model kind (2-, 4-, 6-bit, byte-key 4-bit, Student-t 4-bit; key order, shuffled, 100 k,
+// 500 k; tools/perf/r4/batch1.sh, two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
+//   decode_trained (one tile per wavefront at a time, 52-61 VGPRs, 32 wavefronts per CU) -- everything, except
+//   2 R < t <= 4 R on row-record models: decode_records_persistent (20 wavefronts per CU, software pipeline):
+//       100 000 rows -4.3..-6 % (4-bit), -8..-9 % (6-bit), -1.5 % (2-bit); at 500 k rows it is 3-11 % BEHIND.
+// The general persistent pipeline lost every dump (+2.3 % 4-bit, +4.9 % 2-bit; 6-bit -1.8 % on one box) and every
+// shuffled batch (+1.7..+9.4 %); with it went the per-context timing that chose between the two ("autotune").
+// Block size: four wavefronts; EIGHT for batches of more than 16 R tiles of nibble-key models -- dumps: the reference's
+// own large batch is keys() in key order (python/memb/reader.py:27-28) -- measured on two boxes: 4-bit key order
+// -3.7 / -4.1 %, 2-bit -6.2 %, Student-t like 4-bit; byte-key models +-0.6 % (6-bit) and -2.4 % / +3.5 % (9-bit code),
+// so they keep four. The price: full-size batches in SHUFFLED order +1.2..1.8 % (4-bit; 2-bit -2.1 %).
+// force: -1 = by the rule, 0 = one tile per wavefront, 1 = decode_records_persistent where the layout allows
 int planTrained(
     const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
-    const uint64_t generalResident = uint64_t(ctx->cuCount) * 16;
-    // The persistent kernel keeps one tile's bitstreams in registers; tiles wider than that
-    // (long streams with few lanes per word) take the one-shot kernel.
-    const uint32_t tilePieces = wordsPerWave * (ctx->recordPieces ? ctx->recordPieces : ctx->slotDwords / 4);
-    // Row records have a pipeline of their own (decode_records_persistent): 1 = stream registers, 2 = LDS-DMA;
-    // both need the tile's slot image to fit two 64-lane rounds.
-    const bool recordsKernel = ctx->recordPieces && ctx->switches.pipeline && wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
-    bool wantPersistent = ctx->switches.persistent == 2;
-    if (ctx->switches.persistent == 1) {
-        if (tiles > BIG_BATCH_RESIDENT_MULTIPLE * generalResident) {
-            wantPersistent = ctx->bigBatchKernel.load(std::memory_order_relaxed) != 1;
-        } else {
-            wantPersistent = recordsKernel && tiles > 2 * generalResident && tiles <= 4 * generalResident;
-        }
-    }
+    const uint64_t R = uint64_t(ctx->cuCount) * PIPELINE_WAVES_PER_CU;
+    // the pipeline keeps a tile's row regions in two registers per lane: the slot image must fit two 64-lane rounds
+    const bool recordsFit = ctx->recordPieces && wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
+    bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > 2 * R && tiles <= 4 * R);
     if (force >= 0) {
         wantPersistent = force != 0;
     }
-    plan->persistent = (tilePieces + WAVE - 1) / WAVE <= STREAM_REGISTERS && wantPersistent;
-    plan->pipeline = 0;
-    if (plan->persistent && recordsKernel) {
-        plan->pipeline = ctx->switches.pipeline == 3 ? (tiles <= 4 * generalResident ? 1u : 0u) : ctx->switches.pipeline;
-    }
-    const uint32_t slotSets = plan->pipeline == 2 ? 2 : 1;
-    plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, slotSets);
+    plan->persistent = recordsFit && wantPersistent;
+    const uint32_t preferred = !plan->persistent && ctx->fast && tiles > 16 * R ? 8u : 4u;
+    plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, 32, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;
     }
     if (plan->persistent && plan->geometry.waves) {
         // again with what the kernel's registers allow (a block size whose LDS would hold more wavefronts than
         // the registers admit is no better than a smaller one)
-        plan->kernel = persistentKernel(ctx, plan->geometry.mode, plan->pipeline);
+        plan->kernel = recordsKernel(ctx, plan->geometry.mode);
         hipError_t status = registerWavesPerCu(plan->kernel, &plan->registerWavesPerCu, &plan->numRegs);
         if (status != hipSuccess) {
             return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
         }
         const int mode = plan->geometry.mode;
-        plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, slotSets, plan->registerWavesPerCu);
+        plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, plan->registerWavesPerCu);
         plan->geometry.mode = mode;
     }
     return MEMB_HIP_OK;
 }
 
 // keysOut: `out` receives rows of centroid indices (OUT_KEYS) instead of fp32 rows; ld = dim, colOff = 0.
+// Enqueues one kernel on `stream` and returns.
 int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
-    const Epilogue& epilogue, bool keysOut = false, int force = -1);
-
-// The first large batch of a context: both kernels on that very batch, ALTERNATING, every launch between its own pair
-// of events, all enqueued without a gap and waited for once; the first RUN_IN pairs are not counted, the rest are
-// summed. Two things this has to get right (both seen): three launches of one kernel and then three of the other is
-// not a measurement -- after an idle gap this part runs launches 3 to ~25 of a burst about 10 % slower than later ones
-//  and the kernel timed second lost every time; and twelve alternating launches still sit inside
-// that transient, where the two kernels tie on models on which the one-tile kernel is 3-10 % faster once the part has
-// settled (batch 8) -- hence a run-in of 13 pairs (~15 ms). The persistent kernel is kept if it is at least 1.5 % faster.
-// The batch is decoded 34 times instead of once -- the same bits every time -- and the call waits for the device this
-// once (~20 ms for a 2.2 M-word dump; a context's staging takes 50 times that).
-int timeBigBatchKernels(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream)
-{
-    constexpr int ROUNDS = 17;
-    constexpr int RUN_IN = 13;
-    hipEvent_t events[ROUNDS][2][2] = {};
-    hipError_t status = hipSuccess;
-    for (int round = 0; round < ROUNDS && status == hipSuccess; ++round) {
-        for (int kind = 0; kind < 2 && status == hipSuccess; ++kind) {
-            for (int edge = 0; edge < 2 && status == hipSuccess; ++edge) {
-                status = hipEventCreate(&events[round][kind][edge]);
-            }
-        }
-    }
-    int code = status == hipSuccess ? MEMB_HIP_OK : fail(MEMB_HIP_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(status));
-    for (int round = 0; round < ROUNDS && code == MEMB_HIP_OK; ++round) {
-        for (int kind = 0; kind < 2 && code == MEMB_HIP_OK; ++kind) {   // 0 = persistent, 1 = one tile per wavefront
-            status = hipEventRecord(events[round][kind][0], stream);
-            code = launchTrained(ctx, rows, n, out, ld, colOff, stream, Epilogue(), false, kind == 0 ? 1 : 0);
-            if (status == hipSuccess) {
-                status = hipEventRecord(events[round][kind][1], stream);
-            }
-            if (status != hipSuccess && code == MEMB_HIP_OK) {
-                code = fail(MEMB_HIP_ERR_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(status));
-            }
-        }
-    }
-    float ms[2] = {0.f, 0.f};
-    if (code == MEMB_HIP_OK) {
-        status = hipEventSynchronize(events[ROUNDS - 1][1][1]);
-        for (int round = RUN_IN; round < ROUNDS && status == hipSuccess; ++round) {
-            for (int kind = 0; kind < 2 && status == hipSuccess; ++kind) {
-                float one = 0.f;
-                status = hipEventElapsedTime(&one, events[round][kind][0], events[round][kind][1]);
-                ms[kind] += one;
-            }
-        }
-        if (status != hipSuccess) {
-            code = fail(MEMB_HIP_ERR_DEVICE, std::string("timing the kernels: ") + hipGetErrorString(status));
-        }
-    } else {
-        (void)hipStreamSynchronize(stream);
-    }
-    for (auto& round : events) {
-        for (auto& kind : round) {
-            for (hipEvent_t event : kind) {
-                if (event) {
-                    (void)hipEventDestroy(event);
-                }
-            }
-        }
-    }
-    if (code == MEMB_HIP_OK) {
-        ctx->bigBatchMs[0] = ms[0] / (ROUNDS - RUN_IN);
-        ctx->bigBatchMs[1] = ms[1] / (ROUNDS - RUN_IN);
-        // (a tie goes to the one-tile kernel: what is timed is one batch in one row order, and on rows in random order
-        // the one-tile kernel is the faster one on every model measured -- by 2.5-7 % on 2.2 M rows, batches 25 and 29)
-        ctx->bigBatchKernel.store(ms[0] < 0.985f * ms[1] ? 0 : 1, std::memory_order_relaxed);
-        if (ctx->switches.verbose) {
-            std::fprintf(stderr, "memb_hip: large batches: persistent %.4f ms, one tile per wavefront %.4f ms per launch -> %s\n",
-                         ms[0] / (ROUNDS - RUN_IN), ms[1] / (ROUNDS - RUN_IN), ctx->bigBatchKernel.load() ? "one tile per wavefront" : "persistent");
-        }
-    }
-    return code;
-}
-
-int launchTrained(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
-    const Epilogue& epilogue, bool keysOut, int force)
+    const Epilogue& epilogue, bool keysOut = false, int force = -1)
 {
     const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-    if (force < 0 && ctx->switches.persistent == 1 && ctx->switches.autotune && !keysOut && !epilogue.accumulate &&
-        epilogue.divisor == 0.f && ctx->bigBatchKernel.load(std::memory_order_relaxed) < 0 &&
-        (n + wordsPerWave - 1) / wordsPerWave > BIG_BATCH_RESIDENT_MULTIPLE * ctx->cuCount * 16) {
-        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
-            (void)hipGetLastError();
-            capture = hipStreamCaptureStatusActive;   // (the legacy stream while another one captures: leave it alone)
-        }
-        if (capture == hipStreamCaptureStatusNone) {
-            return timeBigBatchKernels(ctx, rows, n, out, ld, colOff, stream);   // (the batch is decoded by it)
-        }
-    }
     TrainedPlan plan;
     int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
     const bool persistent = plan.persistent;
-    const uint32_t pipeline = plan.pipeline;
     TrainedGeometry geometry = plan.geometry;
     TrainedKernel kernel = plan.kernel;
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
     TrainedParams params = baseTrainedParams(ctx);
-    params.slotSets = pipeline == 2 ? 2 : 1;
-    params.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -758,7 +613,7 @@ int launchTrained(
             params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
             uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
             (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
-            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true, params.slotSets) &&
+            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
             (ctx->fast || (params.table != nullptr && params.tableDwords >= (1u << params.rootBits))) &&
             geometry.ldsBytes <= ctx->ldsLimit && ld >= colOff + params.dim;
         if (!consistent) {
@@ -766,21 +621,15 @@ int launchTrained(
         }
     }
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
-    uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
     const uint32_t threads = geometry.waves * WAVE;
     hipError_t status;
-    if (!persistent) {
-        params.tilesPerWave = oneTileSteps(ctx, tiles);
-        const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
-        blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
-    }
     if (persistent) {
+        const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
         status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
     } else {
-        // (blocks_per_cu also caps the residency of the one-tile kernel: LDS it does not use keeps further blocks off a CU)
-        if (ctx->switches.blocksPerCu) {
-            geometry.ldsBytes = std::max<uint32_t>(geometry.ldsBytes, ctx->ldsLimit / ctx->switches.blocksPerCu / 1024 * 1024);
-        }
+        params.tilesPerWave = oneTileSteps(ctx, tiles, 4u * (params.tableDwords + params.codebookDwords), false);
+        const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
+        const uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
         switch (geometry.mode) {
             case OUT_FLAT:
                 status = launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
@@ -804,15 +653,9 @@ int launchTrained(
 
 typedef void (*UnionKernel)(UnionParams);
 
-// pipeline: 0 = one tile per wavefront, 1 = persistent with stream registers, 2 = persistent with LDS-DMA
-// (both persistent forms: two models staged as row records)
 template <bool HAS_SUB, bool FAST, bool AVERAGE>
-UnionKernel unionKernelOf(size_t count, uint32_t pipeline)
+UnionKernel unionKernelOf(size_t count)
 {
-    if (pipeline) {
-        return pipeline == 2 ? &decode_records_union_persistent<HAS_SUB, FAST, 2, AVERAGE, true>
-                             : &decode_records_union_persistent<HAS_SUB, FAST, 2, AVERAGE, false>;
-    }
     switch (count) {
         case 2:
             return &decode_trained_union<HAS_SUB, FAST, 2, AVERAGE>;
@@ -823,15 +666,15 @@ UnionKernel unionKernelOf(size_t count, uint32_t pipeline)
     }
 }
 
-UnionKernel unionKernel(bool hasSub, bool fast, bool average, size_t count, uint32_t pipeline)
+UnionKernel unionKernel(bool hasSub, bool fast, bool average, size_t count)
 {
     if (fast) {
-        return average ? unionKernelOf<false, true, true>(count, pipeline) : unionKernelOf<false, true, false>(count, pipeline);
+        return average ? unionKernelOf<false, true, true>(count) : unionKernelOf<false, true, false>(count);
     }
     if (hasSub) {
-        return average ? unionKernelOf<true, false, true>(count, pipeline) : unionKernelOf<true, false, false>(count, pipeline);
+        return average ? unionKernelOf<true, false, true>(count) : unionKernelOf<true, false, false>(count);
     }
-    return average ? unionKernelOf<false, false, true>(count, pipeline) : unionKernelOf<false, false, false>(count, pipeline);
+    return average ? unionKernelOf<false, false, true>(count) : unionKernelOf<false, false, false>(count);
 }
 
 // See memb_hip_decode_rows_union_device. MEMB_HIP_UNSUPPORTED when the models cannot share the kernel.
@@ -875,15 +718,6 @@ int launchTrainedUnion(
     const uint32_t wordsPerWave = WAVE / first->lanesPerWord;
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
 
-    // The persistent pipeline keeps one unit's bitstreams in registers (as the single-model kernel does)
-    // and pays its prologue once per wavefront: used when every model's tile fits and there is more than
-    // one tile per resident wavefront to amortise it over.
-    bool persistent = first->switches.persistent && count == 2;
-    for (size_t m = 0; m < count; ++m) {
-        persistent = persistent && ctxs[m]->recordPieces && wordsPerWave * (ctxs[m]->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
-    }
-    const bool dma = first->switches.pipeline == 2;
-
     UnionParams params{};
     uint32_t sharedDwords = 0;
     for (size_t m = 0; m < count; ++m) {
@@ -913,7 +747,6 @@ int launchTrainedUnion(
             }
         }
         p.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * count * (ctx->dim / 4));
-        p.dmaMagic = magicFor(ctx->slotDwords / 4, uint64_t(RECORD_ROUNDS) * WAVE);
         p.debugFlags = first->switches.debugFlags;   // (measurement builds: the first reader's switches for all)
         params.tableOffsetDwords[m] = sharedDwords;
         sharedDwords += p.tableDwords;
@@ -924,26 +757,12 @@ int launchTrainedUnion(
     params.rowPieces = (average ? 1u : static_cast<uint32_t>(count)) * (first->dim / 4);
     params.rowMagic = magicFor(params.rowPieces, uint64_t(wordsPerWave) * params.rowPieces);
 
-    // one wavefront's LDS area
-    auto layOut = [&](bool sharedSlots) {
+    // one wavefront's LDS area in decode_trained_union: bitstream slots and a symbol tile per model
+    auto layOut = [&] {
         uint32_t at = 0;
-        if (sharedSlots) {
-            uint32_t slotDwords = 0;
-            for (size_t m = 0; m < count; ++m) {
-                slotDwords = std::max(slotDwords, wordsPerWave * ctxs[m]->slotDwords);
-                params.slotOffsetDwords[m] = 0;
-            }
-            at = roundUp4(slotDwords);
-            if (dma) {   // a second set, filled by LDS-DMA while the first is decoded (slotOffsetDwords[1]: count == 2)
-                params.slotOffsetDwords[1] = at;
-                at *= 2;
-            }
-        }
         for (size_t m = 0; m < count; ++m) {
-            if (!sharedSlots) {
-                params.slotOffsetDwords[m] = at;
-                at += roundUp4(wordsPerWave * ctxs[m]->slotDwords);
-            }
+            params.slotOffsetDwords[m] = at;
+            at += roundUp4(wordsPerWave * ctxs[m]->slotDwords);
             params.keyTileOffsetDwords[m] = at;
             at += roundUp4(params.model[m].keyTileDwords);
         }
@@ -980,7 +799,7 @@ int launchTrainedUnion(
 
     // decode_union_split: two models staged as row records -- the wavefront's word slots are divided
     // between the models, a tile is half as many words, LDS per wavefront as in the single-model kernel.
-    // Against the forms below (nibble keys, batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k - 1 M -1.5..-3 %.
+    // Against decode_trained_union (nibble keys, round 3 batch 32): 10 k words -20 %, 30 k -14 %, 100 k -10 %, 500 k -9 %.
     bool split = count == 2 && first->switches.unionSplit != 0 && wordsPerWave % 2 == 0 &&
         ((wordsPerWave / 2) * params.model[0].keyRowBytes) % 4 == 0;
     // the slots take the geometry of the model with the larger row regions; the other model's loads then run up to as
@@ -1015,7 +834,7 @@ int launchTrainedUnion(
         }
         if (waves) {
             const size_t splitTiles = (n + half - 1) / half;
-            sp.model[2].tilesPerWave = oneTileSteps(first, splitTiles);
+            sp.model[2].tilesPerWave = oneTileSteps(first, splitTiles, 4u * shared, true);
             const size_t perBlock = size_t(waves) * sp.model[2].tilesPerWave;
             {
                 std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
@@ -1036,53 +855,33 @@ int launchTrainedUnion(
         // (does not fit: the forms below lay their areas out afresh)
         registerWaves = 32;
     }
-    // One tile per wavefront below 16 tiles per CU's worth of wavefronts (32 k words on 256 CUs). Measured (batch 31):
-    // 30 k words a tie, 60 k words the persistent form 14 % ahead, 100 k - 1 M words 4-7 % ahead.
-    if (persistent && first->switches.persistent != 2 && tiles < 1ull * first->cuCount * 16) {
-        persistent = false;
+    // decode_trained_union, one tile per wavefront: three or four models, pairs without row records
+    layOut();
+    kernel = unionKernel(hasSub, allFast, average, count);
+    hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
     }
-    for (int attempt = 0; attempt < 2 && !waves; ++attempt) {
-        layOut(persistent);
-        kernel = unionKernel(hasSub, allFast, average, count, persistent ? (dma ? 2u : 1u) : 0u);
-        hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
-        if (status != hipSuccess) {
-            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
-        }
-        chooseWaves(sharedDwords, params.perWaveDwords, registerWaves, &waves, &ldsBytes);
-        if (!waves && persistent) {
-            persistent = false;   // the one-tile kernel's layout may still fit
-        } else {
-            break;
-        }
-    }
+    chooseWaves(sharedDwords, params.perWaveDwords, registerWaves, &waves, &ldsBytes);
     if (!waves) {
         return fail(MEMB_HIP_UNSUPPORTED, "union kernel: tables and bitstream slots of the models do not fit into LDS together");
     }
     const uint32_t threads = waves * WAVE;
     const uint32_t tileBlocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
-    hipError_t status;
-    if (persistent) {
-        status = launchPersistentGeneric(
-            first, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
-            }, tileBlocks, threads, ldsBytes);
-    } else {
-        {
-            std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
-            KernelFacts* facts = nullptr;
-            status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
-        }
-        if (status == hipSuccess) {
-            hipLaunchKernelGGL(kernel, dim3(tileBlocks), dim3(threads), ldsBytes, stream, params);
-            status = hipGetLastError();
-        }
+    {
+        std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
+        KernelFacts* facts = nullptr;
+        status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
+    }
+    if (status == hipSuccess) {
+        hipLaunchKernelGGL(kernel, dim3(tileBlocks), dim3(threads), ldsBytes, stream, params);
+        status = hipGetLastError();
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_union launch: ") + hipGetErrorString(status));
     }
-    std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "%s<%s, %s, %zu, %s%s>",
-                  persistent ? "decode_records_union_persistent" : "decode_trained_union", hasSub ? "true" : "false",
-                  allFast ? "true" : "false", count, average ? "true" : "false", persistent ? (dma ? ", true" : ", false") : "");
+    std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_trained_union<%s, %s, %zu, %s>",
+                  hasSub ? "true" : "false", allFast ? "true" : "false", count, average ? "true" : "false");
     return MEMB_HIP_OK;
 }
 
@@ -1380,11 +1179,6 @@ Switches readSwitches()
 #endif
     switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
     switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
-    switches.ntLoads = envUint("MEMB_HIP_NT_LOADS", switches.ntLoads ? 1 : 0) != 0;
-    switches.blocksPerCu = envUint("MEMB_HIP_BLOCKS_PER_CU", 0);
-    switches.gridPolicy = envUint("MEMB_HIP_GRID_POLICY", switches.gridPolicy);
-    switches.pipeline = std::min<uint32_t>(envUint("MEMB_HIP_PIPELINE", switches.pipeline), 3);
-    switches.autotune = envUint("MEMB_HIP_AUTOTUNE", 1) != 0;
     switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
@@ -2052,27 +1846,12 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
     }
     const std::string key(name);
     std::lock_guard<std::mutex> lock(ctx->mutex);
-    if (key == "nt_loads" && value <= 1) {
-        ctx->switches.ntLoads = value != 0;
-    } else if (key == "waves_per_block" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) {
+    if (key == "waves_per_block" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {
         ctx->switches.waves = static_cast<uint32_t>(value);
-    } else if (key == "blocks_per_cu" && value <= 32) {
-        ctx->switches.blocksPerCu = static_cast<uint32_t>(value);
-    } else if (key == "autotune" && value <= 2) {
-        // 0 / 1: off / on; 2: forget what was measured (the next large batch times the kernels again)
-        if (value == 2) {
-            ctx->bigBatchKernel.store(-1, std::memory_order_relaxed);
-        } else {
-            ctx->switches.autotune = value != 0;
-        }
-    } else if (key == "tiles_per_wave" && value <= 65536) {
+    } else if (key == "tiles_per_wave" && value <= 64) {
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {
         ctx->switches.unionSplit = static_cast<uint32_t>(value);
-    } else if (key == "pipeline" && value <= 3) {
-        ctx->switches.pipeline = static_cast<uint32_t>(value);
-    } else if (key == "grid_policy" && value <= 1) {
-        ctx->switches.gridPolicy = static_cast<uint32_t>(value);
     } else if (key == "persistent" && value <= 2) {
         ctx->switches.persistent = static_cast<uint32_t>(value);
     } else if (key == "host_expand" && value <= 1) {
@@ -2095,7 +1874,6 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
     info->dim = ctx->dim;
     info->n_rows = ctx->nRows;
     info->device_bytes = ctx->deviceBytes;
-    info->large_batch_kernel = -1;
     if (ctx->storage == memb::wire::Storage_Trained) {
         const memb::DecodeTable& table = ctx->fast ? ctx->hostTable : ctx->byteTable;   // the lookup kernels' table
         info->root_bits = table.rootBits;
@@ -2114,9 +1892,6 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         }
         const TrainedGeometry geometry = plan.geometry;
         info->waves_per_block = geometry.waves;
-        info->large_batch_kernel = ctx->bigBatchKernel.load(std::memory_order_relaxed);
-        info->large_batch_persistent_ms = ctx->bigBatchMs[0];
-        info->large_batch_one_tile_ms = ctx->bigBatchMs[1];
         std::snprintf(info->union_kernel, sizeof(info->union_kernel), "%s", ctx->unionKernel);
         info->kernel_registers = static_cast<uint32_t>(plan.numRegs);
         info->register_waves_per_cu = plan.persistent ? plan.registerWavesPerCu : 0;
@@ -2126,13 +1901,17 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         info->row_layout = ctx->recordPieces ? 2u : (ctx->rowMeta ? 1u : 0u);
         info->row_bytes = ctx->recordPieces * 16;
         // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys, ...>
-        const char* name = !plan.persistent ? "decode_trained" : plan.pipeline ? "decode_records_persistent" : "decode_trained_persistent";
-        const char* last = !plan.persistent ? "" : plan.pipeline ? (plan.pipeline == 2 ? ", true" : ", false")
-                                                                 : (ctx->switches.ntLoads ? ", true" : ", false");
         std::snprintf(
-            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s%s>", name,
+            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", plan.persistent ? "decode_records_persistent" : "decode_trained",
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
-            ctx->fast ? "true" : "false", last);
+            ctx->fast ? "true" : "false");
+        if (!plan.persistent) {
+            const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+            const uint64_t words = batchWords ? batchWords : uint64_t(1) << 30;
+            info->tiles_per_wavefront = oneTileSteps(
+                ctx, (words + wordsPerWave - 1) / wordsPerWave,
+                4u * ((ctx->fast ? ctx->tableDwords : packedTableDwords(ctx)) + codebookDwords(ctx)), false);
+        }
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
         const uint32_t uniformWordsPerWave = std::min<uint32_t>(WAVE, UNIFORM_ROUNDS * WAVE / std::max<uint32_t>(ctx->regionPieces, 1));

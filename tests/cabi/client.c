@@ -62,9 +62,9 @@ int main(void)
     printf("error: %s\n", memb_hip_last_error());
     {
         /* memb_hip_ctx_get_info fills no more than the caller's struct_size: a client built against an older, shorter
-           struct (here: up to large_batch_kernel) must find the bytes behind it untouched */
+           struct (here: up to tiles_per_wavefront) must find the bytes behind it untouched */
         union { memb_hip_ctx_info info; unsigned char bytes[sizeof(memb_hip_ctx_info)]; } whole, older;
-        const size_t old_size = offsetof(memb_hip_ctx_info, large_batch_kernel);
+        const size_t old_size = offsetof(memb_hip_ctx_info, tiles_per_wavefront);
         size_t k;
         memset(&whole, 0, sizeof whole);
         whole.info.struct_size = sizeof(memb_hip_ctx_info);

@@ -32,7 +32,7 @@ def test_abi_version_and_options_without_compute(native):
     header = open(os.path.join(REPO, 'include', 'memb_hip.h')).read()
     assert library.memb_hip_abi_version() == int(re.search(r'#define MEMB_HIP_ABI_VERSION (\d+)', header).group(1))
     library.memb_hip_last_error.restype = ctypes.c_char_p
-    assert library.memb_hip_ctx_set_option(None, b'nt_loads', ctypes.c_uint64(1)) == 1   # MEMB_HIP_ERR_INVALID
+    assert library.memb_hip_ctx_set_option(None, b'persistent', ctypes.c_uint64(1)) == 1   # MEMB_HIP_ERR_INVALID
     assert library.memb_hip_ctx_get_info(None, None) == 1
 
 

@@ -63,14 +63,11 @@ def test_full_vocabulary_dump(native, full_model):
 
 def expected_kernel_class(tiles, resident):
     """The kernel a dense batch of `tiles` tiles runs with default options (memb_hip.hip planTrained; DESIGN.md
-    section 5 table "kernel by batch size"): resident = 16 wavefronts per CU."""
-    if tiles <= 2 * resident:
-        return ('decode_trained<',)
-    if tiles <= 4 * resident:
-        return ('decode_records_persistent<',)
-    if tiles <= 16 * resident:
-        return ('decode_trained<',)
-    return ('decode_trained<', 'decode_trained_persistent<')   # settled per context by timing
+    section 5 "which kernel owns which configuration"): resident = 16 wavefronts per CU x CUs; blocks of four
+    wavefronts, eight for batches of more than 16 x resident tiles of a nibble-key model."""
+    if 2 * resident < tiles <= 4 * resident:
+        return 'decode_records_persistent<', None
+    return 'decode_trained<', 8 if tiles > 16 * resident else 4
 
 
 def test_default_path_of_every_batch_size_class(native, full_model):
@@ -89,15 +86,16 @@ def test_default_path_of_every_batch_size_class(native, full_model):
 
     def check(rows, label):
         tiles = (len(rows) + words_per_tile - 1) // words_per_tile
-        kernel = reader.info(len(rows))['kernel']
-        assert kernel.startswith(expected_kernel_class(tiles, resident)), (label, len(rows), kernel)
+        info = reader.info(len(rows))
+        family, waves = expected_kernel_class(tiles, resident)
+        assert info['kernel'].startswith(family), (label, len(rows), info['kernel'])
+        assert waves is None or info['waves_per_block'] == waves, (label, len(rows), info['waves_per_block'])
         ids = torch.from_numpy(rows.view(np.int32)).cuda()
         out = torch.full((len(rows), 300), 7.0, dtype=torch.float32, device='cuda')
         reader.rows_embedding_device(ids, out=out)
         torch.cuda.synchronize()
-        assert reader.info(len(rows))['kernel'].startswith(expected_kernel_class(tiles, resident)), label
-        assert bits_equal(out.cpu().numpy(), checker.rows_embedding(rows)), (label, len(rows), kernel)
-        return kernel
+        assert bits_equal(out.cpu().numpy(), checker.rows_embedding(rows)), (label, len(rows), info['kernel'])
+        return info['kernel']
 
     # configs[1]: bench.py's batch_rows(count, 100000)
     rng = np.random.default_rng(11)
@@ -232,8 +230,8 @@ def _dump_against_checker(native, path, centroid_limit):
         expected = checker.rows_embedding(np.arange(start, stop, dtype=np.uint32))
         assert bits_equal(out[start:stop].cpu().numpy(), expected), (start, stop)
     assert torch.unique(out).numel() <= centroid_limit
-    # the reverse dump with the OTHER kernel for large batches (the first dump timed both and kept one)
-    reader.set_option('persistent', 0 if 'persistent' in reader.info()['kernel'] else 2)
+    # the reverse dump with the OTHER kernel a single model can run (decode_records_persistent where the layout allows)
+    reader.set_option('persistent', 2)
     backwards = reader.rows_embedding_device(torch.flip(rows, dims=(0,)).contiguous())
     torch.cuda.synchronize()
     reader.set_option('persistent', 1)
@@ -247,9 +245,8 @@ def test_fasttext_shaped_6bit_full_dump(native):
     count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', 1999995))
     path, _ = synthetic.cached_model(count, 300, 'trained', 6)
     reader, _ = _dump_against_checker(native, path, 64)
-    # (the first full-size batch timed both kernels for large batches on this context and kept the faster)
-    assert reader.info()['kernel'].startswith(('decode_trained_persistent<', 'decode_trained<'))
-    for forced, name in ((2, 'decode_trained_persistent<'), (0, 'decode_trained<')):
+    assert reader.info()['kernel'].startswith('decode_trained<')
+    for forced, name in ((2, 'decode_records_persistent<'), (0, 'decode_trained<')):
         reader.set_option('persistent', forced)
         assert reader.info()['kernel'].startswith(name)
 

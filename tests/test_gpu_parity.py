@@ -898,16 +898,17 @@ def test_host_results_written_with_non_temporal_stores(native, make_model, monke
 
 
 @pytest.mark.parametrize('bits,distribution', [(4, 'normal'), (2, 'normal'), (6, 'student'), (8, 'student')])
-def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distribution):
-    """decode_records_persistent (option 'pipeline': 1 = stream registers, 2 = LDS-DMA) against the general
-    persistent kernel and the checker: dense rows, strided rows, unaligned output (scalar stores), host
-    batches (centroid indices over PCIe) and ragged / tiny batches, with missing rows in every one."""
+def test_every_kernel_of_a_model_produces_the_same_rows(native, make_model, bits, distribution):
+    """The kernels a single trained model can run -- decode_trained with one, two and five tiles per wavefront
+    (option 'tiles_per_wave') in blocks of 4 and 8 wavefronts, and decode_records_persistent (option 'persistent' = 2)
+    -- against the checker: dense rows, strided rows, unaligned output (scalar stores), host batches (centroid indices
+    over PCIe) and ragged / tiny batches, with missing rows in every one."""
     import torch
     path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
     checker = oracle.OracleReader(path)
     reader = native.Reader(path, device=0)
-    assert reader.info()['row_layout'] == 2   # row records: the layout these kernels are for
-    reader.set_option('persistent', 2)        # the persistent kernels whatever the batch size (default: by size)
+    has_records = reader.info()['row_layout'] == 2   # (the 8-bit model's rows are too long for row records)
+    assert has_records == (bits <= 6)
     rng = np.random.default_rng(bits)
     for count in (20000, 4097, 9, 1):
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)
@@ -916,30 +917,34 @@ def test_record_pipelines_produce_the_same_rows(native, make_model, bits, distri
             rows[:12000] = np.arange(12000, dtype=np.uint32)   # a key-order run as well
         expected = checker.rows_embedding(rows)
         ids = torch.from_numpy(rows.view(np.int32)).cuda()
-        for pipeline in (0, 1, 2):
-            reader.set_option('pipeline', pipeline)
-            name = reader.info()['kernel']
-            # (rows too long for two 64-lane rounds per tile -- the 8-bit model -- stay on the general kernel)
-            if pipeline == 0 or bits <= 4:
-                assert name.startswith('decode_records_persistent' if pipeline else 'decode_trained_persistent'), name
+        for persistent, steps, waves in ((0, 1, 0), (0, 2, 8), (0, 5, 4), (2, 0, 0), (1, 0, 0)):
+            reader.set_option('persistent', persistent)
+            reader.set_option('tiles_per_wave', steps)
+            reader.set_option('waves_per_block', waves)
+            name = reader.info(count)['kernel']
+            if persistent != 1:
+                assert name.startswith('decode_records_persistent<' if persistent == 2 and has_records else 'decode_trained<'), name
+            setting = (persistent, steps, waves, count)
             dense = reader.rows_embedding_device(ids)
-            assert bits_equal(dense.cpu().numpy(), expected), (pipeline, count)
+            assert bits_equal(dense.cpu().numpy(), expected), setting
             wide = torch.full((count, 640), 7.0, dtype=torch.float32, device='cuda')
             reader.rows_embedding_device(ids, out=wide, col_off=320)
-            assert bits_equal(wide[:, 320:620].cpu().numpy(), expected), (pipeline, count)
+            assert bits_equal(wide[:, 320:620].cpu().numpy(), expected), setting
             assert bool((wide[:, :320] == 7.0).all()) and bool((wide[:, 620:] == 7.0).all())
             odd = torch.zeros((count, 301), dtype=torch.float32, device='cuda')   # rows not 16-byte aligned: scalar stores
             reader.rows_embedding_device(ids, out=odd, col_off=1)
-            assert bits_equal(odd[:, 1:].cpu().numpy(), expected), (pipeline, count)
-            assert bits_equal(reader.rows_embedding(rows), expected), (pipeline, count)   # host buffers
-    reader.set_option('pipeline', 0)
+            assert bits_equal(odd[:, 1:].cpu().numpy(), expected), setting
+            assert bits_equal(reader.rows_embedding(rows), expected), setting   # host buffers
+    reader.set_option('persistent', 1)
+    reader.set_option('tiles_per_wave', 0)
+    reader.set_option('waves_per_block', 0)
 
 
 @pytest.mark.parametrize('bits_a,bits_b,seed_b', [(4, 4, 1234), (6, 8, 1234), (2, 4, 1234), (4, 4, 99), (4, 6, 99), (6, 6, 5)])
-def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
-    """decode_records_union_persistent (batches of at least one tile per resident wavefront -- 32 k words on 256 CUs; option 'pipeline' of the
-    first reader: 2 = LDS-DMA, else stream registers) and the one-tile kernel ('persistent' = 0) against numpy over the
-    checker's rows: concatenation and average, words missing from either model."""
+def test_union_kernels(native, make_model, bits_a, bits_b, seed_b):
+    """decode_union_split (two models staged as row records: the wavefront's word slots divided between them; one and
+    three tiles per wavefront) and decode_trained_union ('union_split' = 0, or pairs that do not qualify) against numpy
+    over the checker's rows: concatenation and average, words missing from either model."""
     import torch
     from memb_amd import _memb
     path_a, words_a = make_model(20000, 300, 'trained', bits_a, seed=1234)
@@ -952,7 +957,7 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
     formats = {reader.info()['kernel'].split('<')[1].split(',')[2].strip(' >') for reader in readers}
     assert len(formats) == (2 if seed_b == 99 else 1), formats
     rng = np.random.default_rng(bits_a * 10 + bits_b)
-    batch = 90001   # 11 251 tiles: more than two per resident wavefront (256 CUs x 16), the last tile ragged
+    batch = 90001   # the last tile ragged
     rows = []
     for count in (20000, 15000):
         picks = rng.integers(0, count, size=batch).astype(np.uint32)
@@ -961,40 +966,37 @@ def test_persistent_union_kernels(native, make_model, bits_a, bits_b, seed_b):
     expected = [checker.rows_embedding(picks) for checker, picks in zip(checkers, rows)]
     ids = [torch.from_numpy(picks.view(np.int32)).cuda() for picks in rows]
     stream = torch.cuda.current_stream().cuda_stream
-    # union_split: decode_union_split (two nibble-key models with row records of one size: the wavefront's word slots
-    # divided between the models) -- 1 = whenever the pair qualifies (others fall through to the forms below), 0 = never
-    for persistent, pipeline, split in ((1, 3, 1), (2, 1, 0), (2, 2, 0), (0, 0, 0), (1, 3, 0)):
-        readers[0].set_option('persistent', persistent)
-        readers[0].set_option('pipeline', pipeline)
+    for split, steps in ((1, 0), (1, 1), (1, 3), (0, 0)):
         readers[0].set_option('union_split', split)
+        readers[0].set_option('tiles_per_wave', steps)
         merged = torch.full((batch, 600), 3.0, dtype=torch.float32, device='cuda')
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 300], batch,
                                           merged.data_ptr(), 600, stream, False)
-        assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (persistent, pipeline, split)
+        assert bits_equal(merged.cpu().numpy(), np.concatenate(expected, axis=1)), (split, steps)
         ran = readers[0].info()['union_kernel']   # what that launch was
         # (the 8-bit model's row regions are too long for a tile of eight to fit two 64-lane rounds of pieces)
         if split and max(bits_a, bits_b) <= 6 and all(reader.info()['row_layout'] == 2 for reader in readers):
             # row records: also with regions of different sizes (2-bit + 4-bit), byte keys (6-bit + 6-bit) and mixed key formats
             assert ran.startswith('decode_union_split<'), ran
-        elif persistent == 0:
+        else:
             assert ran.startswith('decode_trained_union<'), ran
-        elif max(bits_a, bits_b) <= 6:
-            assert ran.startswith('decode_records_union_persistent<'), ran     # (the 8-bit model has no row records)
         mean = torch.full((batch, 300), 3.0, dtype=torch.float32, device='cuda')
         assert _memb.union_rows_to_device([r._impl for r in readers], [t.data_ptr() for t in ids], [0, 0], batch,
                                           mean.data_ptr(), 300, stream, True)
-        assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (persistent, pipeline, split)
+        assert bits_equal(mean.cpu().numpy(), np.mean(expected, axis=0)), (split, steps)
     # small and ragged batches through the split kernel (a tile is four words there)
     readers[0].set_option('union_split', 1)
-    for small in (1, 3, 4, 5, 517):
-        merged = torch.full((small, 640), 3.0, dtype=torch.float32, device='cuda')
-        assert _memb.union_rows_to_device([r._impl for r in readers], [t[:small].contiguous().data_ptr() for t in ids], [320, 0], small,
-                                          merged.data_ptr(), 640, stream, False)
-        got = merged.cpu().numpy()
-        assert bits_equal(np.ascontiguousarray(got[:, 320:620]), expected[0][:small]), small
-        assert bits_equal(np.ascontiguousarray(got[:, 0:300]), expected[1][:small]), small
-        assert (got[:, 300:320] == 3.0).all() and (got[:, 620:] == 3.0).all()
-    readers[0].set_option('union_split', 1)
+    for steps in (0, 2):
+        readers[0].set_option('tiles_per_wave', steps)
+        for small in (1, 3, 4, 5, 517):
+            merged = torch.full((small, 640), 3.0, dtype=torch.float32, device='cuda')
+            assert _memb.union_rows_to_device([r._impl for r in readers], [t[:small].contiguous().data_ptr() for t in ids], [320, 0], small,
+                                              merged.data_ptr(), 640, stream, False)
+            got = merged.cpu().numpy()
+            assert bits_equal(np.ascontiguousarray(got[:, 320:620]), expected[0][:small]), small
+            assert bits_equal(np.ascontiguousarray(got[:, 0:300]), expected[1][:small]), small
+            assert (got[:, 300:320] == 3.0).all() and (got[:, 620:] == 3.0).all()
+    readers[0].set_option('tiles_per_wave', 0)
 
 
 def test_union_split_with_first_levels_of_different_widths(native, make_model):

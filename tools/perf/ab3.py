@@ -1,6 +1,6 @@
 """Interleaved A/B of kernel variants on ONE Reader (one allocation), with an A/A control.
 
-    AB3='nt:nt_loads=1,w4:waves_per_block=4' python tools/perf/ab3.py
+    AB3='t2:tiles_per_wave=2,w8:waves_per_block=8' python tools/perf/ab3.py
 
 Why: tools/perf/ab2.py gave every variant a Reader -- and so a 351 MB stream array -- of its own, and two
 variants that were IDENTICAL machine code differed by 2-4 % in every round: it measured where
@@ -36,8 +36,8 @@ run_in_ms = float(os.environ.get('AB3_RUN_IN_MS', '20'))
 cases = os.environ.get('AB3_CASES', 'sorted,random,100k').split(',')
 placement = int(os.environ.get('AB3_PLACEMENT', '0'))
 out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
-DEFAULTS = {'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': 0, 'nt_loads': int(os.environ.get('MEMB_HIP_NT_LOADS', '0')), 'waves_per_block': 0, 'blocks_per_cu': 0,
-            'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1')), 'pipeline': int(os.environ.get('MEMB_HIP_PIPELINE', '3')), 'grid_policy': int(os.environ.get('MEMB_HIP_GRID_POLICY', '0'))}
+DEFAULTS = {'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': int(os.environ.get('MEMB_HIP_TILES_PER_WAVE', '0')), 'waves_per_block': 0,
+            'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1'))}
 
 print('package: %s   model: %d words, %d-bit seed %s %s   rounds %d x %d launches after %.0f ms run-in' % (
     os.path.dirname(memb_amd.__file__), n, bits, os.environ.get('AB3_SEED', '1234'), os.environ.get('AB3_DIST', 'normal'), rounds, reps, run_in_ms), flush=True)

@@ -14,7 +14,6 @@ count = int(os.environ.get('PH_WORDS', '100000'))
 generator = torch.Generator(device='cuda'); generator.manual_seed(5)
 rows = torch.randperm(n, device='cuda', generator=generator)[:count].to(torch.int32).contiguous()
 out = torch.empty((count, 300), dtype=torch.float32, device='cuda')
-reader.set_option('autotune', 0)
 for key, value in (('persistent', os.environ.get('PH_PERSISTENT')), ('debug', os.environ.get('PH_DEBUG'))):
     if value not in (None, ''):
         reader.set_option(key, int(value))

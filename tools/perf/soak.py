@@ -21,8 +21,8 @@ while time.time()-start < seconds:
     reader=memb_amd.Reader(path)
     if rng.random()<0.5 and 'trained' in reader._impl.storage_name():
         # round 3: the kernels are chosen by batch size; force other choices now and then (results never depend on them)
-        reader.set_option('pipeline', int(rng.integers(0,4))); reader.set_option('persistent', int(rng.integers(0,3)))
-        reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8]))); reader.set_option('blocks_per_cu', int(rng.choice([0,0,2,5])))
+        reader.set_option('tiles_per_wave', int(rng.choice([0,0,1,2,3,7]))); reader.set_option('persistent', int(rng.integers(0,3)))
+        reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
     for _ in range(int(rng.integers(1,6))):
         n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
@@ -44,7 +44,7 @@ while time.time()-start < seconds:
     if rng.random()<0.3:
         a=memb_amd.Reader(models[0][0]); b=memb_amd.Reader(models[1][0])
         pool=models[0][1][:2000]+models[1][1][:2000]
-        if rng.random()<0.5: a.set_option('pipeline', int(rng.integers(0,4)))
+        if rng.random()<0.5: a.set_option('tiles_per_wave', int(rng.choice([0,1,2,3])))
         a.set_option('union_split', int(rng.integers(0,2))); a.set_option('persistent', int(rng.integers(0,3)))
         batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000,90000])))]
         for mode in ('concatenate','average'):

@@ -907,8 +907,10 @@ def test_every_kernel_of_a_model_produces_the_same_rows(native, make_model, bits
     path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
     checker = oracle.OracleReader(path)
     reader = native.Reader(path, device=0)
-    has_records = reader.info()['row_layout'] == 2   # (the 8-bit model's rows are too long for row records)
-    assert has_records == (bits <= 6)
+    assert reader.info()['row_layout'] == 2   # row records
+    # (the 8-bit model's row regions are too long for a tile of eight to fit the pipeline's two 64-lane rounds of pieces:
+    # it runs decode_trained whatever is asked for)
+    has_records = bits <= 6
     rng = np.random.default_rng(bits)
     for count in (20000, 4097, 9, 1):
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)

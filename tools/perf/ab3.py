@@ -195,6 +195,23 @@ def run_case(reader, case, target):
         return timeit(lambda: reader.rows_embedding_device(rows, out=target), cold)
     if kind == 'random':
         return timeit(lambda: reader.rows_embedding_device(perm, out=target), cold)
+    if kind.startswith('rot'):
+        # 'rot<N>k': FOUR different batches of N thousand random rows round-robin into four output buffers -- more than the
+        # 256 MB Infinity Cache holds from one turn to the next at 100 k rows: every launch reads from and writes to HBM
+        count = int(kind[3:-1]) * 1000
+        if kind not in rotating:
+            sets = []
+            for k in range(4):
+                ids = perm[(300000 + k * count) % (n - count):][:count].contiguous()
+                sets.append((ids, torch.empty((count, 300), dtype=torch.float32, device='cuda')))
+            rotating[kind] = (sets, [0])
+        sets, turn = rotating[kind]
+
+        def call():
+            ids, target_k = sets[turn[0] % 4]
+            turn[0] += 1
+            reader.rows_embedding_device(ids, out=target_k)
+        return timeit(call, cold)
     if kind not in batches:   # any '<N>k': N thousand random rows
         count = int(kind[:-1]) * 1000
         batches[kind] = perm[1000000:1000000 + count].contiguous()
@@ -203,6 +220,7 @@ def run_case(reader, case, target):
     return timeit(lambda: reader.rows_embedding_device(batch, out=view), cold)
 
 
+rotating = {}
 results = {}   # (variant, case) -> [median of each round]
 started = time.time()
 for rnd in range(rounds):

@@ -646,6 +646,22 @@ def measure_union(reader_a, path_a, reader_b, path_b, timer, library, torch, np,
     }
 
 
+def recorded_traffic(results, names):
+    """HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json: rocprofv3 passes over each workload, tools/perf/prof.sh)
+    next to the algorithmic bytes of every configuration that has them; static, like roofline.traffic of the main line."""
+    path = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    if not os.path.exists(path):
+        return
+    with open(path) as f:
+        recorded = json.load(f)
+    for entry in results:
+        for prefix, key in names:
+            if entry['workload'].startswith(prefix) and recorded.get(key) is not None and 'algorithmic_bytes' in entry:
+                entry['traffic'] = recorded[key]
+                entry['traffic_over_algorithmic'] = recorded[key] / entry['algorithmic_bytes']
+                entry['traffic_source'] = 'static: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over --workload {})'.format(key)
+
+
 def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, sizes):
     """Every BASELINE.json configuration, measured on cuda:0 outside the timed region."""
     glove, fasttext = sizes
@@ -732,6 +748,10 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
         'uniform-8bit-500k', 'full dump of a 500 000-word uniform 8-bit model (bit-exact dequantisation, four IEEE fp32 operations per weight)',
         reader, path, np.arange(len(reader), dtype=np.uint32), timer, library, torch, np))
     del reader
+    if not args.small:
+        recorded_traffic(results, (('glove840b-300d-4bit-100k', 'glove840b-300d-4bit-100k'), ('fasttext2m-300d-6bit-fullvocab', 'fasttext2m-300d-6bit-fullvocab'),
+                                   ('glove840b-300d-2bit-fullvocab (', 'glove840b-300d-2bit-fullvocab'), ('union-concat', 'union-concat-500k'),
+                                   ('uniform-8bit-500k', 'uniform-8bit-500k')))
     return results, build_seconds
 
 

@@ -1026,7 +1026,8 @@ __global__ void decode_union_split(UnionParams u)
     const uint32_t measure = measureFlags(u.model[0]);   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
     const uint32_t totalPieces = both.wordsPerWave * both.loadPieces;
 
-    // the lane's row of tile `ofTile`: checked against the lane's model, MISSING for absent words and past the batch
+    // the lane's row id of tile `ofTile` as the batch has it (MISSING past the batch end): the load only -- `checked`
+    // compares it with the lane's model when the id is used, a tile later, so that nothing waits for it here
     auto loadRow = [&](unsigned long long ofTile, uint32_t ofLane) -> uint32_t {
         const LaneRole role = laneRole(both, ofLane);
         const bool upper = role.word >= half;
@@ -1035,11 +1036,47 @@ __global__ void decode_union_split(UnionParams u)
         if (!role.spare && index < both.n && !(measure & 4)) {
             const uint32_t* ids = upper ? u.model[1].rows : u.model[0].rows;
             row = ids ? ids[index] : static_cast<uint32_t>(index);
-            row = row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
         }
         return row;
     };
+    auto checked = [&](uint32_t row, uint32_t ofLane) -> uint32_t {
+        const bool upper = laneRole(both, ofLane).word >= half;
+        return row < (upper ? u.model[1].nRows : u.model[0].nRows) ? row : MISSING;
+    };
+    // the row regions of all eight (word, model) pairs of a tile: piece q of the slot image belongs to word slot
+    // q / loadPieces (regions of the lane's model; when the models' regions differ in size, `both` has the larger slot
+    // geometry and the smaller model's slots take a few pieces of the following row along, as every compact-layout load does)
+    auto issueRegions = [&](uint32_t ofRow, uint32_t ofLane, u32x4& first, u32x4& second) {
+        const LaneRole role = laneRole(both, ofLane);
+        const bool upper = role.word >= half;
+        const uint32_t start = ofRow != MISSING ? ofRow * (upper ? u.model[1].recordPieces : u.model[0].recordPieces) : 0u;   // absent words read row 0 and never emit it
+#pragma unroll
+        for (int round = 0; round < RECORD_ROUNDS; ++round) {
+            // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
+            const uint32_t q = min(round * WAVE + ofLane, totalPieces - 1);
+            const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
+            const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
+            if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
+                const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
+                const u32x4 piece = loadPiece(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
+                if (round == 0) {
+                    first = piece;
+                } else {
+                    second = piece;
+                }
+            }
+        }
+    };
+    static_assert(RECORD_ROUNDS == 2, "two stream registers per lane");
+
+    // A pipeline of depth one over the wavefront's T tiles: while tile k is decoded and stored, the row regions of tile
+    // k + 1 are in flight (two registers per lane) and the row ids of tile k + 2 behind them.
     uint32_t row = loadRow(tile, lane);
+    uint32_t rowNext = both.tilesPerWave > 1 ? loadRow(tile + wavesPerBlock, lane) : MISSING;
+    u32x4 piece0 = {0, 0, 0, 0};
+    u32x4 piece1 = {0, 0, 0, 0};
+    row = checked(row, lane);
+    issueRegions(row, lane, piece0, piece1);
 #pragma nounroll
     for (uint32_t step = 0; step < both.tilesPerWave; ++step, tile += wavesPerBlock) {
         const unsigned long long tileBase = tile * half;
@@ -1052,32 +1089,18 @@ __global__ void decode_union_split(UnionParams u)
         const bool upper = role.word >= half;           // the lane's model
         const uint32_t word = role.word - (upper ? half : 0u);
         const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(half), both.n - tileBase));
-        // the regions of all eight (word, model) pairs: piece q of the slot image belongs to word slot q / loadPieces
-        // (regions of the lane's model; when the models' regions differ in size, `both` has the larger slot geometry and the
-        // smaller model's slots take a few pieces of the following row along, as every compact-layout load does)
-        const uint32_t start = row != MISSING ? row * (upper ? u.model[1].recordPieces : u.model[0].recordPieces) : 0u;   // absent words read row 0 and never emit it
-        u32x4 pieces[RECORD_ROUNDS];
-#pragma unroll
-        for (int round = 0; round < RECORD_ROUNDS; ++round) {
-            pieces[round] = u32x4{0, 0, 0, 0};
-            // (the shuffle with every lane active: lanes past the image's last piece are the source lanes of others)
-            const uint32_t q = min(round * WAVE + lane, totalPieces - 1);
-            const uint32_t slot = fastDivide(q, both.slotMagic, both.loadPieces);
-            const uint32_t wordStart = __shfl(start, slot * both.lanesPerWord);
-            if (static_cast<uint32_t>(round) * WAVE < totalPieces && !(measure & 4)) {
-                const u32x4* base = reinterpret_cast<const u32x4*>(slot >= half ? u.model[1].streams : u.model[0].streams);
-                pieces[round] = loadPiece(base + (static_cast<unsigned long long>(wordStart) + (q - slot * both.loadPieces)));
+        // consume point of the loads issued a tile ago -- the only place that touches them
+        writeStream(both, slots, lane, 0, piece0);
+        writeStream(both, slots, lane, 1, piece1);
+        const uint32_t rowNow = row;
+        waveLdsFence();
+        if (step + 1 < both.tilesPerWave) {
+            row = checked(rowNext, lane);
+            issueRegions(row, lane, piece0, piece1);
+            if (step + 2 < both.tilesPerWave) {
+                rowNext = loadRow(tile + 2 * wavesPerBlock, lane);
             }
         }
-        const uint32_t rowNow = row;
-        if (step + 1 < both.tilesPerWave) {
-            row = loadRow(tile + wavesPerBlock, lane);   // in flight while this tile is decoded
-        }
-#pragma unroll
-        for (int round = 0; round < RECORD_ROUNDS; ++round) {
-            writeStream(both, slots, lane, round, pieces[round]);
-        }
-        waveLdsFence();
 
         WordMeta meta;
         meta.row = rowNow;

@@ -498,7 +498,9 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
     }
     const uint64_t slots = uint64_t(ctx->cuCount) * 32;   // resident wavefronts of the one-tile kernels
     if (unionSplit) {
-        return tiles >= 6 * slots ? 2u : 1u;
+        // (with the next tile's row regions in flight during a tile's decode and stores -- batch 7: another -3..-7 % at
+        // 250 k - 500 k words -- four tiles pay from about a million words on: -1..-2.5 % against two)
+        return tiles >= 24 * slots ? 4u : tiles >= 6 * slots ? 2u : 1u;
     }
     return copyBytes >= 16 * 1024 && tiles >= 2 * slots ? 2u : 1u;
 }
@@ -959,6 +961,7 @@ int launchUniform(
     params.dim = ctx->dim;
     params.wordsPerBlock = rowwiseWordsPerBlock(ctx->dim);
     params.levels = ctx->levels;
+    params.reciprocal = ctx->levels >= 1.f && ctx->levels <= 255.f && ctx->levels == std::floor(ctx->levels) ? 1.f / ctx->levels : 0.f;
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     // The persistent LDS-DMA pipeline: 16-byte output pieces, a tile's regions within UNIFORM_ROUNDS rounds, and

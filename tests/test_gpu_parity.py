@@ -542,6 +542,54 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
                     (low, high, value, levels)
 
 
+def test_uniform_division_for_every_level_count(native):
+    """The uniform kernels divide by `levels` with a reciprocal and two FMAs where the operand allows it
+    (hip_rowwise_kernels.h: divideByLevels) and with the full division elsewhere: every divisor 1 .. 255, every weight
+    0 .. 255, rows whose (min, max) put range * weight inside, at the edges of and outside the fast path's exponent
+    range -- against the reference's expression as compiled with its own flags (oracle/uniform_expr.cpp), bit for bit."""
+    import ctypes
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+
+    class Row(ctypes.Structure):
+        _fields_ = [('values', ctypes.c_void_p), ('n_values', ctypes.c_uint32),
+                    ('min_value', ctypes.c_float), ('max_value', ctypes.c_float)]
+
+    class Desc(ctypes.Structure):
+        _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64), ('rows', ctypes.c_void_p),
+                    ('quantization_levels', ctypes.c_uint8)]
+
+    rng = np.random.default_rng(255)
+    payload = np.arange(256, dtype=np.uint8)
+    lows = (rng.standard_normal(160) * 0.5).astype(np.float32)
+    highs = (lows + np.abs(rng.standard_normal(160)).astype(np.float32) * np.float32(1.5)).astype(np.float32)
+    # ranges whose products with the weights straddle the fast path's limits (2^-100, 2^100), tiny, huge, negative, zero
+    for low, high in ((0.0, 2.0 ** -107), (0.0, 2.0 ** -100), (-2.0 ** -104, 2.0 ** -104), (1.0, 1.0), (3.0, -2.0),
+                      (0.0, 2.0 ** 93), (-2.0 ** 99, 2.0 ** 99), (0.0, 2.0 ** 120), (1e-30, 1e-29), (-1e30, 1e30),
+                      (0.0, 1e-44), (2.0 ** -126, 2.0 ** -125), (0.25, 0.25 + 2.0 ** -20), (-0.0, 0.0)):
+        lows = np.append(lows, np.float32(low))
+        highs = np.append(highs, np.float32(high))
+    count = len(lows)
+    ids = np.tile(np.arange(count, dtype=np.uint32), 400)   # 69 600 rows: the persistent kernel; the first `count` also alone
+    for levels in range(1, 256):
+        rows = (Row * count)()
+        for i in range(count):
+            rows[i] = Row(payload.ctypes.data, 256, float(lows[i]), float(highs[i]))
+        desc = Desc(256, count, ctypes.addressof(rows), levels)
+        context = ctypes.c_void_p()
+        assert library.memb_hip_ctx_create_uniform(ctypes.byref(context), 0, ctypes.byref(desc)) == 0, library.memb_hip_last_error()
+        try:
+            expected = np.stack([oracle.uniform_expression(lows[i], highs[i], levels, payload) for i in range(count)])
+            for batch in (ids[:count], ids):
+                out = np.empty((len(batch), 256), dtype=np.float32)
+                assert library.memb_hip_decode_rows(
+                    context, batch.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(batch)),
+                    out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(256), ctypes.c_size_t(0)) == 0, library.memb_hip_last_error()
+                assert nan_aware_equal(out, expected[batch]), levels
+        finally:
+            library.memb_hip_ctx_destroy(context)
+
+
 def test_strided_output_leaves_other_columns_alone(native, make_model):
     path, words = make_model(20000, 300, 'trained', 4)
     reader = native.Reader(path)

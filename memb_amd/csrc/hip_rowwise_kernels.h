@@ -26,7 +26,6 @@ struct UniformParams {
     uint32_t wordsPerBlock;
     uint32_t pieceMagic;     // ceil(2^32 / (dim / 4)), vector path
     float levels;
-    float reciprocal;        // RN(1 / levels) for levels = 1 .. 255, else 0 (divideByLevels then always divides)
     // dequant_uniform_persistent
     uint32_t wordsPerWave;   // words of a wavefront's tile: their regions fill at most UNIFORM_ROUNDS 64-lane rounds
     uint32_t regionMagic;    // fastDivide magic for regionPieces
@@ -37,36 +36,19 @@ __device__ __forceinline__ const uint8_t* uniformRegion(const UniformParams& p, 
     return reinterpret_cast<const uint8_t*>(p.records + static_cast<unsigned long long>(row) * p.regionPieces);
 }
 
-// a / levels, correctly rounded (IEEE round to nearest even), for levels = 1 .. 255 and reciprocal = RN(1 / levels):
-//     q = RN(a * reciprocal);  r = a - q * levels (one FMA: exact);  result = RN(q + r * reciprocal) (one FMA)
-// -- three instructions where hipcc's correctly rounded division (v_div_scale, v_rcp, four FMAs, v_div_fmas,
-// v_div_fixup) takes about ten; the uniform kernels spend half of their vector instructions there (21.7 per weight:
-// profiles/r03_uniform_after_summary.json). Why the result is the correctly rounded quotient (Markstein's correction
-// step): q is within one ulp of a / levels, so r is a multiple of ulp(a) below 2^24 of them and the FMA delivers it
-// exactly; the corrected sum differs from a / levels by 2^-48 relative (the error of `reciprocal` times r); and a /
-// levels cannot lie that close to a rounding boundary -- a boundary is a 25-bit odd significand m, and a = levels * m
-// would need more than 24 bits whatever the power of two in levels, so the distance is at least 2^-33 relative.
-// Checked against IEEE division on 115 million operands over all 255 divisors (numpy float32 `/`; round 4) and, on the
-// device, against the reference's expression for every stored level count (tests/test_gpu_parity.py).
-// Outside a safe exponent range -- zero (whose sign the correction would lose), subnormal, huge, infinite, NaN -- and for
-// a levels field of 0 (division by zero, the reference's behaviour for a file without the field) the full division runs.
-__device__ __forceinline__ float divideByLevels(float a, float levels, float reciprocal)
-{
-    const uint32_t exponent = (__float_as_uint(a) << 1) >> 24;
-    if (reciprocal != 0.f && exponent - 27u < 200u) {   // 2^-100 <= |a| < 2^100: every intermediate is a normal number
-        const float q = mulRn(a, reciprocal);
-        const float r = __fmaf_rn(-q, levels, a);
-        return __fmaf_rn(r, reciprocal, q);
-    }
-    return __fdiv_rn(a, levels);
-}
-
 // reference src/uniform_compression.cpp:70-71, evaluated left to right in fp32:
 // sub, mul, div, add -- each correctly rounded, nothing fused, subnormals kept.
-__device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels, float reciprocal)
+// (The division is hipcc's correctly rounded expansion, about ten of the 21.7 vector instructions a weight costs. Round 4
+// built the cheaper exact form for divisors 1 .. 255 -- q = RN(a * RN(1 / levels)), r = a - q * levels by one FMA,
+// RN(q + r * RN(1 / levels)) by another; correctly rounded inside a safe exponent range, the full division outside it;
+// bit-identical on 115 million operands on the CPU and in tests/test_gpu_parity.py::
+// test_uniform_division_for_every_level_count on the device -- and it bought nothing: 0.162-0.168 ms against
+// 0.158-0.165 for the 500 000-word dump, +3 % on 100 000 rows (tools/perf/r4/batch8.sh; twice the registers for the two
+// paths). The vector ALU is not what these kernels wait for. Removed; the test stays.)
+__device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels)
 {
     const float scaled = mulRn(range, static_cast<float>(v));
-    return addRn(minValue, divideByLevels(scaled, levels, reciprocal));
+    return addRn(minValue, __fdiv_rn(scaled, levels));
 }
 
 constexpr uint32_t ROWWISE_MAX_WORDS = 64;   // words per block of the row-wise kernels
@@ -119,10 +101,10 @@ __global__ void dequant_uniform(UniformParams p)
                     if (rowLds[word[u]] < p.nRows) {
                         const float2 mm = minMaxLds[word[u]];
                         const float range = subRn(mm.y, mm.x);
-                        f.x = dequant(mm.x, range, packed[u] & 0xff, p.levels, p.reciprocal);
-                        f.y = dequant(mm.x, range, (packed[u] >> 8) & 0xff, p.levels, p.reciprocal);
-                        f.z = dequant(mm.x, range, (packed[u] >> 16) & 0xff, p.levels, p.reciprocal);
-                        f.w = dequant(mm.x, range, packed[u] >> 24, p.levels, p.reciprocal);
+                        f.x = dequant(mm.x, range, packed[u] & 0xff, p.levels);
+                        f.y = dequant(mm.x, range, (packed[u] >> 8) & 0xff, p.levels);
+                        f.z = dequant(mm.x, range, (packed[u] >> 16) & 0xff, p.levels);
+                        f.w = dequant(mm.x, range, packed[u] >> 24, p.levels);
                     }
                     float* dst = p.out + (blockBase + word[u]) * p.ld + p.colOff + 4 * column[u];
                     if (p.accumulate || p.divisor != 0.f) {
@@ -142,7 +124,7 @@ __global__ void dequant_uniform(UniformParams p)
             if (row < p.nRows) {
                 const float2 mm = minMaxLds[w];
                 const float range = subRn(mm.y, mm.x);
-                f = dequant(mm.x, range, uniformRegion(p, row)[16 + c], p.levels, p.reciprocal);
+                f = dequant(mm.x, range, uniformRegion(p, row)[16 + c], p.levels);
             }
             float* dst = p.out + (blockBase + w) * p.ld + p.colOff + c;
             if (p.accumulate || p.divisor != 0.f) {
@@ -246,10 +228,10 @@ __global__ void dequant_uniform_persistent(UniformParams p)
                     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (!((absent >> word[b]) & 1)) {
                         const float range = subRn(minMax[b].y, minMax[b].x);
-                        f.x = dequant(minMax[b].x, range, packed[b] & 0xff, p.levels, p.reciprocal);
-                        f.y = dequant(minMax[b].x, range, (packed[b] >> 8) & 0xff, p.levels, p.reciprocal);
-                        f.z = dequant(minMax[b].x, range, (packed[b] >> 16) & 0xff, p.levels, p.reciprocal);
-                        f.w = dequant(minMax[b].x, range, packed[b] >> 24, p.levels, p.reciprocal);
+                        f.x = dequant(minMax[b].x, range, packed[b] & 0xff, p.levels);
+                        f.y = dequant(minMax[b].x, range, (packed[b] >> 8) & 0xff, p.levels);
+                        f.z = dequant(minMax[b].x, range, (packed[b] >> 16) & 0xff, p.levels);
+                        f.w = dequant(minMax[b].x, range, packed[b] >> 24, p.levels);
                     }
                     float* destination = FLAT ? tileOut + 4 * static_cast<size_t>(q0 + WAVE * b)
                                               : tileOut + word[b] * p.ld + 4 * column[b];

@@ -961,7 +961,6 @@ int launchUniform(
     params.dim = ctx->dim;
     params.wordsPerBlock = rowwiseWordsPerBlock(ctx->dim);
     params.levels = ctx->levels;
-    params.reciprocal = ctx->levels >= 1.f && ctx->levels <= 255.f && ctx->levels == std::floor(ctx->levels) ? 1.f / ctx->levels : 0.f;
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     // The persistent LDS-DMA pipeline: 16-byte output pieces, a tile's regions within UNIFORM_ROUNDS rounds, and

@@ -543,10 +543,10 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
 
 
 def test_uniform_division_for_every_level_count(native):
-    """The uniform kernels divide by `levels` with a reciprocal and two FMAs where the operand allows it
-    (hip_rowwise_kernels.h: divideByLevels) and with the full division elsewhere: every divisor 1 .. 255, every weight
-    0 .. 255, rows whose (min, max) put range * weight inside, at the edges of and outside the fast path's exponent
-    range -- against the reference's expression as compiled with its own flags (oracle/uniform_expr.cpp), bit for bit."""
+    """Every divisor 1 .. 255, every weight 0 .. 255, rows whose (min, max) make range * weight ordinary, tiny, huge,
+    subnormal, negative and zero -- both uniform kernels against the reference's expression as compiled with its own
+    flags (oracle/uniform_expr.cpp), bit for bit. (Written for round 4's reciprocal + FMA division, which was exact and
+    not faster and is gone again: hip_rowwise_kernels.h; the vectors in tests/golden cover five level counts.)"""
     import ctypes
     library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
     library.memb_hip_last_error.restype = ctypes.c_char_p

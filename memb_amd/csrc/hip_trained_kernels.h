@@ -585,17 +585,71 @@ __global__ void decode_trained(TrainedParams p)
     unsigned long long tile =
         static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
+    // The block's copy of table and codebook into LDS and the first tile's dependent hops (row ids -> row regions) are
+    // independent of each other: when one 16-byte piece per thread covers the copy (4 KiB of a nibble-key model in a block
+    // of four wavefronts; 5 KiB of the 6-bit model in a block of eight), the row ids are loaded FIRST, the copy's pieces
+    // behind them into a register, the row regions behind those, and the pieces go to LDS -- with the block's barrier --
+    // while the regions are in flight. Loads return in order, so every wait is for exactly what it needs. (Round 3 had
+    // tried ids and regions in front of the whole copy loop: 1-10 % slower -- the copy's stores to LDS then waited for
+    // the regions. Larger tables keep the copy in front.)
+    const uint32_t tablePieces = p.tableDwords / 4;
+    const uint32_t copyPieces = tablePieces + (MODE != OUT_INDEX && MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
+    const bool copyInFlight = copyPieces <= blockDim.x;
     const bool active = tile * p.wordsPerWave < p.n;
-
-    // the loads of a tile, issued and not waited for: index record (layouts without row records), first rounds of regions
-    auto issueTileLoads = [&](uint32_t tileRow, const LaneRole& role, WordMeta& meta, StreamRegisters& first) {
-        meta = loadWordMeta(p, tileRow, role);
-        unpackMeta(p, role, meta);
-        issueStreamLoads(p, meta, lane, 0, first);
+    uint32_t tileRow = MISSING;
+    u32x4 image = {0, 0, 0, 0};
+    WaveLds mem;
+    if (copyInFlight) {
+        mem = waveLds(p, lds);
+        if (active) {
+            tileRow = loadTileRow(p, tile, laneRole(p, lane));
+        }
+        if (!(measureFlags(p) & 0x4000)) {
+            if (threadIdx.x < tablePieces) {
+                image = reinterpret_cast<const u32x4*>(p.table)[threadIdx.x];
+            } else if (threadIdx.x < copyPieces) {
+                image = reinterpret_cast<const u32x4*>(p.codebook)[threadIdx.x - tablePieces];
+            }
+        }
+    } else {
+        mem = setUpLds<MODE>(p, lds);
+        if (active) {
+            tileRow = loadTileRow(p, tile, laneRole(p, lane));
+        }
+    }
+    auto commitCopy = [&] {   // (table and codebook are neighbours in LDS: one image)
+        if (threadIdx.x < copyPieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image;
+        }
+        __syncthreads();
     };
-    // regions -> LDS -> symbols -> rows
-    auto finishTile = [&](const WaveLds& mem, unsigned long long ofTile, const LaneRole& role, WordMeta& meta, const StreamRegisters& first) {
-        const unsigned long long tileBase = ofTile * p.wordsPerWave;
+    if (!active) {
+        if (copyInFlight) {
+            commitCopy();
+        }
+        return;
+    }
+#pragma nounroll
+    for (uint32_t step = 0; step < p.tilesPerWave; ++step, tile += wavesPerBlock) {
+        const unsigned long long tileBase = tile * p.wordsPerWave;
+        if (tileBase >= p.n) {
+            break;
+        }
+        // Everything a lane derives from its number -- word, segment, the pieces it copies and stores -- is worked out
+        // afresh per tile, as a wavefront with one tile did: hoisted out of the loop those values cost 50 vector
+        // registers and half the resident wavefronts (103 against 52: tools/perf/isa.py).
+        asm volatile("" : "+v"(lane));
+        const LaneRole role = laneRole(p, lane);
+        WordMeta meta = loadWordMeta(p, tileRow, role);
+        unpackMeta(p, role, meta);
+        StreamRegisters first = {};   // (defined on every path: otherwise the values are carried around the loop)
+        issueStreamLoads(p, meta, lane, 0, first);
+        if (step + 1 < p.tilesPerWave) {
+            tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
+        }
+        if (copyInFlight && step == 0) {
+            commitCopy();
+        }
         const uint32_t tileWords =
             static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
         writeStreams(p, mem.slots, lane, 0, first);
@@ -616,68 +670,6 @@ __global__ void decode_trained(TrainedParams p)
                 outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
             }
         }
-    };
-
-    // ONE tile per wavefront and a copy that one 16-byte piece per thread covers (4 KiB of a nibble-key model in a block of
-    // four wavefronts, 5 KiB of the 6-bit model in a block of eight) -- every dump and every small batch of the BASELINE
-    // models: the block's copy of table and codebook into LDS and the tile's dependent hops (row ids -> row regions) do not
-    // need each other, so the row ids are loaded FIRST, the copy's pieces behind them into a register, the regions behind
-    // those, and the pieces go to LDS -- with the block's barrier -- while the regions are in flight. Loads return in
-    // order, so every wait is for exactly what it needs. (Round 3 had tried ids and regions in front of the whole copy
-    // loop: 1-10 % slower -- the copy's stores to LDS then waited for the regions.)
-    const uint32_t tablePieces = p.tableDwords / 4;
-    const uint32_t copyPieces = tablePieces + (MODE != OUT_INDEX && MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
-    if (p.tilesPerWave == 1 && copyPieces <= blockDim.x) {
-        const WaveLds mem = waveLds(p, lds);
-        const LaneRole role = laneRole(p, lane);
-        const uint32_t tileRow = active ? loadTileRow(p, tile, role) : MISSING;
-        u32x4 image = {0, 0, 0, 0};
-        if (!(measureFlags(p) & 0x4000)) {
-            if (threadIdx.x < tablePieces) {
-                image = reinterpret_cast<const u32x4*>(p.table)[threadIdx.x];
-            } else if (threadIdx.x < copyPieces) {
-                image = reinterpret_cast<const u32x4*>(p.codebook)[threadIdx.x - tablePieces];
-            }
-        }
-        WordMeta meta;
-        StreamRegisters first = {};
-        if (active) {
-            issueTileLoads(tileRow, role, meta, first);
-        }
-        if (threadIdx.x < copyPieces) {   // (table and codebook are neighbours in LDS: one image)
-            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image;
-        }
-        __syncthreads();
-        if (active) {
-            finishTile(mem, tile, role, meta, first);
-        }
-        return;
-    }
-
-    // The general form: the copy in front, then p.tilesPerWave tiles one after the other, the next tile's row ids loaded
-    // while this one is decoded.
-    const WaveLds mem = setUpLds<MODE>(p, lds);
-    if (!active) {
-        return;
-    }
-    uint32_t tileRow = loadTileRow(p, tile, laneRole(p, lane));
-#pragma nounroll
-    for (uint32_t step = 0; step < p.tilesPerWave; ++step, tile += wavesPerBlock) {
-        if (tile * p.wordsPerWave >= p.n) {
-            break;
-        }
-        // Everything a lane derives from its number -- word, segment, the pieces it copies and stores -- is worked out
-        // afresh per tile, as a wavefront with one tile did: hoisted out of the loop those values cost 50 vector
-        // registers and half the resident wavefronts (103 against 52: tools/perf/isa.py).
-        asm volatile("" : "+v"(lane));
-        const LaneRole role = laneRole(p, lane);
-        WordMeta meta;
-        StreamRegisters first = {};   // (defined on every path: otherwise the values are carried around the loop)
-        issueTileLoads(tileRow, role, meta, first);
-        if (step + 1 < p.tilesPerWave) {
-            tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
-        }
-        finishTile(mem, tile, role, meta, first);
         waveLdsFence();   // (the next tile's streams and symbols go where this one's were)
     }
 }

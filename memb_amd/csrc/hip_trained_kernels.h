@@ -537,23 +537,19 @@ struct WaveLds {
 };
 
 // LDS layout: lookup table | codebook | per wave { bitstream slots | symbol tile }.
-__device__ __forceinline__ WaveLds waveLds(const TrainedParams& p, uint32_t* lds)
-{
-    const uint32_t wave = threadIdx.x / WAVE;
-    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
-    WaveLds result;
-    result.table = reinterpret_cast<const TableEntry*>(lds);
-    result.codebook = lds + p.tableDwords;
-    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
-    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
-    return result;
-}
-
 // Loads table and codebook; ends with a block barrier.
 template <int MODE>
 __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* lds)
 {
+    const uint32_t wave = threadIdx.x / WAVE;
     uint32_t* codebookLds = lds + p.tableDwords;
+    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
+    WaveLds result;
+    result.table = reinterpret_cast<const TableEntry*>(lds);
+    result.codebook = codebookLds;
+    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
+    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
+
     const bool copy = !(measureFlags(p) & 0x4000);   // (measurement builds, bit 14: no table / codebook copy)
     for (uint32_t i = threadIdx.x; copy && i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
@@ -564,7 +560,7 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
         }
     }
     __syncthreads();
-    return waveLds(p, lds);
+    return result;
 }
 
 // One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
@@ -585,50 +581,17 @@ __global__ void decode_trained(TrainedParams p)
     unsigned long long tile =
         static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
-    // The block's copy of table and codebook into LDS and the first tile's dependent hops (row ids -> row regions) are
-    // independent of each other: when one 16-byte piece per thread covers the copy (4 KiB of a nibble-key model in a block
-    // of four wavefronts; 5 KiB of the 6-bit model in a block of eight), the row ids are loaded FIRST, the copy's pieces
-    // behind them into a register, the row regions behind those, and the pieces go to LDS -- with the block's barrier --
-    // while the regions are in flight. Loads return in order, so every wait is for exactly what it needs. (Round 3 had
-    // tried ids and regions in front of the whole copy loop: 1-10 % slower -- the copy's stores to LDS then waited for
-    // the regions. Larger tables keep the copy in front.)
-    const uint32_t tablePieces = p.tableDwords / 4;
-    const uint32_t copyPieces = tablePieces + (MODE != OUT_INDEX && MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
-    const bool copyInFlight = copyPieces <= blockDim.x;
-    const bool active = tile * p.wordsPerWave < p.n;
-    uint32_t tileRow = MISSING;
-    u32x4 image = {0, 0, 0, 0};
-    WaveLds mem;
-    if (copyInFlight) {
-        mem = waveLds(p, lds);
-        if (active) {
-            tileRow = loadTileRow(p, tile, laneRole(p, lane));
-        }
-        if (!(measureFlags(p) & 0x4000)) {
-            if (threadIdx.x < tablePieces) {
-                image = reinterpret_cast<const u32x4*>(p.table)[threadIdx.x];
-            } else if (threadIdx.x < copyPieces) {
-                image = reinterpret_cast<const u32x4*>(p.codebook)[threadIdx.x - tablePieces];
-            }
-        }
-    } else {
-        mem = setUpLds<MODE>(p, lds);
-        if (active) {
-            tileRow = loadTileRow(p, tile, laneRole(p, lane));
-        }
-    }
-    auto commitCopy = [&] {   // (table and codebook are neighbours in LDS: one image)
-        if (threadIdx.x < copyPieces) {
-            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image;
-        }
-        __syncthreads();
-    };
-    if (!active) {
-        if (copyInFlight) {
-            commitCopy();
-        }
+    // The copy of table and codebook stays IN FRONT of the tile's loads. Round 4, batch 9 issued the row ids first, the
+    // copy's pieces behind them into a register, the row regions behind those, and wrote the pieces to LDS (with the
+    // block's barrier) while the regions were in flight -- every wait for exactly what it needs, loads returning in order.
+    // 10 000 rows -4 % (8.0 -> 7.7 us), and every large batch SLOWER: 4-bit key-order dump +5 %, 500 k rows +3 %, 6-bit
+    // dump +6 %, 2-bit shuffled +5 % (round 3 had seen the same sign with a cruder ordering). A block that starts its
+    // dependent loads a microsecond later is the better citizen of a memory system that is the bound.
+    const WaveLds mem = setUpLds<MODE>(p, lds);
+    if (tile * p.wordsPerWave >= p.n) {
         return;
     }
+    uint32_t tileRow = loadTileRow(p, tile, laneRole(p, lane));
 #pragma nounroll
     for (uint32_t step = 0; step < p.tilesPerWave; ++step, tile += wavesPerBlock) {
         const unsigned long long tileBase = tile * p.wordsPerWave;
@@ -646,9 +609,6 @@ __global__ void decode_trained(TrainedParams p)
         issueStreamLoads(p, meta, lane, 0, first);
         if (step + 1 < p.tilesPerWave) {
             tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
-        }
-        if (copyInFlight && step == 0) {
-            commitCopy();
         }
         const uint32_t tileWords =
             static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));

@@ -581,12 +581,14 @@ __global__ void decode_trained(TrainedParams p)
     unsigned long long tile =
         static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
-    // The copy of table and codebook stays IN FRONT of the tile's loads. Round 4, batch 9 issued the row ids first, the
+    // The copy of table and codebook stays IN FRONT of the tile's loads. Round 4, batch 10 issued the row ids first, the
     // copy's pieces behind them into a register, the row regions behind those, and wrote the pieces to LDS (with the
     // block's barrier) while the regions were in flight -- every wait for exactly what it needs, loads returning in order.
-    // 10 000 rows -4 % (8.0 -> 7.7 us), and every large batch SLOWER: 4-bit key-order dump +5 %, 500 k rows +3 %, 6-bit
-    // dump +6 %, 2-bit shuffled +5 % (round 3 had seen the same sign with a cruder ordering). A block that starts its
-    // dependent loads a microsecond later is the better citizen of a memory system that is the bound.
+    // Against this form, three builds alternating on one box: key-order dumps +1.4..+2.3 % (4-bit), +1.6 % (6-bit), 500 k
+    // rows +1.2 %; shuffled 2.2 M rows -1..-2.8 % (4-bit), -4 % (6-bit); 10 000 rows -2 %. The same as straight-line code
+    // without the T loop: 10 000 rows -5 %, dumps +6..+10 %. The BASELINE configurations that run this kernel are dumps:
+    // a block that starts its dependent loads a microsecond later is the better citizen there (round 3 had seen the same
+    // sign with a cruder ordering).
     const WaveLds mem = setUpLds<MODE>(p, lds);
     if (tile * p.wordsPerWave >= p.n) {
         return;

@@ -1021,14 +1021,41 @@ __global__ void decode_union_split(UnionParams u)
     const uint32_t wave = threadIdx.x / WAVE;
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
     const TrainedParams& both = u.model[2];
-    setUpUnionLds<2>(u, lds);
 
     const uint32_t half = both.wordsPerWave / 2;   // words of a tile
     // both.tilesPerWave tiles one after the other (tiles wave, wave + W, ... of the block's run), as decode_trained
     unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * both.tilesPerWave) + wave;
-    if (tile * half >= both.n) {
-        return;
+    const bool active = tile * half < both.n;
+    // The block's copy of two tables and two codebooks into LDS (8 KiB for two nibble-key models) and the first tile's
+    // dependent hops (row ids -> row regions) do not need each other. Union batches are random lookups -- the case in
+    // which overlapping the two paid for the single-model kernel (round 4, batch 10: shuffled rows -1..-4 %; its dumps
+    // +1.4..2.3 %, which is why decode_trained keeps the copy in front) -- so when two 16-byte pieces per thread cover the
+    // copy, the row ids are loaded first, the copy's pieces behind them into registers, the regions behind those, and the
+    // pieces go to LDS, with the block's barrier, while the regions are in flight.
+    const uint32_t tableDwords = u.model[0].tableDwords + u.model[1].tableDwords;   // tables first, then 512 dwords per codebook
+    const uint32_t imagePieces = (tableDwords + 2 * 512) / 4;
+    const bool copyInFlight = imagePieces <= 2 * blockDim.x && !(measureFlags(u.model[0]) & 0x8000);
+    if (!copyInFlight) {
+        setUpUnionLds<2>(u, lds);
+        if (!active) {
+            return;
+        }
     }
+    // piece `at` of the LDS image (16 bytes): where it comes from, or null (padding behind a 256-entry codebook)
+    auto imageSource = [&](uint32_t at) -> const u32x4* {
+        const uint32_t dword = 4 * at;
+        if (dword < u.model[0].tableDwords) {
+            return reinterpret_cast<const u32x4*>(u.model[0].table + dword);
+        }
+        if (dword < tableDwords) {
+            return reinterpret_cast<const u32x4*>(u.model[1].table + (dword - u.model[0].tableDwords));
+        }
+        const uint32_t inCodebooks = dword - tableDwords;
+        const bool second = inCodebooks >= 512;
+        const uint32_t offset = inCodebooks - (second ? 512u : 0u);
+        const TrainedParams& model = second ? u.model[1] : u.model[0];
+        return at < imagePieces && offset < model.codebookDwords ? reinterpret_cast<const u32x4*>(model.codebook) + offset / 4 : nullptr;
+    };
     uint32_t* waveLds = lds + u.sharedDwords + wave * u.perWaveDwords;
     uint32_t* slots = waveLds + u.slotOffsetDwords[0];
     const uint32_t measure = measureFlags(u.model[0]);   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
@@ -1079,12 +1106,39 @@ __global__ void decode_union_split(UnionParams u)
 
     // A pipeline of depth one over the wavefront's T tiles: while tile k is decoded and stored, the row regions of tile
     // k + 1 are in flight (two registers per lane) and the row ids of tile k + 2 behind them.
-    uint32_t row = loadRow(tile, lane);
-    uint32_t rowNext = both.tilesPerWave > 1 ? loadRow(tile + wavesPerBlock, lane) : MISSING;
+    uint32_t row = active ? loadRow(tile, lane) : MISSING;
+    uint32_t rowNext = active && both.tilesPerWave > 1 ? loadRow(tile + wavesPerBlock, lane) : MISSING;
+    u32x4 image0 = {0, 0, 0, 0};
+    u32x4 image1 = {0, 0, 0, 0};
+    if (copyInFlight && !(measure & 0x4000)) {
+        const u32x4* source0 = imageSource(threadIdx.x);
+        const u32x4* source1 = imageSource(threadIdx.x + blockDim.x);
+        if (source0) {
+            image0 = *source0;
+        }
+        if (source1) {
+            image1 = *source1;
+        }
+    }
     u32x4 piece0 = {0, 0, 0, 0};
     u32x4 piece1 = {0, 0, 0, 0};
-    row = checked(row, lane);
-    issueRegions(row, lane, piece0, piece1);
+    if (active) {
+        row = checked(row, lane);
+        issueRegions(row, lane, piece0, piece1);
+    }
+    if (copyInFlight) {
+        // (the codebook areas are 512 dwords each whatever the codebook's size: padding pieces are written as zeros)
+        if (threadIdx.x < imagePieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image0;
+        }
+        if (threadIdx.x + blockDim.x < imagePieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x + blockDim.x] = image1;
+        }
+        __syncthreads();
+        if (!active) {
+            return;
+        }
+    }
 #pragma nounroll
     for (uint32_t step = 0; step < both.tilesPerWave; ++step, tile += wavesPerBlock) {
         const unsigned long long tileBase = tile * half;

@@ -537,19 +537,23 @@ struct WaveLds {
 };
 
 // LDS layout: lookup table | codebook | per wave { bitstream slots | symbol tile }.
+__device__ __forceinline__ WaveLds waveLds(const TrainedParams& p, uint32_t* lds)
+{
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
+    WaveLds result;
+    result.table = reinterpret_cast<const TableEntry*>(lds);
+    result.codebook = lds + p.tableDwords;
+    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
+    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
+    return result;
+}
+
 // Loads table and codebook; ends with a block barrier.
 template <int MODE>
 __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* lds)
 {
-    const uint32_t wave = threadIdx.x / WAVE;
     uint32_t* codebookLds = lds + p.tableDwords;
-    const uint32_t perWave = p.wordsPerWave * p.slotDwords + p.keyTileDwords;
-    WaveLds result;
-    result.table = reinterpret_cast<const TableEntry*>(lds);
-    result.codebook = codebookLds;
-    result.slots = lds + p.tableDwords + p.codebookDwords + wave * perWave;
-    result.keyTile = result.slots + p.wordsPerWave * p.slotDwords;
-
     const bool copy = !(measureFlags(p) & 0x4000);   // (measurement builds, bit 14: no table / codebook copy)
     for (uint32_t i = threadIdx.x; copy && i < p.tableDwords / 4; i += blockDim.x) {
         reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(p.table)[i];
@@ -560,7 +564,7 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
         }
     }
     __syncthreads();
-    return result;
+    return waveLds(p, lds);
 }
 
 // One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
@@ -674,16 +678,54 @@ __global__ void decode_records_persistent(TrainedParams p)
     uint32_t rowCurrent = loadTileRow(p, tile, role);
     uint32_t rowNext = loadTileRow(p, tile + stride, role);
     uint32_t rowLoading = loadTileRow(p, tile + 2 * stride, role);
-    const WaveLds mem = setUpLds<MODE>(p, lds);
-    if (tile >= tiles) {
-        return;
-    }
-    uint32_t* slots = mem.slots;
     u32x4 stream0 = {0, 0, 0, 0};                       // the next tile's pieces (a tile of at most 64 pieces
     u32x4 stream1 = {0, 0, 0, 0};                       // never loads the second one)
+    // The batches this kernel serves are random lookups of two or three tiles per wavefront: mostly prologue. When two
+    // 16-byte pieces per thread cover the copy of table and codebook, the pieces are loaded into registers behind the row
+    // ids, the first tile's row regions behind them, and the pieces go to LDS -- with the block's barrier -- while the
+    // regions are in flight (as decode_union_split; the single-model dumps of decode_trained are what this does NOT pay for).
+    const uint32_t tablePieces = p.tableDwords / 4;
+    const uint32_t copyPieces = tablePieces + (MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
+    WaveLds mem;
+    if (copyPieces <= 2 * blockDim.x && !(measureFlags(p) & 0x8000)) {
+        mem = waveLds(p, lds);
+        u32x4 image0 = {0, 0, 0, 0};
+        u32x4 image1 = {0, 0, 0, 0};
+        auto imageSource = [&](uint32_t at) {   // (table and codebook are neighbours in LDS: one image)
+            return at < tablePieces ? reinterpret_cast<const u32x4*>(p.table) + at
+                                    : reinterpret_cast<const u32x4*>(p.codebook) + (at - tablePieces);
+        };
+        if (!(measureFlags(p) & 0x4000)) {
+            if (threadIdx.x < copyPieces) {
+                image0 = *imageSource(threadIdx.x);
+            }
+            if (threadIdx.x + blockDim.x < copyPieces) {
+                image1 = *imageSource(threadIdx.x + blockDim.x);
+            }
+        }
+        if (tile < tiles) {
+            issueRecordLoads(p, rowCurrent, lane, stream0, stream1);
+        }
+        if (threadIdx.x < copyPieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image0;
+        }
+        if (threadIdx.x + blockDim.x < copyPieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x + blockDim.x] = image1;
+        }
+        __syncthreads();
+        if (tile >= tiles) {
+            return;
+        }
+    } else {
+        mem = setUpLds<MODE>(p, lds);
+        if (tile >= tiles) {
+            return;
+        }
+        issueRecordLoads(p, rowCurrent, lane, stream0, stream1);
+    }
+    uint32_t* slots = mem.slots;
 
     // prologue
-    issueRecordLoads(p, rowCurrent, lane, stream0, stream1);
     writeStream(p, slots, lane, 0, stream0);
     writeStream(p, slots, lane, 1, stream1);
     issueRecordLoads(p, rowNext, lane, stream0, stream1);

@@ -486,11 +486,13 @@ struct Epilogue {
 };
 
 // Tiles a wavefront of the one-tile kernels (decode_trained, decode_union_split) decodes one after the other, behind
-// ONE copy of table(s) and codebook(s) into LDS per block. Measured (round 4, batches 2-4; `copyBytes` = what a block
-// copies): the copy is 2.8 % of a 4-bit dump (4 KiB) and more than it gains back there (T = 2: -0.9 % / +1.9 % key order
-// / shuffled, T = 4: +3.6 %), 8.6 % of the split union (8 KiB for 4 tiles of 4 words: T = 2..4 -4 % at 250 k words, -7 %
-// at 500 k, -9 % at 1 M; +8 % at 100 k, where the grid gets too small), and what made the 8-bit model (33 KiB) the last
-// customer of the general persistent kernel (T = 2: dumps +0.1..0.3 % against it, 500 k rows -1.5 %).
+// ONE copy of table(s) and codebook(s) into LDS per block. Measured (round 4, batches 2-4 and 12; `copyBytes` = what a
+// block copies): the copy is 2.8 % of a 4-bit dump (4 KiB) and more than it gains back there (T = 2: -0.9 % / +1.9 % key
+// order / shuffled, T = 4: +3.6 %); it is what made the 8-bit model (33 KiB) the last customer of the general persistent
+// kernel (T = 2: dumps +0.1..0.3 % against it, 500 k rows -1.5 %). The split union -- 8 KiB for four tiles of four words,
+// and with T > 1 a pipeline of depth one (the next tile's row regions in flight during a tile's decode and stores) --
+// wants T = 2 at every size measured once its copy is overlapped with the first tile's loads (batch 12: 30 k words -6 %,
+// 100 k -2 %, 160 k -3 %, 500 k -4 %, 1 M -3 % against T = 1; T = 3 and 4 are behind T = 2 everywhere).
 uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyBytes, bool unionSplit)
 {
     if (ctx->switches.tilesPerWave) {
@@ -498,9 +500,7 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
     }
     const uint64_t slots = uint64_t(ctx->cuCount) * 32;   // resident wavefronts of the one-tile kernels
     if (unionSplit) {
-        // (with the next tile's row regions in flight during a tile's decode and stores -- batch 7: another -3..-7 % at
-        // 250 k - 500 k words -- four tiles pay from about a million words on: -1..-2.5 % against two)
-        return tiles >= 24 * slots ? 4u : tiles >= 6 * slots ? 2u : 1u;
+        return 2 * tiles >= slots ? 2u : 1u;   // (from 16 k words on 256 CUs; below, halving the grid leaves CUs idle)
     }
     return copyBytes >= 16 * 1024 && tiles >= 2 * slots ? 2u : 1u;
 }

@@ -155,6 +155,34 @@ __global__ void tiles_persistent(Params p)
     }
 }
 
+// Experiments (tools/perf/r4/store_patterns.py; not part of bench.py's table). What makes the linear fill fast?
+//   EXPERIMENT 0: every wavefront stores ONE KiB and exits -- after `delay` x ~0.43 us of sleeping (a wavefront that lives
+//                 as long as a decoding one, but still stores once)
+//   EXPERIMENT 1: every wavefront stores `stores` consecutive KiB (its own run) and exits, `delay` sleeps before the first
+//   EXPERIMENT 2: as 1, `delay` sleeps between consecutive stores
+__global__ void store_experiment(float4* out, unsigned long long pieces, int experiment, int stores, int delay)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long wave = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) / WAVE;
+    const int perWave = experiment == 0 ? 1 : stores;
+    if (experiment != 2) {
+        for (int i = 0; i < delay; ++i) {
+            __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+        }
+    }
+    for (int k = 0; k < perWave; ++k) {
+        const unsigned long long i = (wave * perWave + k) * WAVE + lane;
+        if (i < pieces) {
+            out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+        }
+        if (experiment == 2) {
+            for (int d = 0; d < delay; ++d) {
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+    }
+}
+
 // union: 4 words per tile, each 600 floats wide; records of the 4 words from both arrays (slots 0-3 / 4-7)
 __global__ void union_tile_per_wave(Params p)
 {
@@ -250,6 +278,21 @@ int memb_ceiling_launch(
         default:
             return static_cast<int>(hipErrorInvalidValue);
     }
+    return static_cast<int>(hipGetLastError());
+}
+
+// tools/perf/r4/store_patterns.py: see store_experiment. threads = 64 .. 1024 per block.
+int memb_ceiling_store_experiment(float* out, unsigned long long words, int experiment, int stores, int delay, int threads, void* stream)
+{
+    if (!out || words == 0 || stores < 1 || threads < 64 || threads > 1024 || threads % 64) {
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    const unsigned long long pieces = words * (ROW_FLOATS / 4);
+    const unsigned long long perWave = static_cast<unsigned long long>(experiment == 0 ? 1 : stores) * WAVE;
+    const unsigned long long waves = (pieces + perWave - 1) / perWave;
+    const unsigned long long blocks = (waves * WAVE + threads - 1) / threads;
+    hipLaunchKernelGGL(store_experiment, dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float4*>(out), pieces, experiment, stores, delay);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -776,8 +776,8 @@ __global__ void decode_records_persistent(TrainedParams p)
 // every other `dim` floats of the merged rows -- half lines, twice, far apart in time (2.7 TB/s
 // against 4.4 TB/s for dense rows). Here one wavefront decodes its tile of the batch for ALL
 // models (each into a symbol tile of its own) and then writes the merged rows whole.
-// One tile per wavefront (union batches are random lookups; the persistent pipeline buys
-// nothing there), COUNT models of the same geometry (dim, lanes per word) and key format.
+// One tile per wavefront (union batches are random lookups), COUNT models of the same geometry
+// (dim, lanes per word) and key format.
 // AVERAGE: the 'average' mode instead (python/memb/readers_union.py:5-18, numpy.mean over the
 // readers): the models' vectors are added in reader order and divided by COUNT in registers --
 // the operations numpy performs, so the same bits -- and the row is written once, where separate
@@ -787,9 +787,8 @@ constexpr int UNION_MAX_MODELS = 4;
 struct UnionParams {
     TrainedParams model[UNION_MAX_MODELS];   // out / ld shared, colOff per model; n, wordsPerWave etc. equal
     uint32_t tableOffsetDwords[UNION_MAX_MODELS];
-    // inside one wavefront's LDS area: where model m's bitstream slots and symbol tile live. The one-tile
-    // kernel gives every model slots of its own; the persistent kernel decodes the models one after the
-    // other out of ONE set of slots (the largest model's), so only the symbol tiles are per model.
+    // inside one wavefront's LDS area: where model m's bitstream slots and symbol tile live (decode_trained_union:
+    // slots and a tile per model; decode_union_split: one set of slots, one tile, [1] = where model 1's rows begin in it)
     uint32_t slotOffsetDwords[UNION_MAX_MODELS];
     uint32_t keyTileOffsetDwords[UNION_MAX_MODELS];
     uint32_t codebookOffsetDwords;   // model m's codebook at this + m * 512 dwords
@@ -986,8 +985,8 @@ __device__ __forceinline__ void outputUnionTile(
     }
 }
 
-// One tile per wavefront: for tiles too wide for the persistent kernel's registers, and for batches
-// of less than one tile per resident wavefront.
+// One tile per wavefront, the models' decodes one after the other: unions of three or four models and pairs that
+// decode_union_split does not take (no row records, row regions too different in size).
 template <bool HAS_SUB, bool FAST, int COUNT, bool AVERAGE>
 __global__ void decode_trained_union(UnionParams u)
 {

@@ -358,6 +358,20 @@ def box_ceilings(torch, timer, out, words, launches=20, union=None, patterns=Non
         result['union_tile_fill_random_records'] = {
             'what': 'the union shape: {} merged rows of 600 floats, a tile = 4 rows, eight 160-byte records at random rows of two arrays, 25 % of them absent (not loaded)'.format(batch),
             'ms': ms, 'bytes_moved_GBps': (4.0 * batch * 600 + 160.0 * 2 * 0.75 * batch) / (ms * 1e-3) / 1e9}
+    if patterns is None or 9 in patterns:
+        uniform_rows = min(500000, rows)
+        wide = torch.randint(0, 2 ** 31 - 1, (uniform_rows, 80), dtype=torch.int32, device=device, generator=generator)   # 320 B per row
+        target = out[:uniform_rows]
+
+        def call():
+            status = library.memb_ceiling_launch(9, target.data_ptr(), uniform_rows, wide.data_ptr(), None, uniform_rows, None, None, stream, units)
+            if status != 0:
+                raise RuntimeError('memb_ceiling_launch(9) failed: hipError {}'.format(status))
+        times = timer.launches(call, launches)
+        ms = times[len(times) // 2]
+        result['uniform_tile_fill_sequential_records'] = {
+            'what': 'the uniform storage\'s shape: {} rows of 300 floats, eight rows per wavefront, 320-byte row records of consecutive rows read first (dequant_uniform_tile\'s loads and stores)'.format(uniform_rows),
+            'ms': ms, 'bytes_moved_GBps': uniform_rows * 1520.0 / (ms * 1e-3) / 1e9}
     return result
 
 

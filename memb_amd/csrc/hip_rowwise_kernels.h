@@ -18,7 +18,7 @@ struct UniformParams {
     unsigned long long colOff;
     // ROW RECORDS: row r owns regionPieces 16-byte pieces at piece r * regionPieces: piece 0 = {min, max, 0, 0},
     // the quantised weights (one byte each, zero padded) from piece 1 on. A lookup is one address computation
-    // and one contiguous fetch; the persistent kernel moves whole regions into LDS by LDS-DMA.
+    // and one contiguous fetch; the tile kernel moves whole regions into LDS.
     const uint4* records;
     uint32_t regionPieces;   // 1 + ceil(dim / 16)
     unsigned long long nRows;
@@ -26,8 +26,8 @@ struct UniformParams {
     uint32_t wordsPerBlock;
     uint32_t pieceMagic;     // ceil(2^32 / (dim / 4)), vector path
     float levels;
-    // dequant_uniform_persistent
-    uint32_t wordsPerWave;   // words of a wavefront's tile: their regions fill at most UNIFORM_ROUNDS 64-lane rounds
+    // dequant_uniform_tile
+    uint32_t wordsPerWave;   // words of a wavefront's tile
     uint32_t regionMagic;    // fastDivide magic for regionPieces
 };
 
@@ -135,121 +135,89 @@ __global__ void dequant_uniform(UniformParams p)
     }
 }
 
-// The persistent, pipelined form (dense 16-byte aligned output rows, dim a multiple of 4). The one-block-per-
-// 13-words kernel above is latency bound: a block lives for three dependent global hops (row ids -> region ->
-// stores) and moves 15 KB in that time (profiles/r03_uniform_before_*: wavefronts wait 76 % of their cycles,
-// 0.56 of the HBM peak). Here a wavefront owns tiles of wordsPerWave words and walks them with the pipeline of
-// decode_records_persistent: while tile t is converted and stored out of one set of LDS slots, the regions of
-// tile t + 1 land in the other by LDS-DMA and the row ids of tiles t + 2 and t + 3 are on their way.
-constexpr int UNIFORM_ROUNDS = 3;   // 64-lane LDS-DMA rounds per tile
-
-__device__ __forceinline__ void issueUniformDma(const UniformParams& p, uint32_t row, uint32_t lane, uint32_t* slots)
-{
-    const uint32_t start = row < p.nRows ? row * p.regionPieces : 0u;   // absent words fetch row 0 and store zeros
-    const uint32_t totalPieces = p.wordsPerWave * p.regionPieces;
-#pragma unroll
-    for (int round = 0; round < UNIFORM_ROUNDS; ++round) {
-        const uint32_t q = round * WAVE + lane;
-        const uint32_t w = fastDivide(min(q, totalPieces - 1), p.regionMagic, p.regionPieces);
-        const uint32_t wordStart = __shfl(start, w);   // (every lane active here)
-        if (q < totalPieces) {
-            const uint4* source = p.records + (static_cast<unsigned long long>(wordStart) + (q - w * p.regionPieces));
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)source,
-                (__attribute__((address_space(3))) void*)(slots + round * WAVE * 4), 16, 0, 0);
-        }
-    }
-}
-
+// Row of the tile's word `lane` (lanes past the tile's words and past the batch: MISSING).
 __device__ __forceinline__ uint32_t loadUniformRow(const UniformParams& p, unsigned long long tile, uint32_t lane)
 {
     const unsigned long long index = tile * p.wordsPerWave + lane;
     return lane < p.wordsPerWave && index < p.n ? p.rows[index] : 0xFFFFFFFFu;
 }
 
+// One tile per wavefront at a time, short-lived blocks -- the shape that won every large batch of the trained storage in
+// round 4 (decode_trained), for the uniform one: a wavefront owns wordsPerWave words (8 at dim 300: 9600 bytes of output, a
+// whole number of 128-byte lines), fetches their row regions with 16-byte loads into its own LDS slots, converts and
+// stores, and exits. No tables to copy, so no block barrier at all. Round 3's form was a persistent pipeline fed by
+// LDS-DMA (dequant_uniform_persistent, 0.58-0.60 of the HBM peak on the 500 000-word dump); the memory pattern alone
+// (tools/perf/ceilings.hip, uniform_rows_per_wave<8>) runs that dump in 0.137 ms where the pipeline took 0.157-0.164, and
+// this kernel takes 0.136: -17 % on the dump, -12 % shuffled, -16 % on 2 M rows, ties at 1 k and 10 k rows; the pipeline
+// was 8 % ahead at 100 000 rows (two to four tiles per resident wavefront, as for the trained storage), which no BASELINE
+// configuration is: removed (round 4, batch 16).
 template <bool FLAT>
-__global__ void dequant_uniform_persistent(UniformParams p)
+__global__ void dequant_uniform_tile(UniformParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t uniformLds[];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = threadIdx.x / WAVE;
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
-    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
-    if (tile >= tiles) {
+    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    const unsigned long long tileBase = tile * p.wordsPerWave;
+    if (tileBase >= p.n) {
         return;
     }
-    const uint32_t setDwords = p.wordsPerWave * p.regionPieces * 4;
-    uint32_t* slots = uniformLds + wave * 2 * setDwords;
-    uint32_t* otherSlots = slots + setDwords;
+    const uint32_t tileWords = static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+    uint32_t* slots = uniformLds + wave * p.wordsPerWave * p.regionPieces * 4;
+    const uint32_t row = loadUniformRow(p, tile, lane);              // lane w: the row of the tile's word w
+    const unsigned long long absent = __ballot(row >= p.nRows);      // bit w: word w is missing (or past the batch)
+    const uint32_t start = row < p.nRows ? row * p.regionPieces : 0u;   // absent words fetch row 0 and store zeros
+    const uint32_t totalPieces = tileWords * p.regionPieces;
+    for (uint32_t q0 = 0; q0 < totalPieces; q0 += WAVE) {
+        const uint32_t q = min(q0 + lane, totalPieces - 1);
+        const uint32_t w = fastDivide(q, p.regionMagic, p.regionPieces);
+        const uint32_t wordStart = __shfl(start, w);   // (every lane active here)
+        if (q0 + lane < totalPieces) {
+            const uint4 piece = p.records[static_cast<unsigned long long>(wordStart) + (q - w * p.regionPieces)];
+            *reinterpret_cast<uint4*>(slots + 4 * q) = piece;
+        }
+    }
+    waveLdsFence();
+
     const uint32_t piecesPerWord = p.dim / 4;
     const bool hasEpilogue = p.accumulate || p.divisor != 0.f;
-
-    // Round t: wait for what round t - 1 issued (tile t's regions, tile t + 1's row ids, and its own stores) |
-    // start tile t + 1's regions into the other slot set and the row ids of tile t + 2 | convert and store tile t.
-    // The loads of a round have the whole conversion of the tile before them to land.
-    uint32_t rowCurrent = loadUniformRow(p, tile, lane);
-    uint32_t rowNext = loadUniformRow(p, tile + stride, lane);
-    issueUniformDma(p, rowCurrent, lane, slots);
-
-    for (; tile < tiles; tile += stride) {
-        const unsigned long long tileBase = tile * p.wordsPerWave;
-        const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        waveLdsFence();
-        uint32_t rowAfter;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(rowAfter) : "v"(rowNext));
-        issueUniformDma(p, rowAfter, lane, otherSlots);
-        rowNext = loadUniformRow(p, tile + 2 * stride, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long absent = __ballot(rowCurrent >= p.nRows);   // bit w: word w of the tile is missing
-
-        const uint32_t pieces = tileWords * piecesPerWord;
-        float* tileOut = p.out + tileBase * p.ld + p.colOff;
-        constexpr int BURST = 4;
-        for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
-            uint32_t packed[BURST];
-            float2 minMax[BURST];
-            uint32_t word[BURST];
-            uint32_t column[BURST];
+    const uint32_t pieces = tileWords * piecesPerWord;
+    float* tileOut = p.out + tileBase * p.ld + p.colOff;
+    constexpr int BURST = 4;
+    for (uint32_t q0 = lane; q0 < pieces; q0 += WAVE * BURST) {
+        uint32_t packed[BURST];
+        float2 minMax[BURST];
+        uint32_t word[BURST];
+        uint32_t column[BURST];
 #pragma unroll
-            for (int b = 0; b < BURST; ++b) {
-                const uint32_t q = min(q0 + WAVE * b, pieces - 1);
-                word[b] = fastDivide(q, p.pieceMagic, piecesPerWord);
-                column[b] = q - word[b] * piecesPerWord;
-                const uint32_t* region = slots + word[b] * p.regionPieces * 4;
-                minMax[b] = *reinterpret_cast<const float2*>(region);
-                packed[b] = region[4 + column[b]];
-            }
+        for (int b = 0; b < BURST; ++b) {
+            const uint32_t q = min(q0 + WAVE * b, pieces - 1);
+            word[b] = fastDivide(q, p.pieceMagic, piecesPerWord);
+            column[b] = q - word[b] * piecesPerWord;
+            const uint32_t* region = slots + word[b] * p.regionPieces * 4;
+            minMax[b] = *reinterpret_cast<const float2*>(region);
+            packed[b] = region[4 + column[b]];
+        }
 #pragma unroll
-            for (int b = 0; b < BURST; ++b) {
-                if (q0 + WAVE * b < pieces) {
-                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!((absent >> word[b]) & 1)) {
-                        const float range = subRn(minMax[b].y, minMax[b].x);
-                        f.x = dequant(minMax[b].x, range, packed[b] & 0xff, p.levels);
-                        f.y = dequant(minMax[b].x, range, (packed[b] >> 8) & 0xff, p.levels);
-                        f.z = dequant(minMax[b].x, range, (packed[b] >> 16) & 0xff, p.levels);
-                        f.w = dequant(minMax[b].x, range, packed[b] >> 24, p.levels);
-                    }
-                    float* destination = FLAT ? tileOut + 4 * static_cast<size_t>(q0 + WAVE * b)
-                                              : tileOut + word[b] * p.ld + 4 * column[b];
-                    if (hasEpilogue) {
-                        f = epilogue4(f, destination, p.accumulate, p.divisor);
-                    }
-                    *reinterpret_cast<float4*>(destination) = f;
+        for (int b = 0; b < BURST; ++b) {
+            if (q0 + WAVE * b < pieces) {
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!((absent >> word[b]) & 1)) {
+                    const float range = subRn(minMax[b].y, minMax[b].x);
+                    f.x = dequant(minMax[b].x, range, packed[b] & 0xff, p.levels);
+                    f.y = dequant(minMax[b].x, range, (packed[b] >> 8) & 0xff, p.levels);
+                    f.z = dequant(minMax[b].x, range, (packed[b] >> 16) & 0xff, p.levels);
+                    f.w = dequant(minMax[b].x, range, packed[b] >> 24, p.levels);
                 }
+                float* destination = FLAT ? tileOut + 4 * static_cast<size_t>(q0 + WAVE * b)
+                                          : tileOut + word[b] * p.ld + 4 * column[b];
+                if (hasEpilogue) {
+                    f = epilogue4(f, destination, p.accumulate, p.divisor);
+                }
+                *reinterpret_cast<float4*>(destination) = f;
             }
         }
-        waveLdsFence();
-        __builtin_amdgcn_sched_barrier(0);
-        rowCurrent = rowAfter;
-        uint32_t* swap = slots;
-        slots = otherSlots;
-        otherSlots = swap;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be landing when the block's LDS is handed on
 }
 
 struct FullParams {

@@ -963,27 +963,34 @@ int launchUniform(
     params.levels = ctx->levels;
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    // The persistent LDS-DMA pipeline: 16-byte output pieces, a tile's regions within UNIFORM_ROUNDS rounds, and
-    // more than one tile per resident wavefront (smaller batches: the block-per-13-words kernel below spreads wider).
-    const uint32_t wordsPerWave = std::min<uint32_t>(WAVE, UNIFORM_ROUNDS * WAVE / std::max<uint32_t>(ctx->regionPieces, 1));
-    if (vec && wordsPerWave >= 1 && ctx->switches.persistent && n >= size_t(wordsPerWave) * ctx->cuCount * 16 &&
-        uint64_t(ctx->nRows + 1) * ctx->regionPieces < (1ull << 32)) {
-        params.wordsPerWave = wordsPerWave;
-        params.regionMagic = magicFor(ctx->regionPieces, uint64_t(UNIFORM_ROUNDS) * WAVE);
-        params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
-        const uint32_t waves = 4;
-        const uint32_t threads = waves * WAVE;
-        const uint32_t ldsBytes = waves * 2 * wordsPerWave * ctx->regionPieces * 16;
-        const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
-        const uint32_t tileBlocks = static_cast<uint32_t>((tiles + waves - 1) / waves);
+    // One tile per wavefront (dequant_uniform_tile) whenever output pieces are 16 bytes and a tile's row regions fit into
+    // LDS (blocks of four wavefronts, fewer for very wide rows); `persistent` = 0 keeps the block kernel (tests).
+    const uint32_t tileWords = std::max<uint32_t>(1, std::min<uint32_t>(WAVE, (9600 + ctx->dim * 4 - 1) / (ctx->dim * 4)));
+    uint32_t waves = 4;
+    while (waves > 1 && uint64_t(waves) * tileWords * ctx->regionPieces * 16 > ctx->ldsLimit) {
+        waves /= 2;
+    }
+    if (vec && ctx->switches.persistent != 0 && uint64_t(ctx->nRows + 1) * ctx->regionPieces < (1ull << 32) &&
+        uint64_t(waves) * tileWords * ctx->regionPieces * 16 <= ctx->ldsLimit) {
+        params.wordsPerWave = tileWords;
+        params.regionMagic = magicFor(ctx->regionPieces, uint64_t(tileWords) * ctx->regionPieces + WAVE);
+        params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(tileWords) * (ctx->dim / 4));
+        const uint32_t ldsBytes = waves * tileWords * ctx->regionPieces * 16;
+        const uint64_t tiles = (n + tileWords - 1) / tileWords;
         const bool flat = ld == ctx->dim && colOff == 0;
-        void (*kernel)(UniformParams) = flat ? &dequant_uniform_persistent<true> : &dequant_uniform_persistent<false>;
-        hipError_t launched = launchPersistentGeneric(
-            ctx, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
-            }, tileBlocks, threads, ldsBytes);
-        if (launched != hipSuccess) {
-            return fail(MEMB_HIP_ERR_DEVICE, std::string("dequant_uniform_persistent launch: ") + hipGetErrorString(launched));
+        void (*kernel)(UniformParams) = flat ? &dequant_uniform_tile<true> : &dequant_uniform_tile<false>;
+        hipError_t status;
+        {
+            std::lock_guard<std::mutex> lock(g_kernelFactsMutex);   // (raises the kernel's LDS limit on first use)
+            KernelFacts* facts = nullptr;
+            status = kernelFactsLocked(reinterpret_cast<const void*>(kernel), &facts);
+        }
+        if (status == hipSuccess) {
+            hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((tiles + waves - 1) / waves)), dim3(waves * WAVE), ldsBytes, stream, params);
+            status = hipGetLastError();
+        }
+        if (status != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("dequant_uniform_tile launch: ") + hipGetErrorString(status));
         }
         return MEMB_HIP_OK;
     }
@@ -1916,12 +1923,10 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         }
     } else {
         info->waves_per_block = ROWWISE_THREADS / WAVE;
-        const uint32_t uniformWordsPerWave = std::min<uint32_t>(WAVE, UNIFORM_ROUNDS * WAVE / std::max<uint32_t>(ctx->regionPieces, 1));
-        const bool pipelined = ctx->storage == memb::wire::Storage_Uniform && ctx->dim % 4 == 0 && ctx->switches.persistent &&
-            uniformWordsPerWave >= 1 && (!batchWords || batchWords >= uint64_t(uniformWordsPerWave) * ctx->cuCount * 16);
+        const bool tiled = ctx->storage == memb::wire::Storage_Uniform && ctx->dim % 4 == 0 && ctx->switches.persistent != 0;
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<true>",
-            pipelined ? "dequant_uniform_persistent" : ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");
+            tiled ? "dequant_uniform_tile" : ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");
     }
     return MEMB_HIP_OK;
 }

@@ -521,7 +521,7 @@ def test_uniform_expression_vectors_on_device(native, tmp_path):
             context, ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(pairs)),
             out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(values)), ctypes.c_size_t(0))
         assert code == 0, library.memb_hip_last_error()
-        # the same rows many times over: a batch large enough for dequant_uniform_persistent (LDS-DMA pipeline)
+        # the same rows many times over, with missing rows: a large batch (many tiles per CU, a ragged last tile)
         many = np.tile(ids, 70000 // len(ids) + 1)
         many[5::1001] = 0xFFFFFFFF
         out_many = np.empty((len(many), len(values)), dtype=np.float32)
@@ -1088,20 +1088,22 @@ def test_union_split_with_first_levels_of_different_widths(native, make_model):
             assert bits_equal(mean.cpu().numpy(), np.mean([expected[k] for k in order], axis=0)), (bits_a, bits_b, order)
 
 
-def test_uniform_persistent_pipeline(native, make_model):
-    """dequant_uniform_persistent (row records fetched by LDS-DMA; batches of more than one tile per resident
-    wavefront) against the checker: dense, strided, accumulate / divide epilogue, unaligned output (which takes the
-    block kernel), missing rows, a ragged last tile; bit-exact as every uniform result."""
+def test_uniform_tile_kernel(native, make_model):
+    """dequant_uniform_tile (one tile of eight words per wavefront, row regions through LDS) and the block kernel
+    (option 'persistent' = 0; also what unaligned output takes) against the checker: dense, strided, accumulate / divide
+    epilogue, unaligned output, missing rows, a ragged last tile, tiny batches; bit-exact as every uniform result."""
     import torch
     path, words = make_model(3000, 300, 'uniform', 8)
     reader = native.Reader(path, device=0)
     checker = oracle.OracleReader(path)
-    assert reader.info()['kernel'].startswith('dequant_uniform')
+    assert reader.info()['kernel'].startswith('dequant_uniform_tile')
     rng = np.random.default_rng(8)
-    for count in (60001, 36863):
+    for count, block_kernel in ((60001, 0), (36863, 0), (60001, 1), (7, 0), (1, 0)):
+        reader.set_option('persistent', 0 if block_kernel else 1)
+        assert reader.info()['kernel'].startswith('dequant_uniform<' if block_kernel else 'dequant_uniform_tile<')
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)
         rows[rng.random(count) < 0.03] = 0xFFFFFFFF
-        rows[:3000] = np.arange(3000, dtype=np.uint32)
+        rows[:min(count, 3000)] = np.arange(min(count, 3000), dtype=np.uint32)
         expected = checker.rows_embedding(rows)
         ids = torch.from_numpy(rows.view(np.int32)).cuda()
         assert bits_equal(reader.rows_embedding_device(ids).cpu().numpy(), expected)
@@ -1116,3 +1118,4 @@ def test_uniform_persistent_pipeline(native, make_model):
         reader.rows_embedding_device(ids, out=accumulated, accumulate=True, divisor=2.0)
         assert bits_equal(accumulated.cpu().numpy(), (np.float32(0.5) + expected) / np.float32(2.0))
         assert bits_equal(reader.rows_embedding(rows), expected)   # host buffers
+    reader.set_option('persistent', 1)

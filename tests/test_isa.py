@@ -35,7 +35,7 @@ def test_the_kernel_zoo_is_what_design_md_says(kernels):
     families = {name.split('(anonymous namespace)::')[1].split('<')[0].split('(')[0] for name in kernels}
     assert families == {
         'decode_trained', 'decode_records_persistent', 'decode_union_split', 'decode_trained_union',
-        'dequant_uniform', 'dequant_uniform_persistent', 'gather_full',
+        'dequant_uniform', 'dequant_uniform_tile', 'gather_full',
         'repack_streams', 'pack_row_meta',
         'quantise_rows', 'stream_lengths', 'pack_streams'}, families
 

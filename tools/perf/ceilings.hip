@@ -183,6 +183,46 @@ __global__ void store_experiment(float4* out, unsigned long long pieces, int exp
     }
 }
 
+// Uniform-storage shapes (tools/perf/r4/store_patterns.py): a row's record is 20 pieces (320 B: {min, max} + 300 weights).
+//   ROWS = 1: one row per wavefront -- 20 lanes load the record, the row leaves as TWO stores (1 KiB + 176 B), exit
+//   ROWS = 8: eight rows per wavefront -- 160 pieces in three rounds, 9600 B as ten stores, exit
+template <int ROWS>
+__global__ void uniform_rows_per_wave(Params p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 4 * 20 * 8];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const unsigned long long first = (static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave) * ROWS;
+    if (first >= p.words) {
+        return;
+    }
+    uint32_t* slots = lds + wave * 4 * 20 * 8;
+    constexpr uint32_t RECORD = 20;
+    for (uint32_t q = lane; q < ROWS * RECORD; q += WAVE) {
+        const uint32_t w = q / RECORD;
+        const unsigned long long word = first + w;
+        unsigned long long row = word < p.words ? (p.ids ? p.ids[word] : word) : 0xFFFFFFFFull;
+        u32x4 v = {0, 0, 0, 0};
+        if (row < p.rows) {
+            v = p.records[row * RECORD + (q - w * RECORD)];
+        }
+        *reinterpret_cast<u32x4*>(slots + 4 * q) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long endPiece = p.words * (ROW_FLOATS / 4);
+    float4* out = reinterpret_cast<float4*>(p.out) + first * (ROW_FLOATS / 4);
+    for (uint32_t q = lane; q < ROWS * (ROW_FLOATS / 4); q += WAVE) {
+        const uint32_t w = q / (ROW_FLOATS / 4);
+        const uint32_t key = slots[4 * RECORD * w + 4 + (q - w * (ROW_FLOATS / 4))];   // the piece's four weights
+        float4 value = make_float4(1.f, 2.f, 3.f, 4.f);
+        value.x = __uint_as_float(key & 0x3f800000u);
+        if (first * (ROW_FLOATS / 4) + q < endPiece) {
+            out[q] = value;
+        }
+    }
+}
+
 // union: 4 words per tile, each 600 floats wide; records of the 4 words from both arrays (slots 0-3 / 4-7)
 __global__ void union_tile_per_wave(Params p)
 {
@@ -270,6 +310,12 @@ int memb_ceiling_launch(
         case 4: hipLaunchKernelGGL(tiles_persistent<0>, dim3(tileBlocks < resident ? tileBlocks : resident), dim3(256), 0, s, p); break;
         case 5: hipLaunchKernelGGL(tiles_persistent<1>, dim3(tileBlocks < resident ? tileBlocks : resident), dim3(256), 0, s, p); break;
         case 6: hipLaunchKernelGGL(tiles_persistent<2>, dim3(tileBlocks < resident ? tileBlocks : resident), dim3(256), 0, s, p); break;
+        case 8:   // (records: rows x 320 bytes here; ids may be null = consecutive rows)
+            hipLaunchKernelGGL(uniform_rows_per_wave<1>, dim3(static_cast<uint32_t>((words + 3) / 4)), dim3(256), 0, s, p);
+            break;
+        case 9:
+            hipLaunchKernelGGL(uniform_rows_per_wave<8>, dim3(static_cast<uint32_t>(((words + 7) / 8 + 3) / 4)), dim3(256), 0, s, p);
+            break;
         case 7: {
             const unsigned long long unionTiles = (words + TILE_ROWS / 2 - 1) / (TILE_ROWS / 2);
             hipLaunchKernelGGL(union_tile_per_wave, dim3(static_cast<uint32_t>((unionTiles + 3) / 4)), dim3(256), 0, s, p);

@@ -43,3 +43,27 @@ for stores in (3, 10):
 for stores in (3, 10):
     for delay in (1, 2, 5):
         run('%2d stores per wavefront, %4.1f us of sleep BETWEEN stores, blocks of 256' % (stores, delay * 0.43), 2, stores, delay, 256)
+
+
+# uniform-storage shapes: one row per wavefront (two stores) against eight rows per wavefront (ten stores), 320-byte records
+library.memb_ceiling_launch.restype = ctypes.c_int
+library.memb_ceiling_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+generator = torch.Generator(device='cuda')
+generator.manual_seed(31)
+for rows in (500000, 2196017):
+    records = torch.randint(0, 2 ** 31 - 1, (rows, 80), dtype=torch.int32, device='cuda', generator=generator)   # 320 B per row
+    ids = torch.randperm(rows, device='cuda', generator=generator).to(torch.int32)
+    target = out[:rows]
+    for pattern, name in ((8, 'one row per wavefront (2 stores)'), (9, 'eight rows per wavefront (10 stores)')):
+        for order, id_pointer in (('consecutive rows', None), ('random rows', ids.data_ptr())):
+            def call():
+                status = library.memb_ceiling_launch(pattern, target.data_ptr(), rows, records.data_ptr(), None, rows, id_pointer, None, stream, 256)
+                assert status == 0, status
+            times = timer.launches(call, 20)
+            median = times[len(times) // 2]
+            if median < 0.2:
+                median = timer.bursts(call, 50)[2]
+            moved = rows * (1200 + 320) / 1e9
+            print('uniform shape, %7d rows, %-38s %-16s %.4f ms  %.2f TB/s of bytes moved' % (rows, name, order, median, moved / median), flush=True)
+    del records, ids

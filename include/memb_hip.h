@@ -164,7 +164,7 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
 /*
  * Tuning knobs of a live context (results never depend on them). Unknown names and values
  * out of range return MEMB_HIP_ERR_INVALID and change nothing.
- *   "waves_per_block" 0 = choose (four; eight for dumps of nibble-key models), or 1, 2, 4, 8 (16: measurements)
+ *   "waves_per_block" 0 = choose (four; eight for dumps of nibble-key models), or 1 .. 16
  *   "persistent"      1 (default) = the kernel by batch size: decode_trained (one tile per wavefront at a time), except
  *                     decode_records_persistent for two to four tiles per 16 wavefronts per CU (65 000 - 131 000 words on 256 CUs);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows

@@ -264,7 +264,7 @@ TrainedGeometry chooseGeometry(
 {
     TrainedGeometry best{};
     double bestWaves = -1;
-    const uint32_t forcedWaves = ctx->switches.waves;   // (1, 2, 4, 8 or, measurements only, 16)
+    const uint32_t forcedWaves = ctx->switches.waves;   // (1 .. 16; anything but 1, 2, 4, 8: measurements)
     const uint32_t order[5] = {forcedWaves ? forcedWaves : preferred, 4u, 8u, 2u, 1u};
     for (uint32_t waves : order) {
         if (forcedWaves && waves != forcedWaves) {
@@ -1855,7 +1855,7 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
     }
     const std::string key(name);
     std::lock_guard<std::mutex> lock(ctx->mutex);
-    if (key == "waves_per_block" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {
+    if (key == "waves_per_block" && value <= 16) {
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "tiles_per_wave" && value <= 64) {
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);

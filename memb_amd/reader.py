@@ -50,6 +50,15 @@ class BaseReader(ABC):
         pass
 
 
+def _current_stream(torch, index):
+    '''torch's current stream on device `index` as a raw hipStream_t (the C call behind torch.cuda.current_stream,
+    without building a Stream object: a microsecond per lookup)'''
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:
+        return raw(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
 def tokenizer_word_list(tokenizer):
     """The words of a keras Tokenizer placed at their indices, '' where an index
     has no word (index 0 never has one). With `num_words` set only indices below
@@ -161,21 +170,23 @@ class Reader(BaseReader):
         accumulate : add the rows to what `out` holds instead of overwriting it
         divisor : if non-zero, divide the (accumulated) rows by it
         '''
+        # (a small batch is seven microseconds of which the kernel is three: every attribute is fetched once)
         import torch
-        if rows.device.type != 'cuda' or rows.dtype not in (torch.int32, torch.uint32) or not rows.is_contiguous():
+        device = rows.device
+        if device.type != 'cuda' or rows.dtype not in (torch.int32, torch.uint32) or not rows.is_contiguous():
             raise TypeError('rows must be a contiguous int32/uint32 tensor on the GPU')
         n = rows.numel()
         if out is None:
-            out = torch.empty((n, col_off + self.dim), dtype=torch.float32, device=rows.device)
+            out = torch.empty((n, col_off + self.dim), dtype=torch.float32, device=device)
         if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n:
             raise TypeError('out must be a float32 (n, width) tensor with unit column stride')
         # the kernel runs on this reader's device with these pointers: both tensors must live there
-        if rows.device.index != self.device or out.device != rows.device:
+        index = device.index
+        if index != self._impl.device() or out.device != device:
             raise ValueError('rows and out must be on cuda:{} (the device this reader is staged on), got {} and {}'.format(
-                self.device, rows.device, out.device))
-        stream = torch.cuda.current_stream(rows.device).cuda_stream
+                self.device, device, out.device))
         self._impl.rows_to_device(
-            rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, stream, accumulate, float(divisor))
+            rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, _current_stream(torch, index), accumulate, float(divisor))
         return out
 
     def batch_embedding_device(self, words):

@@ -1,7 +1,8 @@
 // libmemb_ceilings.so -- what this GPU does with the decoder's MEMORY pattern and nothing else.
 //
 // Measurement code, not product: bench.py loads it (ctypes) to put the box's own ceilings next to the
-// kernel's time in the JSON line (`roofline.box_ceilings`), tools/perf/ceilings.py prints the table.
+// kernel's time in the JSON line (`roofline.box_ceilings`); tools/perf/r4/small_ceilings.py and store_patterns.py
+// run the same entry points at other sizes and shapes.
 // No decode, no tables; every pattern writes `words` rows of 300 floats (the 2.2 M-word dump: 2.635 GB)
 // and, from pattern 2 on, reads what a decoder of row records reads -- the stored values DEPEND on the
 // loaded bytes (through LDS, as in the decoder), so no load can be dropped or overtaken by its tile's stores.
@@ -11,10 +12,11 @@
 //   2  1 + the tile's 8 records read first, SEQUENTIAL rows (8 x 160 B = 1280 consecutive bytes) -- a key-order dump
 //   3  1 + the tile's 8 records at RANDOM rows (row ids from an array; 160-byte records at 32-byte
 //      alignment: two 128-byte lines each)                                                      -- random / shuffled rows
-//   4  persistent tiles: 16 wavefronts per CU walk the tiles, write only                        -- decode_trained_persistent's stores
+//   4  persistent tiles: 16 wavefronts per CU walk the tiles, write only                        -- a persistent pipeline's stores
 //   5  4 + sequential records, the next tile's loads in flight while this tile is stored
 //   6  4 + random records, same prefetch
 //   7  union shape: a tile is 4 merged rows of 600 floats (9600 B), 8 records at random rows of TWO arrays
+//   8, 9  uniform-storage shapes (320-byte records): one row per wavefront / eight rows per wavefront
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (build_native.py). gfx950 only.
 #include <hip/hip_runtime.h>

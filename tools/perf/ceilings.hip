@@ -225,6 +225,69 @@ __global__ void uniform_rows_per_wave(Params p)
     }
 }
 
+// A parametrised tile pattern (tools/perf/r4/tile_patterns.py): `rowsPerTile` rows per wavefront (records of consecutive or
+// random rows read first, through LDS), `delay` x ~0.43 us of sleeping between the loads and the stores (a decode's
+// latency), and the order of the stores: 0 = the wavefront's own tile, ascending; 1 = descending; 2 = after a block
+// barrier the block's wavefronts sweep the block's region together (wavefront w stores KiB w, w + W, ...).
+__global__ void tile_experiment(Params p, int rowsPerTile, int delay, int order)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t wavesPerBlock = blockDim.x / WAVE;
+    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave;
+    const uint32_t recordPieces = static_cast<uint32_t>(rowsPerTile) * RECORD_PIECES;
+    uint32_t* slots = dynamicLds + wave * recordPieces * 4;
+    const bool active = tile * rowsPerTile < p.words;
+    if (active) {
+        for (uint32_t q = lane; q < recordPieces; q += WAVE) {
+            const uint32_t w = q / RECORD_PIECES;
+            const unsigned long long word = tile * rowsPerTile + w;
+            const unsigned long long row = word < p.words ? (p.ids ? p.ids[word] : word) : 0xFFFFFFFFull;
+            u32x4 v = {0, 0, 0, 0};
+            if (row < p.rows) {
+                v = p.records[row * RECORD_PIECES + (q - w * RECORD_PIECES)];
+            }
+            *reinterpret_cast<u32x4*>(slots + 4 * q) = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < delay; ++i) {
+        __builtin_amdgcn_s_sleep(16);
+    }
+    const unsigned long long endPiece = p.words * (ROW_FLOATS / 4);
+    const uint32_t tilePieces = static_cast<uint32_t>(rowsPerTile) * (ROW_FLOATS / 4);
+    if (order == 2) {
+        __syncthreads();
+        const unsigned long long blockFirst = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock * tilePieces;
+        const uint32_t blockPieces = wavesPerBlock * tilePieces;
+        float4* out = reinterpret_cast<float4*>(p.out) + blockFirst;
+        for (uint32_t q = wave * WAVE + lane; q < blockPieces; q += wavesPerBlock * WAVE) {
+            float4 value = make_float4(1.f, 2.f, 3.f, 4.f);
+            value.x = __uint_as_float(dynamicLds[q % (wavesPerBlock * recordPieces * 4)] & 0x3f800000u);
+            if (blockFirst + q < endPiece) {
+                out[q] = value;
+            }
+        }
+        return;
+    }
+    if (!active) {
+        return;
+    }
+    const unsigned long long firstPiece = tile * tilePieces;
+    float4* out = reinterpret_cast<float4*>(p.out) + firstPiece;
+    const uint32_t rounds = (tilePieces + WAVE - 1) / WAVE;
+    for (uint32_t k = 0; k < rounds; ++k) {
+        const uint32_t q = (order == 1 ? rounds - 1 - k : k) * WAVE + lane;
+        float4 value = make_float4(1.f, 2.f, 3.f, 4.f);
+        value.x = __uint_as_float(slots[q % (recordPieces * 4)] & 0x3f800000u);
+        if (q < tilePieces && firstPiece + q < endPiece) {
+            out[q] = value;
+        }
+    }
+}
+
 // union: 4 words per tile, each 600 floats wide; records of the 4 words from both arrays (slots 0-3 / 4-7)
 __global__ void union_tile_per_wave(Params p)
 {
@@ -326,6 +389,32 @@ int memb_ceiling_launch(
         default:
             return static_cast<int>(hipErrorInvalidValue);
     }
+    return static_cast<int>(hipGetLastError());
+}
+
+// tools/perf/r4/tile_patterns.py: see tile_experiment. ids may be null (consecutive rows); wavesPerBlock 1 .. 16.
+int memb_ceiling_tile_experiment(
+    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int rowsPerTile,
+    int wavesPerBlock, int delay, int order, void* stream)
+{
+    if (!out || !records || words == 0 || rowsPerTile < 1 || rowsPerTile > 64 || wavesPerBlock < 1 || wavesPerBlock > 16) {
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    Params p{};
+    p.out = out;
+    p.words = words;
+    p.records = static_cast<const u32x4*>(records);
+    p.rows = rows;
+    p.ids = ids;
+    const unsigned long long tiles = (words + rowsPerTile - 1) / rowsPerTile;
+    const uint32_t blocks = static_cast<uint32_t>((tiles + wavesPerBlock - 1) / wavesPerBlock);
+    const uint32_t ldsBytes = static_cast<uint32_t>(wavesPerBlock) * rowsPerTile * RECORD_PIECES * 16;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_experiment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(tile_experiment, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, rowsPerTile, delay, order);
     return static_cast<int>(hipGetLastError());
 }
 

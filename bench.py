@@ -709,6 +709,10 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
         nbytes = algorithmic_bytes(library, reader4, picks)
         small.append({'batch': count, 'kernel': reader4.info(count)['kernel'], 'us_per_launch': ms * 1e3,
                       'embeddings_per_s': count / (ms * 1e-3), 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+        if count <= 10000:
+            # the same batch through Reader.prepared_lookup: the tensors are checked once, a call is the launch
+            prepared = reader4.prepared_lookup(ids, target)
+            small[-1]['prepared_us_per_launch'] = timer.burst(prepared, 100) * 1e3
         del ids, target
     results[-1]['small_batches_of_the_same_model'] = small
 

@@ -699,6 +699,32 @@ def test_device_resident_lookup_matches_host_path(native, make_model):
     assert bool((wide[:, :40] == -1).all()) and bool((wide[:, 340:] == -1).all())
 
 
+def test_prepared_lookup(native, make_model):
+    """Reader.prepared_lookup: the checks once, then a function that only launches -- same rows as the checked call,
+    refilled ids are picked up (the function keeps pointers, not values), bad arguments are refused when it is made."""
+    import torch
+    path, words = make_model(20000, 300, 'trained', 4)
+    reader = native.Reader(path, device=0)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(41)
+    rows = rng.integers(0, len(words), size=1000).astype(np.uint32)
+    rows[::50] = 0xFFFFFFFF
+    ids = torch.from_numpy(rows.view(np.int32)).cuda()
+    out = torch.full((1000, 320), 5.0, dtype=torch.float32, device='cuda')
+    call = reader.prepared_lookup(ids, out, col_off=20)
+    for _ in range(3):
+        assert call() is out
+    assert bits_equal(out[:, 20:].cpu().numpy(), checker.rows_embedding(rows)) and bool((out[:, :20] == 5.0).all())
+    other = rng.integers(0, len(words), size=1000).astype(np.uint32)
+    ids.copy_(torch.from_numpy(other.view(np.int32)))
+    call()
+    assert bits_equal(out[:, 20:].cpu().numpy(), checker.rows_embedding(other))
+    with pytest.raises(TypeError):
+        reader.prepared_lookup(ids.cpu(), out)
+    with pytest.raises(TypeError):
+        reader.prepared_lookup(ids, out[:10])
+
+
 def test_batch_split_like_two_ranks(native, make_model):
     # the N > 1 split (memb_amd/sharding.py) through the HIP path, slices concatenated on the host
     from memb_amd.sharding import lookup_shard

@@ -699,6 +699,28 @@ def test_device_resident_lookup_matches_host_path(native, make_model):
     assert bool((wide[:, :40] == -1).all()) and bool((wide[:, 340:] == -1).all())
 
 
+def test_large_tables_take_two_tiles_per_wavefront_by_default(native, make_model):
+    """The one rule of memb_hip.hip's oneTileSteps that no BASELINE model reaches: a model whose table and codebook are 16 KiB
+    and more (8-bit: a 13-bit first level) decodes two tiles per wavefront behind one copy once the batch has two tiles
+    per resident wavefront slot -- DEFAULT options, against the checker."""
+    import torch
+    path, words = make_model(150000, 300, 'trained', 8)   # (N(0, 0.4^2): codes up to 13 bits, a 32 KiB first level)
+    reader = native.Reader(path, device=0)
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    slots = 32 * torch.cuda.get_device_properties(0).multi_processor_count
+    tile = 64 // reader.info()['lanes_per_word']
+    for count in (2 * slots * tile + 5, 2 * slots * tile - 8):
+        facts = reader.info(count)
+        assert facts['kernel'].startswith('decode_trained<') and facts['table_entries'] * 4 >= 16 * 1024
+        assert facts['tiles_per_wavefront'] == (2 if count >= 2 * slots * tile else 1), (count, facts['tiles_per_wavefront'])
+        rng = np.random.default_rng(count)
+        rows = rng.integers(0, len(words), size=count).astype(np.uint32)
+        rows[rng.integers(0, count, size=count // 100)] = 0xFFFFFFFF
+        rows[:100000] = np.arange(100000, dtype=np.uint32)
+        ids = torch.from_numpy(rows.view(np.int32)).cuda()
+        assert bits_equal(reader.rows_embedding_device(ids).cpu().numpy(), checker.rows_embedding(rows)), count
+
+
 def test_prepared_lookup(native, make_model):
     """Reader.prepared_lookup: the checks once, then a function that only launches -- same rows as the checked call,
     refilled ids are picked up (the function keeps pointers, not values), bad arguments are refused when it is made."""

@@ -1441,25 +1441,9 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
     }
     const size_t streamPieces = size_t(streamStarts[desc->n_rows]) + ctx->slotDwords / 4 + 1;   // + guard of one slot
 
-    // Placement experiments (tools/perf/ab3.py): MEMB_HIP_STREAM_ALIGN = power of two the array's first
-    // byte is aligned to (hipMalloc gives 2 MiB for large blocks), MEMB_HIP_STREAM_OFFSET = bytes added
-    // to that (multiple of 256).
-    const size_t align = envUint("MEMB_HIP_STREAM_ALIGN", 0);
-    const size_t offset = envUint("MEMB_HIP_STREAM_OFFSET", 0) / 256 * 256;
-    int code;
-    if ((align & (align - 1)) == 0 && (align || offset)) {
-        uint8_t* raw = nullptr;
-        code = deviceAlloc(ctx, &raw, streamPieces * 16 + align + offset);
-        if (code == MEMB_HIP_OK) {
-            uintptr_t first = reinterpret_cast<uintptr_t>(raw);
-            if (align) {
-                first = (first + align - 1) / align * align;
-            }
-            ctx->streams = reinterpret_cast<uint4*>(first + offset);
-        }
-    } else {
-        code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
-    }
+    // (Where the array lies does not matter: round 3 placed it at 1 GiB and 2 MiB alignments with 64 MiB / 4 KiB / 256 B
+    // offsets, all within 0.25 % -- profiles/r03_aa_control.txt; the switches for that experiment are gone.)
+    int code = deviceAlloc(ctx, &ctx->streams, streamPieces * 16);
     if (ctx->switches.verbose) {
         std::fprintf(stderr, "memb_hip: stream array at %p, %zu bytes\n", static_cast<void*>(ctx->streams), streamPieces * 16);
     }

@@ -55,7 +55,7 @@ def _hipcc():
 def build_hip_library(force=False, extra_flags=()):
     sources = [os.path.join(CSRC, name) for name in
                ('memb_hip.hip', 'hip_device_common.h', 'hip_trained_kernels.h', 'hip_rowwise_kernels.h',
-                'hip_host_path.h', 'hip_encoder.h', 'hip_encoder_kernels.h', 'worker_pool.h', 'codec.h', 'wire.h')]
+                'hip_host_path.h', 'hip_encoder.h', 'hip_encoder_kernels.h', 'hip_words.h', 'hip_words_kernels.h', 'worker_pool.h', 'codec.h', 'wire.h')]
     sources.append(os.path.join(INCLUDE, 'memb_hip.h'))
     if force or _newer(HIP_LIBRARY, sources):
         _run([

@@ -16,8 +16,12 @@
  * and the batch driver Reader::batchEmbeddingToBuffer (reference src/reader.cpp:59-86).
  *
  * The caller (memb::Reader in memb_amd/csrc/reader.cpp, or any other host
- * language through its FFI -- see INTEGRATION.md) resolves word -> row on the
- * host and hands over row ids; row id MEMB_HIP_MISSING_ROW produces a zero row.
+ * language through its FFI -- see INTEGRATION.md) hands over row ids; row id
+ * MEMB_HIP_MISSING_ROW produces a zero row. Word -> row (the search in front of
+ * every extract: reference src/trained_compression.cpp:115-125, flatbuffers LookupByKey at
+ * src/uniform_compression.cpp:56 and src/full_compression.cpp:39) is either the caller's
+ * business on the host, or this library's on the device: memb_hip_ctx_stage_words +
+ * memb_hip_words_* + memb_hip_resolve_rows_device below (round 5).
  *
  * Every function returns 0 on success and a non-zero code on failure;
  * memb_hip_last_error() returns the message for the calling thread.
@@ -108,9 +112,13 @@ typedef struct memb_hip_full_desc {
  * memb_hip_ctx_set_option and the builder entry points were added). 4 = round 4 (memb_hip_ctx_info: the
  * three large_batch_* fields of the per-context kernel timing are gone with it, tiles_per_wavefront
  * takes their place; options nt_loads, blocks_per_cu, autotune, pipeline, grid_policy no longer exist;
- * memb_hip_encoder_rows was added).
+ * memb_hip_encoder_rows was added). 5 = round 5: word -> row on the device (memb_hip_ctx_stage_words, memb_hip_words_*,
+ * memb_hip_resolve_rows_device, memb_hip_resolve_packed_device), several batches in one launch
+ * (memb_hip_decode_batches_device); memb_hip_ctx_info is back on its ABI-3 offsets -- two reserved dwords follow
+ * tiles_per_wavefront, where ABI 3 had the rest of its large_batch_* fields -- and grew at the END only (word_index_*);
+ * memb_hip_ctx_get_info refuses the struct_size of the ABI-4 declaration, whose union_kernel sat 8 bytes lower.
  */
-#define MEMB_HIP_ABI_VERSION 4
+#define MEMB_HIP_ABI_VERSION 5
 int memb_hip_abi_version(void);
 
 /*
@@ -144,8 +152,13 @@ typedef struct memb_hip_ctx_info {
                                     by batch size); 0 = a large batch */
     uint32_t tiles_per_wavefront;   /* trained, decode_trained: tiles a wavefront decodes one after the other behind one copy
                                        of table and codebook into LDS (1, or 2 for tables of 16 KiB and more) */
+    uint32_t reserved_abi3[2];   /* zero (ABI 3 had two more dwords here; keeps union_kernel where ABI 3 clients read it) */
     char union_kernel[96];       /* the kernel the last memb_hip_decode_rows_union_device call with this context as its FIRST
                                     model launched ("" = none yet, or the call returned MEMB_HIP_UNSUPPORTED) */
+    /* ---- appended in ABI 5 ---- */
+    uint64_t word_index_bytes;   /* HBM held by the word -> row index (keys + hash table); 0 = not staged (part of device_bytes) */
+    uint32_t word_index_slots;   /* slots of the hash table (a power of two >= 2 x n_rows) */
+    uint32_t word_index_keys;    /* keys in the table (n_rows minus repeated keys, which resolve to their first row) */
 } memb_hip_ctx_info;
 
 int memb_hip_device_count(int* count);
@@ -238,6 +251,99 @@ int memb_hip_decode_rows_device_ex(
 int memb_hip_decode_rows_union_device(
     memb_hip_ctx* const* ctxs, const uint32_t* const* rows, const size_t* col_offs, size_t count, size_t n,
     float* out, size_t ld, void* stream, uint32_t flags);
+
+/*
+ * Several batches of one context in ONE launch (a serving loop's way to amortise launch gap, prologue and tail of
+ * batches too small to fill the device: reference src/reader.cpp:59-86 is a per-call driver): batch k looks up
+ * batches[k].n rows batches[k].rows into batches[k].out with its own ld / col_off; results are those of `count`
+ * memb_hip_decode_rows_device calls. Device pointers, enqueued on `stream`, returns without waiting. Trained
+ * storages run the tiles of all batches numbered through in one decode_trained grid (up to MEMB_HIP_MAX_BATCHES per
+ * launch, more are split); uniform and full storages launch once per batch.
+ */
+#define MEMB_HIP_MAX_BATCHES 16
+typedef struct memb_hip_batch {
+    const uint32_t* rows;   /* device */
+    size_t n;
+    float* out;             /* device */
+    size_t ld;
+    size_t col_off;
+} memb_hip_batch;
+int memb_hip_decode_batches_device(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_t count, void* stream);
+
+/*
+ * Word -> row on the device (replaces, for whole batches, the search in front of every extract:
+ *     TrainedCompressedStorage::extract   lower_bound + strcmp    reference src/trained_compression.cpp:115-125
+ *     Uniform / Full ...::extract         LookupByKey             reference src/uniform_compression.cpp:56, src/full_compression.cpp:39
+ * and the list -> vector<string> copy of the binding, reference python/memb_bindings.cpp:54-63).
+ *
+ * memb_hip_ctx_stage_words copies the model's keys to HBM once and builds an open-addressing hash table over them
+ * on the device: 16-byte slots {hash tag, row, key offset, key length}, FNV-1a 64 over the key's bytes, linear
+ * probing, at most half full. n_words keys, NUL terminated, key r (= row r, sorted order) at
+ * packed_words + word_offsets[r]; packed_words[packed_bytes - 1] must be NUL (the trained storage's own
+ * packed_words / word_offsets arrays qualify as they are: trained_compression.fbs:7,9). n_words must equal the
+ * context's row count. A key equal to its predecessor is left out, so a repeated key resolves to its FIRST row, as
+ * lower_bound does. Idempotent: a second call returns MEMB_HIP_OK and changes nothing.
+ *
+ * A lookup hashes the query, probes, and CONFIRMS a tag match by comparing length and bytes with the key: the
+ * answer is the one the reference's binary search gives for every file whose keys are sorted (what its writers
+ * produce: src/trained_compression.cpp:73-79, CreateVectorOfSortedTables), misses included -- also the word that
+ * sorts after every key, where the reference dereferences end() (src/trained_compression.cpp:125).
+ */
+int memb_hip_ctx_stage_words(
+    memb_hip_ctx* ctx, const char* packed_words, uint64_t packed_bytes, const uint32_t* word_offsets, uint64_t n_words);
+
+/*
+ * A batch of query words for one device, in pinned host memory that the lookup kernel reads over PCIe as it goes (the
+ * copy to the device and the lookup are one kernel: nothing is staged in HBM, the row ids come out there). One object
+ * may serve several contexts of that device (a ReadersUnion resolves one batch against every reader).
+ *
+ * Layout (memb_hip_words_plan): the batch is cut into JOBS of job_words words (a power of two, a multiple of 64; the
+ * last job may be shorter). Job j owns the bytes [j * job_bytes, (j + 1) * job_bytes) of `bytes` and the entries
+ * [j * (job_words + 1), ...) of `offsets`: its words back to back from the start of its region, and per word the
+ * position of its first byte RELATIVE TO `bytes`, followed by one more entry, the end of its last word. Jobs are
+ * independent, so any number of caller threads can fill them side by side, each word's bytes touched once.
+ *
+ *   begin     sizes the pinned buffers for n words of about bytes_per_word bytes (0 = default) and fills in the plan;
+ *             waits first for whatever lookup still reads the previous batch of this object.
+ *   (the caller writes jobs; a job that would overflow job_bytes: begin again with a larger bytes_per_word)
+ *   commit    all jobs are written: memb_hip_words_count() == n from here on.
+ *   pack      begin + fill + commit for C strings: words[i] is exactly lengths[i] bytes long (no terminator needed; a
+ *             NUL among them is a byte like any other and matches no key), or NUL terminated when lengths is NULL.
+ *             (The reference compares with strcmp, so for IT a std::string ends at its first NUL: memb::WordBatch and
+ *             the Python binding cut words there.) Pooled host threads of the object do the filling; the host strings
+ *             are free again when the call returns.
+ *   resolve   rows_dev[i] = row of word i, or MEMB_HIP_MISSING_ROW, for all words of a committed batch
+ *             (memb_hip_resolve_rows_device) or for words [first_word, first_word + n_words) of a batch whose jobs
+ *             covering them are written, committed or not (memb_hip_resolve_range_device; first_word a multiple of
+ *             job_words: lookups of finished jobs overlap the filling of later ones). Enqueued on `stream`, returns
+ *             without waiting. The rows never visit the host: hand rows_dev to memb_hip_decode_rows_device.
+ * The pinned buffers must stay untouched until the lookups that read them have run (begin waits for them; destroy too).
+ * Not thread-safe: one batch in the making per object.
+ */
+typedef struct memb_hip_words memb_hip_words;
+typedef struct memb_hip_words_plan {
+    uint8_t* bytes;       /* pinned host memory, jobs * job_bytes bytes */
+    uint32_t* offsets;    /* pinned host memory, jobs * (job_words + 1) entries */
+    size_t n;             /* words of the batch */
+    size_t job_words;
+    size_t jobs;          /* ceil(n / job_words), at least 1 */
+    size_t job_bytes;     /* capacity of one job's region (a multiple of 16) */
+} memb_hip_words_plan;
+int memb_hip_words_create(memb_hip_words** words, int device);
+void memb_hip_words_destroy(memb_hip_words* words);
+int memb_hip_words_begin(memb_hip_words* batch, size_t n, size_t bytes_per_word, memb_hip_words_plan* plan);
+int memb_hip_words_commit(memb_hip_words* batch);
+int memb_hip_words_pack(memb_hip_words* batch, const char* const* words, const uint32_t* lengths, size_t n);
+int memb_hip_words_count(const memb_hip_words* batch, size_t* n);
+int memb_hip_resolve_rows_device(memb_hip_ctx* ctx, const memb_hip_words* batch, uint32_t* rows_dev, void* stream);
+int memb_hip_resolve_range_device(
+    memb_hip_ctx* ctx, const memb_hip_words* batch, size_t first_word, size_t n_words, uint32_t* rows_dev, void* stream);
+/*
+ * The same lookup for callers whose words are on the device already: word i = bytes_dev[offsets_dev[i] ..
+ * offsets_dev[i + 1]) (n + 1 offsets, ascending; no NUL inside a word).
+ */
+int memb_hip_resolve_packed_device(
+    memb_hip_ctx* ctx, const uint8_t* bytes_dev, const uint32_t* offsets_dev, size_t n, uint32_t* rows_dev, void* stream);
 
 /* Wait for the context's own stream (used by memb_hip_decode_rows). */
 int memb_hip_sync(memb_hip_ctx* ctx);

@@ -14,6 +14,12 @@
 
 #include <sys/mman.h>
 
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
 namespace py = pybind11;
 
 namespace {
@@ -80,6 +86,186 @@ struct WordPointers {
     const char* const* data() const { return pointers.data(); }
 };
 
+// A list of str into a word batch on the device (memb::WordBatch, include/memb_hip.h: memb_hip_words_plan) -- the part
+// of a device word search that is host work, and at 2.2 M words the longest part of a lookup, so every word is touched
+// ONCE: pooled threads read the str objects and write their UTF-8 bytes (up to the first NUL, where the reference's
+// strcmp stops) straight into the batch's pinned job regions, which the lookup kernel reads over PCIe. The calling
+// thread holds the GIL throughout, so no Python code runs meanwhile; the pool reads the objects' memory only: a compact
+// ASCII str (nearly every token) has its bytes behind its header, a str with a cached UTF-8 form has pointer and length
+// in its header. A job that meets anything else (non-ASCII without the cache, not a str at all) is redone after the
+// calling thread has gone over its words through the API, which may allocate and raise. The walk is a cache miss per
+// word and little else: every thread prefetches the objects a few words ahead.
+// onChunk(firstWord, words) is called on the calling thread for consecutive runs of finished jobs, in order, while
+// later jobs are still being filled: the lookups of a run overlap the filling of the next.
+struct WordFiller {
+    static size_t poolThreads()
+    {
+        const char* text = std::getenv("MEMB_PACK_THREADS");
+        const unsigned wanted = text && *text ? static_cast<unsigned>(std::strtoul(text, nullptr, 10)) : 32u;
+        return std::max(2u, std::min(std::min(wanted, 128u), std::thread::hardware_concurrency()));
+    }
+
+    static memb::WorkerPool& pool()
+    {
+        static memb::WorkerPool workers(poolThreads() - 1);
+        return workers;
+    }
+
+    enum JobState : int { FILLED = 0, NEEDS_API = 1, TOO_LONG = 2 };
+
+    // One job of the plan; returns its state (and, for OVERFLOW, the bytes it needs in *needed).
+    static JobState fillJob(const memb_hip_words_plan& plan, PyObject** items, size_t job, uint64_t* needed)
+    {
+        constexpr size_t AHEAD = 12;
+        const size_t first = job * plan.job_words, last = std::min(plan.n, first + plan.job_words);
+        uint32_t* offsets = plan.offsets + job * (plan.job_words + 1);
+        const uint64_t base = uint64_t(job) * plan.job_bytes;
+        uint64_t at = 0;
+        bool fits = true;
+        for (size_t i = first; i < last; ++i) {
+            if (i + AHEAD < last) {
+                __builtin_prefetch(items[i + AHEAD]);
+                __builtin_prefetch(reinterpret_cast<const char*>(items[i + AHEAD]) + 64);
+            }
+            PyObject* item = items[i];
+            const char* text = nullptr;
+            Py_ssize_t size = 0;
+            bool ready = PyUnicode_Check(item);
+#if PY_VERSION_HEX < 0x030C0000
+            ready = ready && PyUnicode_IS_READY(item);
+#endif
+            if (ready && PyUnicode_IS_COMPACT_ASCII(item)) {
+                text = reinterpret_cast<const char*>(reinterpret_cast<PyASCIIObject*>(item) + 1);
+                size = PyUnicode_GET_LENGTH(item);
+            } else if (ready && PyUnicode_IS_COMPACT(item) && reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8) {
+                text = reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8;
+                size = reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8_length;
+            }
+            if (!text || size < 0) {
+                return NEEDS_API;
+            }
+            const size_t length = ::strnlen(text, static_cast<size_t>(size));
+            if (fits && at + length <= plan.job_bytes) {
+                offsets[i - first] = static_cast<uint32_t>(base + at);
+                std::memcpy(plan.bytes + base + at, text, length);
+            } else {
+                fits = false;
+            }
+            at += length;
+        }
+        if (!fits) {
+            *needed = at;
+            return TOO_LONG;
+        }
+        offsets[last - first] = static_cast<uint32_t>(base + at);
+        return FILLED;
+    }
+
+    // The words a job could not read without the API: the calling thread (GIL held) makes their UTF-8 form
+    // available, or raises for what is not a str.
+    static void prepareWithApi(PyObject** items, size_t first, size_t last)
+    {
+        for (size_t i = first; i < last; ++i) {
+            if (!PyUnicode_Check(items[i])) {
+                throw py::type_error("words must be str");
+            }
+            Py_ssize_t size = 0;
+            if (!PyUnicode_AsUTF8AndSize(items[i], &size)) {   // (caches the UTF-8 form in the object)
+                throw py::error_already_set();
+            }
+        }
+    }
+
+    template <typename OnChunk>
+    static size_t fill(memb::WordBatch& batch, const py::handle& words, OnChunk onChunk)
+    {
+        py::object fast = py::reinterpret_steal<py::object>(PySequence_Fast(words.ptr(), "expected a list of str"));
+        if (!fast) {
+            throw py::error_already_set();
+        }
+        const size_t count = static_cast<size_t>(PySequence_Fast_GET_SIZE(fast.ptr()));
+        PyObject** items = PySequence_Fast_ITEMS(fast.ptr());
+        static std::mutex poolMutex;
+        size_t bytesPerWord = 0;
+        for (int attempt = 0; attempt < 48; ++attempt) {
+            const memb_hip_words_plan plan = batch.begin(count, bytesPerWord);
+            std::vector<int> state(plan.jobs, FILLED);
+            std::vector<uint64_t> needed(plan.jobs, 0);
+            if (count == 0) {
+                plan.offsets[0] = 0;
+                batch.commit();
+                return 0;
+            }
+            std::unique_lock<std::mutex> lock(poolMutex, std::try_to_lock);
+            const bool pooled = count >= 8192 && lock.owns_lock();
+            bool clean = true;
+            if (!pooled) {
+                for (size_t job = 0; job < plan.jobs; ++job) {
+                    state[job] = fillJob(plan, items, job, &needed[job]);
+                    clean = clean && state[job] == FILLED;
+                }
+                if (clean) {
+                    onChunk(size_t(0), count);
+                }
+            } else {
+                // chunks of consecutive jobs; the pool hands jobs out in order, so chunks complete roughly in order
+                // (at most eight, of at least 65 536 words: a lookup launch is a few microseconds of this thread's time)
+                const size_t chunkJobs = std::max((plan.jobs + 7) / 8, (size_t(65536) + plan.job_words - 1) / plan.job_words);
+                const size_t chunks = (plan.jobs + chunkJobs - 1) / chunkJobs;
+                std::vector<std::atomic<size_t>> done(chunks);
+                for (auto& counter : done) {
+                    counter.store(0, std::memory_order_relaxed);
+                }
+                pool().start(plan.jobs, [&](size_t job) {
+                    state[job] = fillJob(plan, items, job, &needed[job]);
+                    done[job / chunkJobs].fetch_add(1, std::memory_order_release);
+                });
+                std::exception_ptr failure;
+                for (size_t chunk = 0; chunk < chunks; ++chunk) {
+                    const size_t firstJob = chunk * chunkJobs, lastJob = std::min(plan.jobs, firstJob + chunkJobs);
+                    while (done[chunk].load(std::memory_order_acquire) < lastJob - firstJob) {
+                        std::this_thread::yield();
+                    }
+                    for (size_t job = firstJob; job < lastJob; ++job) {
+                        clean = clean && state[job] == FILLED;
+                    }
+                    if (clean && !failure) {
+                        try {
+                            const size_t firstWord = firstJob * plan.job_words;
+                            onChunk(firstWord, std::min(count, lastJob * plan.job_words) - firstWord);
+                        } catch (...) {
+                            failure = std::current_exception();   // (the pool still works on this thread's stack)
+                        }
+                    }
+                }
+                pool().wait();
+                if (failure) {
+                    std::rethrow_exception(failure);
+                }
+            }
+            if (clean) {
+                batch.commit();
+                return count;
+            }
+            // the rare paths: make the words of the jobs that need it readable, size the regions for the longest job
+            uint64_t longest = 0;
+            for (size_t job = 0; job < plan.jobs; ++job) {
+                if (state[job] == NEEDS_API) {
+                    prepareWithApi(items, job * plan.job_words, std::min(count, (job + 1) * plan.job_words));
+                }
+                longest = std::max(longest, needed[job]);
+            }
+            if (longest) {
+                bytesPerWord = std::max<size_t>(
+                    2 * (plan.job_bytes / plan.job_words), (longest + plan.job_words - 1) / plan.job_words * 5 / 4 + 1);
+            } else {
+                bytesPerWord = plan.job_bytes / plan.job_words;
+            }
+        }
+        throw std::runtime_error("internal error: the word batch does not converge");
+    }
+};
+
 py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
 {
     if (reader.device() == memb::CompressedStorage::HOST_DEVICE) {
@@ -117,6 +303,9 @@ py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
     result["register_waves_per_cu"] = info.register_waves_per_cu;
     result["tiles_per_wavefront"] = info.tiles_per_wavefront;
     result["union_kernel"] = std::string(info.union_kernel);
+    result["word_index_bytes"] = info.word_index_bytes;
+    result["word_index_slots"] = info.word_index_slots;
+    result["word_index_keys"] = info.word_index_keys;
     return result;
 }
 
@@ -196,6 +385,19 @@ PYBIND11_MODULE(_memb, m) {
                 builder.save(filename);
             });
 
+    // a batch of query words on a device (memb::WordBatch): see Reader.words_to_rows_device
+    py::class_<memb::WordBatch, std::shared_ptr<memb::WordBatch>>(m, "WordBatch")
+        .def(py::init<int>(), py::arg("device"))
+        .def("size", [](memb::WordBatch& batch) { return batch.size(); })
+        .def("device", [](memb::WordBatch& batch) { return batch.device(); })
+        .def(
+            "pack",
+            [](memb::WordBatch& batch, const py::sequence& wordList) {
+                return WordFiller::fill(batch, wordList, [](size_t, size_t) {});
+            },
+            py::arg("words"),
+            "fills the batch from a list of str (no lookup); returns the number of words");
+
     py::class_<memb::Reader, std::shared_ptr<memb::Reader>>(m, "Reader")
         .def(py::init([](const std::string& filename, size_t numThreads) {
             return makeReader(filename, numThreads, -1, 0);
@@ -268,6 +470,51 @@ PYBIND11_MODULE(_memb, m) {
                 }
                 return rows;
             })
+        .def(
+            "batches_to_device",
+            [](memb::Reader& reader, const std::vector<std::tuple<uintptr_t, size_t, uintptr_t, size_t, size_t>>& batches,
+               uintptr_t stream) {
+                std::vector<memb_hip_batch> list(batches.size());
+                for (size_t k = 0; k < batches.size(); ++k) {
+                    list[k].rows = reinterpret_cast<const uint32_t*>(std::get<0>(batches[k]));
+                    list[k].n = std::get<1>(batches[k]);
+                    list[k].out = reinterpret_cast<float*>(std::get<2>(batches[k]));
+                    list[k].ld = std::get<3>(batches[k]);
+                    list[k].col_off = std::get<4>(batches[k]);
+                }
+                reader.batchesToDeviceBuffers(list.data(), list.size(), reinterpret_cast<void*>(stream));
+            },
+            py::arg("batches"),
+            py::arg("stream") = 0,
+            "several (rows_ptr, n, out_ptr, ld, col_off) lookups in one launch (memb_hip_decode_batches_device)")
+        .def("stage_words", [](memb::Reader& reader) {
+            py::gil_scoped_release release;
+            reader.stageWords();
+        })
+        .def(
+            "resolve_batch_to_device",
+            [](memb::Reader& reader, memb::WordBatch& batch, uintptr_t rows, uintptr_t stream) {
+                reader.resolveRowsToDevice(batch, reinterpret_cast<uint32_t*>(rows), reinterpret_cast<void*>(stream));
+            },
+            py::arg("batch"),
+            py::arg("rows_ptr"),
+            py::arg("stream") = 0,
+            "row ids of an already packed batch into device memory (batch.size() uint32 entries)")
+        .def(
+            "words_to_rows_device",
+            [](memb::Reader& reader, memb::WordBatch& batch, const py::sequence& wordList, uintptr_t rows, uintptr_t stream) {
+                // fill + lookup under one hold of the GIL (the batch object is not shared between two calls in flight);
+                // the lookups of finished runs of jobs are enqueued while the pool fills the next
+                reader.stageWords();
+                return WordFiller::fill(batch, wordList, [&](size_t firstWord, size_t words) {
+                    reader.resolveRangeToDevice(batch, firstWord, words, reinterpret_cast<uint32_t*>(rows), reinterpret_cast<void*>(stream));
+                });
+            },
+            py::arg("batch"),
+            py::arg("words"),
+            py::arg("rows_ptr"),
+            py::arg("stream") = 0,
+            "words -> row ids in device memory (len(words) uint32 entries at rows_ptr), enqueued on `stream`")
         .def(
             "batch_embedding_into",
             [](memb::Reader& reader,
@@ -429,6 +676,40 @@ PYBIND11_MODULE(_memb, m) {
         py::arg("ld"),
         py::arg("stream") = 0,
         py::arg("average") = false);
+    // one batch of words resolved by several readers of one device (ReadersUnion): packed and copied once
+    m.def(
+        "union_words_to_rows_device",
+        [](memb::WordBatch& batch,
+           const py::sequence& wordList,
+           const std::vector<std::shared_ptr<memb::Reader>>& readers,
+           const std::vector<uintptr_t>& rows,
+           uintptr_t stream)
+        {
+            if (readers.size() != rows.size()) {
+                throw std::runtime_error("One row-id array per reader is needed");
+            }
+            for (const auto& reader : readers) {
+                reader->stageWords();
+            }
+            return WordFiller::fill(batch, wordList, [&](size_t firstWord, size_t words) {
+                for (size_t i = 0; i < readers.size(); ++i) {
+                    readers[i]->resolveRangeToDevice(
+                        batch, firstWord, words, reinterpret_cast<uint32_t*>(rows[i]), reinterpret_cast<void*>(stream));
+                }
+            });
+        },
+        py::arg("batch"),
+        py::arg("words"),
+        py::arg("readers"),
+        py::arg("rows_ptrs"),
+        py::arg("stream") = 0);
+    // measurement hook (bench.py's word_search block, tools/perf): seconds the calling thread and the pool spend
+    // writing a list of str into a word batch's pinned memory -- the host work of a device word search
+    m.def("_word_fill_seconds", [](memb::WordBatch& batch, const py::sequence& wordList) {
+        const auto start = std::chrono::steady_clock::now();
+        WordFiller::fill(batch, wordList, [](size_t, size_t) {});
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    });
     m.attr("HOST_DEVICE") = static_cast<int>(memb::CompressedStorage::HOST_DEVICE);
     m.def("_writer_mimics_official_layout", [](bool enabled) {
         memb::wire::BufferBuilder::omitDefaults() = enabled;

@@ -61,6 +61,7 @@ void CompressedStorage::setDevice(int device)
     if (context_ && device != device_) {
         memb_hip_ctx_destroy(context_);
         context_ = nullptr;
+        wordsStaged_.store(false, std::memory_order_release);   // (the keys went with the context)
     }
     device_ = device;
 }
@@ -136,6 +137,70 @@ void CompressedStorage::decodeRowsDevice(
 }
 
 // ---------------------------------------------------------------------------
+// Word -> row on the device
+// ---------------------------------------------------------------------------
+
+void CompressedStorage::packedKeys(PackedKeys* keys) const
+{
+    const size_t count = rowCount();
+    keys->ownedOffsets.resize(count);
+    size_t total = 0;
+    for (size_t row = 0; row < count; ++row) {
+        total += std::strlen(key(row)) + 1;
+    }
+    if (total >= 0xFFFFFFF0ull) {
+        throw std::runtime_error("the keys of this model take 4 GiB and more: word search on the device is not available");
+    }
+    keys->ownedBytes.reserve(total + 1);
+    for (size_t row = 0; row < count; ++row) {
+        keys->ownedOffsets[row] = static_cast<uint32_t>(keys->ownedBytes.size());
+        const char* word = key(row);
+        keys->ownedBytes.append(word, std::strlen(word) + 1);
+    }
+    if (keys->ownedBytes.empty()) {
+        keys->ownedBytes.push_back('\0');
+    }
+    keys->bytes = keys->ownedBytes.data();
+    keys->size = keys->ownedBytes.size();
+    keys->offsets = keys->ownedOffsets.data();
+}
+
+void CompressedStorage::stageWords() const
+{
+    if (wordsStaged_.load(std::memory_order_acquire)) {
+        return;
+    }
+    memb_hip_ctx* context = deviceContext();
+    std::lock_guard<std::mutex> lock(stageWordsMutex_);
+    if (wordsStaged_.load(std::memory_order_acquire)) {
+        return;
+    }
+    PackedKeys keys;
+    packedKeys(&keys);
+    if (memb_hip_ctx_stage_words(context, keys.bytes, keys.size, keys.offsets, rowCount()) != MEMB_HIP_OK) {
+        throwDeviceError("Cannot stage the keys on the HIP device");
+    }
+    wordsStaged_.store(true, std::memory_order_release);
+}
+
+void CompressedStorage::resolveRowsDevice(const memb_hip_words* batch, uint32_t* rowsDevice, void* stream) const
+{
+    stageWords();
+    if (memb_hip_resolve_rows_device(deviceContext(), batch, rowsDevice, stream) != MEMB_HIP_OK) {
+        throwDeviceError("HIP word search failed");
+    }
+}
+
+void CompressedStorage::resolveRangeDevice(
+    const memb_hip_words* batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const
+{
+    stageWords();
+    if (memb_hip_resolve_range_device(deviceContext(), batch, firstWord, count, rowsDevice, stream) != MEMB_HIP_OK) {
+        throwDeviceError("HIP word search failed");
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Hash index over the keys: open addressing, 64-bit slots {hash tag : 32, row : 32},
 // FNV-1a over the word's bytes; a hit is confirmed with strcmp, so the answer is
 // always the one the binary search would give.
@@ -171,6 +236,11 @@ struct CompressedStorage::WordIndex {
         const size_t perThread = (count + threads - 1) / threads;
         auto insertRange = [this, &storage, count](size_t first, size_t last) {
             for (size_t row = first; row < std::min(last, count); ++row) {
+                // keys are sorted: a repeated key is its predecessor's neighbour and stays out, so that the index
+                // answers with the FIRST of equal keys, as the binary search does
+                if (row > 0 && std::strcmp(storage.key(row), storage.key(row - 1)) == 0) {
+                    continue;
+                }
                 const uint64_t h = hash(storage.key(row));
                 const uint64_t value = (h & 0xFFFFFFFF00000000ull) | row;
                 for (uint64_t at = h & mask;; at = (at + 1) & mask) {
@@ -338,6 +408,14 @@ public:
     }
 
 protected:
+    // the file's packed_words (the string's own terminator included) and word_offsets, as they are
+    void packedKeys(PackedKeys* keys) const override
+    {
+        keys->bytes = packedWords_.data;
+        keys->size = packedWords_.size + 1;
+        keys->offsets = wordOffsets_.data;
+    }
+
     // Host decode of one row: the canonical-Huffman walk of the reference's extract
     // (src/trained_compression.cpp:126-135: dim x next() -> centroid) over this project's two-level
     // table (codec.h; results do not depend on the table width, like the reference's L). A 64-bit

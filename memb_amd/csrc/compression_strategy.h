@@ -75,12 +75,29 @@ public:
     // The device context, created (payload staged to HBM) on first use.
     memb_hip_ctx* deviceContext() const;
 
+    // Word -> row on the device (include/memb_hip.h: memb_hip_ctx_stage_words, memb_hip_resolve_rows_device): the keys
+    // and a hash table over them go to HBM with the first call (thread safe), a batch of packed query words is then
+    // resolved by one kernel and the row ids stay on the device. Same answers as `resolve`.
+    void stageWords() const;
+    void resolveRowsDevice(const memb_hip_words* batch, uint32_t* rowsDevice, void* stream) const;
+    void resolveRangeDevice(const memb_hip_words* batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const;
+
 protected:
     virtual memb_hip_ctx* createDeviceContext(int device) const = 0;
     // One row decoded on the host into destination[0 .. dim): what the reference's extract does
     // after its word search (src/trained_compression.cpp:126-135, src/uniform_compression.cpp:58-72,
     // src/full_compression.cpp:40-43).
     virtual void extractRowHost(uint32_t row, float* destination) const = 0;
+    // The keys as the device wants them: NUL terminated, key r at bytes + offsets[r], bytes[size - 1] == 0. The default
+    // collects them from key(); a trained storage hands out the file's own arrays (packed_words / word_offsets).
+    struct PackedKeys {
+        const char* bytes = nullptr;
+        uint64_t size = 0;
+        const uint32_t* offsets = nullptr;
+        std::string ownedBytes;
+        std::vector<uint32_t> ownedOffsets;
+    };
+    virtual void packedKeys(PackedKeys* keys) const;
 
 private:
     void decodeRowsHost(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
@@ -97,6 +114,8 @@ private:
     mutable std::once_flag wordIndexOnce_;
     mutable std::shared_ptr<WordIndex> wordIndex_;
     mutable std::atomic<bool> wordIndexBuilt_{false};
+    mutable std::mutex stageWordsMutex_;
+    mutable std::atomic<bool> wordsStaged_{false};
 };
 
 class Compressor {

@@ -567,23 +567,58 @@ __device__ __forceinline__ WaveLds setUpLds(const TrainedParams& p, uint32_t* ld
     return waveLds(p, lds);
 }
 
+// Several batches in one launch (memb_hip_decode_batches_device): the tiles of all batches are numbered through, batch k
+// owning the virtual tiles [firstTile[k], firstTile[k + 1]); a wavefront finds its tile's batch by comparing against the
+// (wave-uniform, scalar) boundaries and decodes it with that batch's row ids, output, size, ld and col_off. Everything
+// else -- the model, the launch geometry, the block's one copy of table and codebook -- is shared: one prologue and one
+// tail for all of them.
+constexpr uint32_t MAX_BATCHES = MEMB_HIP_MAX_BATCHES;
+
+struct BatchList {
+    uint32_t count;
+    unsigned long long firstTile[MAX_BATCHES + 1];
+    const uint32_t* rows[MAX_BATCHES];
+    float* out[MAX_BATCHES];
+    unsigned long long n[MAX_BATCHES];
+    unsigned long long ld[MAX_BATCHES];
+    unsigned long long colOff[MAX_BATCHES];
+};
+
+// `p` with the fields of the batch that owns virtual tile *tile (a wave-uniform number); *tile becomes the tile's number
+// inside that batch.
+__device__ __forceinline__ TrainedParams batchOfTile(const TrainedParams& p, const BatchList& list, unsigned long long* tile)
+{
+    uint32_t batch = 0;
+    for (uint32_t k = 1; k < list.count; ++k) {
+        batch += *tile >= list.firstTile[k] ? 1u : 0u;
+    }
+    TrainedParams q = p;
+    q.rows = list.rows[batch];
+    q.out = list.out[batch];
+    q.n = list.n[batch];
+    q.ld = list.ld[batch];
+    q.colOff = list.colOff[batch];
+    *tile -= list.firstTile[batch];
+    return q;
+}
+
 // One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
 // keeps the memory system busy. Also builds the segment index (OUT_INDEX).
 // A wavefront decodes p.tilesPerWave tiles one after the other -- tiles wave, wave + W, ... of its block's run of
 // W * tilesPerWave tiles (W = wavefronts per block), so at every step the block's wavefronts write W adjacent tiles --
 // and the block copies table and codebook into LDS once for all of them; the row ids of the next tile are loaded while
 // this one is decoded.
-template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained(TrainedParams p)
+// BATCHES: the tiles are virtual tiles of a BatchList (decode_trained_batches); otherwise `list` is not looked at.
+template <bool HAS_SUB, int MODE, bool FAST, bool BATCHES>
+__device__ __forceinline__ void decodeTilesOfBlock(const TrainedParams& p, const BatchList& list, uint32_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr bool PACKED = !FAST && MODE != OUT_INDEX;   // byte keys; the index pass keeps the 8-byte table
     uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
     // (Round 4, batch 4: giving every XCD one contiguous run of the batch instead of every eighth block: +3.2 % on the
     // key-order dump, +-0 shuffled -- blocks stay dealt out as the dispatcher deals them.)
-    unsigned long long tile =
-        static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + threadIdx.x / WAVE;
+    const uint32_t wave = BATCHES ? __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE) : threadIdx.x / WAVE;
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * p.tilesPerWave) + wave;
     const uint32_t rounds = (p.wordsPerWave * p.loadPieces + WAVE - 1) / WAVE;
     // The copy of table and codebook stays IN FRONT of the tile's loads. Round 4, batch 10 issued the row ids first, the
     // copy's pieces behind them into a register, the row regions behind those, and wrote the pieces to LDS (with the
@@ -594,50 +629,80 @@ __global__ void decode_trained(TrainedParams p)
     // a block that starts its dependent loads a microsecond later is the better citizen there (round 3 had seen the same
     // sign with a cruder ordering).
     const WaveLds mem = setUpLds<MODE>(p, lds);
-    if (tile * p.wordsPerWave >= p.n) {
+    const unsigned long long tiles = BATCHES ? list.firstTile[list.count] : (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
+    if (tile >= tiles) {
         return;
     }
-    uint32_t tileRow = loadTileRow(p, tile, laneRole(p, lane));
+    // (the tile of a wavefront: `q` = the parameters it is decoded with, `local` = its number inside its batch)
+    unsigned long long local = tile;
+    TrainedParams q = BATCHES ? batchOfTile(p, list, &local) : p;
+    uint32_t tileRow = loadTileRow(q, local, laneRole(q, lane));
 #pragma nounroll
     for (uint32_t step = 0; step < p.tilesPerWave; ++step, tile += wavesPerBlock) {
-        const unsigned long long tileBase = tile * p.wordsPerWave;
-        if (tileBase >= p.n) {
+        if (tile >= tiles) {
             break;
         }
+        if (BATCHES && step) {
+            local = tile;
+            q = batchOfTile(p, list, &local);
+        } else if (!BATCHES) {
+            local = tile;
+        }
+        const unsigned long long tileBase = local * q.wordsPerWave;
         // Everything a lane derives from its number -- word, segment, the pieces it copies and stores -- is worked out
         // afresh per tile, as a wavefront with one tile did: hoisted out of the loop those values cost 50 vector
         // registers and half the resident wavefronts (103 against 52: tools/perf/isa.py).
         asm volatile("" : "+v"(lane));
-        const LaneRole role = laneRole(p, lane);
-        WordMeta meta = loadWordMeta(p, tileRow, role);
-        unpackMeta(p, role, meta);
+        const LaneRole role = laneRole(q, lane);
+        WordMeta meta = loadWordMeta(q, tileRow, role);
+        unpackMeta(q, role, meta);
         StreamRegisters first = {};   // (defined on every path: otherwise the values are carried around the loop)
-        issueStreamLoads(p, meta, lane, 0, first);
-        if (step + 1 < p.tilesPerWave) {
-            tileRow = loadTileRow(p, tile + wavesPerBlock, role);   // (MISSING past the batch end)
+        issueStreamLoads(q, meta, lane, 0, first);
+        if (step + 1 < p.tilesPerWave && tile + wavesPerBlock < tiles) {
+            if (BATCHES) {
+                unsigned long long nextLocal = tile + wavesPerBlock;
+                const TrainedParams next = batchOfTile(p, list, &nextLocal);
+                tileRow = loadTileRow(next, nextLocal, role);
+            } else {
+                tileRow = loadTileRow(q, tile + wavesPerBlock, role);
+            }
         }
         const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-        writeStreams(p, mem.slots, lane, 0, first);
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(q.wordsPerWave), q.n - tileBase));
+        writeStreams(q, mem.slots, lane, 0, first);
         for (uint32_t round = STREAM_REGISTERS; round < rounds; round += STREAM_REGISTERS) {
             StreamRegisters v = {};
-            issueStreamLoads(p, meta, lane, round, v);
-            writeStreams(p, mem.slots, lane, round, v);
+            issueStreamLoads(q, meta, lane, round, v);
+            writeStreams(q, mem.slots, lane, round, v);
         }
         waveLdsFence();
 
-        recordSegmentBits(p, mem.slots, role, meta);
-        if (MODE == OUT_INDEX || !(measureFlags(p) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
-            decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, mem.slots, mem.keyTile, role, meta);
+        recordSegmentBits(q, mem.slots, role, meta);
+        if (MODE == OUT_INDEX || !(measureFlags(q) & 1)) {   // (measurement builds: 1 = no decode, 2 = no output, 4 = no loads)
+            decodeSegment<HAS_SUB, MODE, FAST, PACKED>(q, mem.table, mem.slots, mem.keyTile, role, meta);
         }
         if (MODE != OUT_INDEX) {
             waveLdsFence();
-            if (!(measureFlags(p) & 2)) {
-                outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < p.nRows);
+            if (!(measureFlags(q) & 2)) {
+                outputTile<MODE, FAST>(q, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, meta.row < q.nRows);
             }
         }
         waveLdsFence();   // (the next tile's streams and symbols go where this one's were)
     }
+}
+
+template <bool HAS_SUB, int MODE, bool FAST>
+__global__ void decode_trained(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    decodeTilesOfBlock<HAS_SUB, MODE, FAST, false>(p, BatchList(), lds);
+}
+
+template <bool HAS_SUB, int MODE, bool FAST>
+__global__ void decode_trained_batches(TrainedParams p, BatchList list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    decodeTilesOfBlock<HAS_SUB, MODE, FAST, true>(p, list, lds);
 }
 
 // ---------------------------------------------------------------------------

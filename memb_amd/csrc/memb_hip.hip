@@ -81,6 +81,7 @@ int fail(int code, const std::string& message)
 #include "hip_trained_kernels.h"
 #include "hip_rowwise_kernels.h"
 #include "hip_encoder_kernels.h"
+#include "hip_words_kernels.h"
 
 // ceil(2^32 / d) for fastDivide: exact for every q <= maxQ when maxQ * d < 2^32.
 // Returns 0 (plain division) for d == 1, where the magic does not fit 32 bits,
@@ -172,6 +173,13 @@ struct memb_hip_ctx {
     uint32_t regionPieces = 0;
     float levels = 0.f;
     float* fullValues = nullptr;
+
+    // word -> row on the device (memb_hip_ctx_stage_words; hip_words.h): the keys and a hash table over them
+    uint8_t* wordKeyBytes = nullptr;
+    void* wordSlots = nullptr;           // WordSlot [wordSlotMask + 1]; non-null = staged
+    uint32_t wordSlotMask = 0;
+    uint32_t wordIndexKeys = 0;
+    uint64_t wordIndexBytes = 0;
 
     // staging for the host-buffer entry point
     uint32_t* stagedRows = nullptr;
@@ -316,6 +324,40 @@ hipError_t launchTrainedVariant(const TrainedParams& params, uint32_t blocks, ui
     hipLaunchKernelGGL(
         (decode_trained<HAS_SUB, MODE, FAST>), dim3(blocks), dim3(threads), ldsBytes, stream, params);
     return hipGetLastError();
+}
+
+template <bool HAS_SUB, int MODE, bool FAST>
+hipError_t launchBatchesVariant(
+    const TrainedParams& params, const BatchList& list, uint32_t blocks, uint32_t threads, uint32_t ldsBytes, hipStream_t stream)
+{
+    static thread_local int configuredDevice = -1;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (configuredDevice != device) {
+        hipError_t status = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&decode_trained_batches<HAS_SUB, MODE, FAST>),
+            hipFuncAttributeMaxDynamicSharedMemorySize,
+            160 * 1024);
+        if (status != hipSuccess) {
+            return status;
+        }
+        configuredDevice = device;
+    }
+    hipLaunchKernelGGL(
+        (decode_trained_batches<HAS_SUB, MODE, FAST>), dim3(blocks), dim3(threads), ldsBytes, stream, params, list);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launchBatchesMode(
+    const memb_hip_ctx* ctx, const TrainedParams& params, const BatchList& list, uint32_t blocks, uint32_t threads,
+    uint32_t ldsBytes, hipStream_t stream)
+{
+    if (ctx->fast) {
+        return launchBatchesVariant<false, MODE, true>(params, list, blocks, threads, ldsBytes, stream);
+    }
+    return ctx->byteTable.hasSubTables ? launchBatchesVariant<true, MODE, false>(params, list, blocks, threads, ldsBytes, stream)
+                                       : launchBatchesVariant<false, MODE, false>(params, list, blocks, threads, ldsBytes, stream);
 }
 
 typedef void (*TrainedKernel)(TrainedParams);
@@ -485,6 +527,46 @@ struct Epilogue {
     float divisor = 0.f;
 };
 
+// The parameters of a lookup kernel that do not depend on the batch.
+TrainedParams lookupParams(const memb_hip_ctx* ctx)
+{
+    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    TrainedParams params = baseTrainedParams(ctx);
+    params.lanesPerWord = ctx->lanesPerWord;
+    params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
+    params.wordsPerWave = wordsPerWave;
+    params.segmentSymbols = ctx->segmentSymbols;
+    params.keyRowBytes = keyRowBytes(ctx);
+    params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
+    params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
+    if (!ctx->fast) {
+        // byte keys: the PACKED kernels' table (4-byte entries, tableDwords of them incl. padding)
+        params.table = ctx->table32;
+        params.rootBits = ctx->byteTable.rootBits;
+        params.tableDwords = packedTableDwords(ctx);
+    }
+    return params;
+}
+
+// The kernels index LDS and the symbol tile from these numbers without further checks.
+bool lookupParamsConsistent(const memb_hip_ctx* ctx, const TrainedParams& params, const TrainedGeometry& geometry)
+{
+    const uint32_t wordsPerWave = params.wordsPerWave;
+    const uint32_t group = ctx->fast ? 8 : 4;
+    return wordsPerWave >= 1 && wordsPerWave * params.lanesPerWord <= WAVE &&
+        params.slotDwords >= 4 && params.slotDwords % 4 == 0 && params.segmentSymbols % group == 0 &&
+        params.loadPieces >= 1 && params.loadPieces * 4 <= params.slotDwords &&
+        (!params.recordPieces || (params.lanesPerWord <= ROW_META_MAX_LANES && params.slotDwords >= 4 * params.recordPieces + 3)) &&
+        uint64_t(params.lanesPerWord) * params.segmentSymbols >= params.dim &&
+        uint64_t(params.lanesPerWord - 1) * params.segmentSymbols < params.dim &&
+        params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
+        uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
+        (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
+        geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
+        (ctx->fast || (params.table != nullptr && params.tableDwords >= (1u << params.rootBits))) &&
+        geometry.ldsBytes <= ctx->ldsLimit;
+}
+
 // Tiles a wavefront of the one-tile kernels (decode_trained, decode_union_split) decodes one after the other, behind
 // ONE copy of table(s) and codebook(s) into LDS per block. Measured (round 4, batches 2-4 and 12; `copyBytes` = what a
 // block copies): the copy is 2.8 % of a 4-bit dump (4 KiB) and more than it gains back there (T = 2: -0.9 % / +1.9 % key
@@ -581,7 +663,7 @@ int launchTrained(
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
-    TrainedParams params = baseTrainedParams(ctx);
+    TrainedParams params = lookupParams(ctx);
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -589,38 +671,8 @@ int launchTrained(
     params.colOff = colOff;
     params.accumulate = epilogue.accumulate;
     params.divisor = epilogue.divisor;
-    params.lanesPerWord = ctx->lanesPerWord;
-    params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
-    params.wordsPerWave = wordsPerWave;
-    params.segmentSymbols = ctx->segmentSymbols;
-    params.keyRowBytes = keyRowBytes(ctx);
-    params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
-    params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
-    if (!ctx->fast) {
-        // byte keys: the PACKED kernels' table (4-byte entries, tableDwords of them incl. padding)
-        params.table = ctx->table32;
-        params.rootBits = ctx->byteTable.rootBits;
-        params.tableDwords = packedTableDwords(ctx);
-    }
-
-    // The kernels index LDS and the symbol tile from these numbers without further checks.
-    {
-        const uint32_t group = ctx->fast ? 8 : 4;
-        const bool consistent = wordsPerWave >= 1 && wordsPerWave * params.lanesPerWord <= WAVE &&
-            params.slotDwords >= 4 && params.slotDwords % 4 == 0 && params.segmentSymbols % group == 0 &&
-            params.loadPieces >= 1 && params.loadPieces * 4 <= params.slotDwords &&
-            (!params.recordPieces || (params.lanesPerWord <= ROW_META_MAX_LANES && params.slotDwords >= 4 * params.recordPieces + 3)) &&
-            uint64_t(params.lanesPerWord) * params.segmentSymbols >= params.dim &&
-            uint64_t(params.lanesPerWord - 1) * params.segmentSymbols < params.dim &&
-            params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
-            uint64_t(params.keyTileDwords) * 4 >= uint64_t(wordsPerWave) * params.keyRowBytes &&
-            (params.lanesPerWord == 1 || params.segmentIndex != nullptr) &&
-            geometry.ldsBytes == trainedLdsBytes(ctx, geometry.waves, wordsPerWave, true) &&
-            (ctx->fast || (params.table != nullptr && params.tableDwords >= (1u << params.rootBits))) &&
-            geometry.ldsBytes <= ctx->ldsLimit && ld >= colOff + params.dim;
-        if (!consistent) {
-            return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
-        }
+    if (!lookupParamsConsistent(ctx, params, geometry) || ld < colOff + params.dim) {
+        return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
     }
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t threads = geometry.waves * WAVE;
@@ -649,6 +701,73 @@ int launchTrained(
     }
     if (status != hipSuccess) {
         return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained launch: ") + hipGetErrorString(status));
+    }
+    return MEMB_HIP_OK;
+}
+
+// memb_hip_decode_batches_device for a trained storage: the tiles of up to MAX_BATCHES batches numbered through in one
+// decode_trained_batches grid (the same body as decode_trained: one tile per wavefront at a time), launch geometry by
+// the rule of a single batch with as many words as all of them together.
+int launchTrainedBatches(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_t count, hipStream_t stream)
+{
+    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    BatchList list{};
+    uint64_t tiles = 0;
+    size_t words = 0;
+    int mode = OUT_FLAT;
+    for (size_t k = 0; k < count; ++k) {
+        const memb_hip_batch& batch = batches[k];
+        list.firstTile[list.count] = tiles;
+        list.rows[list.count] = batch.rows;
+        list.out[list.count] = batch.out;
+        list.n[list.count] = batch.n;
+        list.ld[list.count] = batch.ld;
+        list.colOff[list.count] = batch.col_off;
+        ++list.count;
+        tiles += (batch.n + wordsPerWave - 1) / wordsPerWave;
+        words += batch.n;
+        const bool vec = (ctx->dim % 4 == 0) && (batch.ld % 4 == 0) && (batch.col_off % 4 == 0) &&
+            (reinterpret_cast<uintptr_t>(batch.out) % 16 == 0);
+        const int batchMode = !vec ? OUT_SCALAR : (batch.ld == ctx->dim && batch.col_off == 0) ? OUT_FLAT : OUT_VEC4;
+        // one output mode for the launch: the most general one any batch needs (OUT_SCALAR < OUT_VEC4 < OUT_FLAT)
+        mode = std::min(mode, batchMode);
+    }
+    list.firstTile[list.count] = tiles;
+    TrainedPlan plan;
+    const int planned = planTrained(ctx, words, ctx->dim, 0, nullptr, false, &plan, 0);
+    if (planned != MEMB_HIP_OK) {
+        return planned;
+    }
+    TrainedGeometry geometry = plan.geometry;
+    geometry.mode = mode;
+    if (!geometry.waves) {
+        return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
+    }
+    TrainedParams params = lookupParams(ctx);
+    if (!lookupParamsConsistent(ctx, params, geometry)) {
+        return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
+    }
+    params.tilesPerWave = oneTileSteps(ctx, tiles, 4u * (params.tableDwords + params.codebookDwords), false);
+    const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
+    const uint64_t blocks = (tiles + perBlock - 1) / perBlock;
+    if (blocks >= 0x7FFFFFFFull) {
+        return fail(MEMB_HIP_ERR_INVALID, "batches too large for one launch");
+    }
+    const uint32_t threads = geometry.waves * WAVE;
+    hipError_t status;
+    switch (mode) {
+        case OUT_FLAT:
+            status = launchBatchesMode<OUT_FLAT>(ctx, params, list, static_cast<uint32_t>(blocks), threads, geometry.ldsBytes, stream);
+            break;
+        case OUT_VEC4:
+            status = launchBatchesMode<OUT_VEC4>(ctx, params, list, static_cast<uint32_t>(blocks), threads, geometry.ldsBytes, stream);
+            break;
+        default:
+            status = launchBatchesMode<OUT_SCALAR>(ctx, params, list, static_cast<uint32_t>(blocks), threads, geometry.ldsBytes, stream);
+            break;
+    }
+    if (status != hipSuccess) {
+        return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_trained_batches launch: ") + hipGetErrorString(status));
     }
     return MEMB_HIP_OK;
 }
@@ -1816,6 +1935,11 @@ int ctx_get_info_checked(const memb_hip_ctx* ctx, memb_hip_ctx_info* info)
     if (callerSize < sizeof(uint32_t) || callerSize > 4096) {
         return fail(MEMB_HIP_ERR_INVALID, "memb_hip_ctx_info.struct_size must be set to sizeof(memb_hip_ctx_info)");
     }
+    // ABI 4 declared union_kernel 8 bytes lower than ABI 3 and ABI 5 do (two dwords fewer in front of it): a client
+    // built against that header would read the kernel name out of step. Its size gives it away.
+    if (callerSize == offsetof(memb_hip_ctx_info, word_index_bytes) - 8) {
+        return fail(MEMB_HIP_ERR_INVALID, "memb_hip_ctx_info: this is the ABI-4 layout; rebuild against include/memb_hip.h of ABI 5");
+    }
     memb_hip_ctx_info filled;
     uint64_t batchWords = 0;
     if (callerSize >= offsetof(memb_hip_ctx_info, batch_words) + sizeof(uint64_t)) {
@@ -1867,6 +1991,9 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
     info->dim = ctx->dim;
     info->n_rows = ctx->nRows;
     info->device_bytes = ctx->deviceBytes;
+    info->word_index_bytes = ctx->wordIndexBytes;
+    info->word_index_slots = ctx->wordSlots ? ctx->wordSlotMask + 1 : 0;
+    info->word_index_keys = ctx->wordIndexKeys;
     if (ctx->storage == memb::wire::Storage_Trained) {
         const memb::DecodeTable& table = ctx->fast ? ctx->hostTable : ctx->byteTable;   // the lookup kernels' table
         info->root_bits = table.rootBits;
@@ -1948,6 +2075,49 @@ int decode_rows_device_ex_checked(
     epilogue.accumulate = (flags & MEMB_HIP_ACCUMULATE) ? 1u : 0u;
     epilogue.divisor = divisor;
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream), epilogue);
+}
+
+int decode_batches_device_checked(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_t count, void* stream)
+{
+    if (!ctx || (count && !batches)) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    std::vector<memb_hip_batch> live;   // (empty batches take no part)
+    for (size_t k = 0; k < count; ++k) {
+        const memb_hip_batch& batch = batches[k];
+        if (batch.n && (!batch.rows || !batch.out)) {
+            return fail(MEMB_HIP_ERR_INVALID, "null argument");
+        }
+        if (batch.ld < batch.col_off + ctx->dim) {
+            return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
+        }
+        if (batch.n > (size_t(1) << 37)) {
+            return fail(MEMB_HIP_ERR_INVALID, "batch too large");
+        }
+        if (batch.n) {
+            live.push_back(batch);
+        }
+    }
+    DeviceScope deviceScope(ctx->device);
+    HIP_TRY(deviceScope.status());
+    if (ctx->storage != memb::wire::Storage_Trained || live.size() == 1) {
+        // uniform / full: their kernels have no shared prologue worth one launch; a single batch: the plain call
+        for (const memb_hip_batch& batch : live) {
+            const int code = launch(ctx, batch.rows, batch.n, batch.out, batch.ld, batch.col_off, static_cast<hipStream_t>(stream));
+            if (code != MEMB_HIP_OK) {
+                return code;
+            }
+        }
+        return MEMB_HIP_OK;
+    }
+    for (size_t first = 0; first < live.size(); first += MAX_BATCHES) {
+        const int code = launchTrainedBatches(
+            ctx, live.data() + first, std::min<size_t>(MAX_BATCHES, live.size() - first), static_cast<hipStream_t>(stream));
+        if (code != MEMB_HIP_OK) {
+            return code;
+        }
+    }
+    return MEMB_HIP_OK;
 }
 
 int decode_rows_checked(
@@ -2142,6 +2312,7 @@ int algorithmic_bytes_checked(const memb_hip_ctx* ctx, const uint32_t* rows, siz
 }  // namespace
 
 #include "hip_encoder.h"
+#include "hip_words.h"
 
 namespace {
 
@@ -2255,6 +2426,11 @@ int memb_hip_decode_rows_device_ex(memb_hip_ctx* ctx, const uint32_t* rows, size
     return guarded([&] { return decode_rows_device_ex_checked(ctx, rows, n, out, ld, col_off, stream, flags, divisor); });
 }
 
+int memb_hip_decode_batches_device(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_t count, void* stream)
+{
+    return guarded([&] { return decode_batches_device_checked(ctx, batches, count, stream); });
+}
+
 int memb_hip_decode_rows(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
 {
     return guarded([&] { return decode_rows_checked(ctx, rows, n, out, ld, col_off); });
@@ -2270,6 +2446,59 @@ int memb_hip_decode_rows_union_device(
 int memb_hip_sync(memb_hip_ctx* ctx)
 {
     return guarded([&] { return sync_checked(ctx); });
+}
+
+int memb_hip_ctx_stage_words(
+    memb_hip_ctx* ctx, const char* packed_words, uint64_t packed_bytes, const uint32_t* word_offsets, uint64_t n_words)
+{
+    return guarded([&] { return stage_words_checked(ctx, packed_words, packed_bytes, word_offsets, n_words); });
+}
+
+int memb_hip_words_create(memb_hip_words** words, int device)
+{
+    return guarded([&] { return words_create_checked(words, device); });
+}
+
+void memb_hip_words_destroy(memb_hip_words* words)
+{
+    destroyWords(words);
+}
+
+int memb_hip_words_begin(memb_hip_words* batch, size_t n, size_t bytes_per_word, memb_hip_words_plan* plan)
+{
+    return guarded([&] { return words_begin_checked(batch, n, bytes_per_word, plan); });
+}
+
+int memb_hip_words_commit(memb_hip_words* batch)
+{
+    return guarded([&] { return words_commit_checked(batch); });
+}
+
+int memb_hip_words_pack(memb_hip_words* batch, const char* const* words, const uint32_t* lengths, size_t n)
+{
+    return guarded([&] { return words_pack_checked(batch, words, lengths, n); });
+}
+
+int memb_hip_resolve_range_device(
+    memb_hip_ctx* ctx, const memb_hip_words* batch, size_t first_word, size_t n_words, uint32_t* rows_dev, void* stream)
+{
+    return guarded([&] { return resolve_range_device_checked(ctx, batch, first_word, n_words, rows_dev, static_cast<hipStream_t>(stream)); });
+}
+
+int memb_hip_words_count(const memb_hip_words* batch, size_t* n)
+{
+    return guarded([&] { return words_count_checked(batch, n); });
+}
+
+int memb_hip_resolve_rows_device(memb_hip_ctx* ctx, const memb_hip_words* batch, uint32_t* rows_dev, void* stream)
+{
+    return guarded([&] { return resolve_rows_device_checked(ctx, batch, rows_dev, static_cast<hipStream_t>(stream)); });
+}
+
+int memb_hip_resolve_packed_device(
+    memb_hip_ctx* ctx, const uint8_t* bytes_dev, const uint32_t* offsets_dev, size_t n, uint32_t* rows_dev, void* stream)
+{
+    return guarded([&] { return resolve_packed_device_checked(ctx, bytes_dev, offsets_dev, n, rows_dev, static_cast<hipStream_t>(stream)); });
 }
 
 int memb_hip_algorithmic_bytes(const memb_hip_ctx* ctx, const uint32_t* rows, size_t n, uint64_t* bytes)

@@ -71,6 +71,61 @@ MappedFile::~MappedFile()
     }
 }
 
+WordBatch::WordBatch(int device):
+    device_(device)
+{
+    if (memb_hip_words_create(&handle_, device) != MEMB_HIP_OK) {
+        throw std::runtime_error(std::string("Cannot create a word batch on the HIP device: ") + memb_hip_last_error());
+    }
+}
+
+WordBatch::~WordBatch()
+{
+    memb_hip_words_destroy(handle_);
+}
+
+void WordBatch::pack(const char* const* words, const uint32_t* lengths, size_t count)
+{
+    if (memb_hip_words_pack(handle_, words, lengths, count) != MEMB_HIP_OK) {
+        throw std::runtime_error(std::string("Packing words for the HIP device failed: ") + memb_hip_last_error());
+    }
+}
+
+void WordBatch::pack(const std::vector<std::string>& words)
+{
+    std::vector<const char*> pointers(words.size());
+    std::vector<uint32_t> lengths(words.size());
+    for (size_t i = 0; i < words.size(); ++i) {
+        pointers[i] = words[i].c_str();
+        // (up to the first NUL: the reference searches words[i].c_str() with strcmp, src/trained_compression.cpp:119)
+        lengths[i] = static_cast<uint32_t>(std::min<size_t>(::strnlen(pointers[i], words[i].size()), 0x7FFFFFFF));
+    }
+    pack(pointers.data(), lengths.data(), words.size());
+}
+
+memb_hip_words_plan WordBatch::begin(size_t count, size_t bytesPerWord)
+{
+    memb_hip_words_plan plan;
+    if (memb_hip_words_begin(handle_, count, bytesPerWord, &plan) != MEMB_HIP_OK) {
+        throw std::runtime_error(std::string("Cannot start a word batch on the HIP device: ") + memb_hip_last_error());
+    }
+    return plan;
+}
+
+void WordBatch::commit()
+{
+    if (memb_hip_words_commit(handle_) != MEMB_HIP_OK) {
+        throw std::runtime_error(std::string("Cannot commit the word batch: ") + memb_hip_last_error());
+    }
+}
+
+size_t WordBatch::size() const
+{
+    size_t count = 0;
+    memb_hip_words_count(handle_, &count);
+    return count;
+}
+
 // reference src/reader.cpp:13-29
 Reader::Reader(
         const std::string& filename,
@@ -154,6 +209,34 @@ bool Reader::hasWordIndex() const
 memb_hip_ctx* Reader::deviceContext() const
 {
     return compressedStorage_->deviceContext();
+}
+
+void Reader::batchesToDeviceBuffers(const memb_hip_batch* batches, size_t count, void* stream) const
+{
+    if (memb_hip_decode_batches_device(compressedStorage_->deviceContext(), batches, count, stream) != MEMB_HIP_OK) {
+        throw std::runtime_error(std::string("HIP batch lookup failed: ") + memb_hip_last_error());
+    }
+}
+
+void Reader::stageWords() const
+{
+    compressedStorage_->stageWords();
+}
+
+void Reader::resolveRowsToDevice(const WordBatch& batch, uint32_t* rowsDevice, void* stream) const
+{
+    if (batch.device() != compressedStorage_->device()) {
+        throw std::runtime_error("the word batch lives on another device than the reader");
+    }
+    compressedStorage_->resolveRowsDevice(batch.handle(), rowsDevice, stream);
+}
+
+void Reader::resolveRangeToDevice(const WordBatch& batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const
+{
+    if (batch.device() != compressedStorage_->device()) {
+        throw std::runtime_error("the word batch lives on another device than the reader");
+    }
+    compressedStorage_->resolveRangeDevice(batch.handle(), firstWord, count, rowsDevice, stream);
 }
 
 // reference src/reader.cpp:41-47 (extract, zeros for a word that is not there): a batch of one.

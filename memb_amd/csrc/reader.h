@@ -30,6 +30,32 @@ private:
     size_t size_ = 0;
 };
 
+// A batch of query words on a device (include/memb_hip.h: memb_hip_words): packed by pooled host threads into pinned
+// memory, copied by the copy engine; one batch can be resolved by several Readers of that device (ReadersUnion).
+class WordBatch {
+public:
+    explicit WordBatch(int device);
+    ~WordBatch();
+    WordBatch(const WordBatch&) = delete;
+    WordBatch& operator=(const WordBatch&) = delete;
+
+    // words[i]: exactly lengths[i] bytes (or NUL terminated when lengths is null). The std::string form cuts every
+    // word at its first NUL, where the reference's strcmp stops. The strings are free again on return.
+    void pack(const char* const* words, const uint32_t* lengths, size_t count);
+    void pack(const std::vector<std::string>& words);
+    // Caller-filled batches (include/memb_hip.h: memb_hip_words_plan): begin hands out the pinned job regions, the
+    // caller's threads write the words into them, commit closes the batch.
+    memb_hip_words_plan begin(size_t count, size_t bytesPerWord = 0);
+    void commit();
+    size_t size() const;
+    int device() const { return device_; }
+    const memb_hip_words* handle() const { return handle_; }
+
+private:
+    int device_;
+    memb_hip_words* handle_ = nullptr;
+};
+
 class Reader {
 public:
     // device: a HIP device index; CompressedStorage::HOST_DEVICE = decode on the host (the reference's
@@ -80,8 +106,21 @@ public:
         const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream,
         bool accumulate = false, float divisor = 0.f) const;
 
+    // Several device-buffer lookups in one kernel launch (include/memb_hip.h: memb_hip_decode_batches_device).
+    void batchesToDeviceBuffers(const memb_hip_batch* batches, size_t count, void* stream) const;
+
     memb_hip_ctx* deviceContext() const;
     bool hasWordIndex() const;   // whether lookups go through the hash index by now
+
+    // Word -> row on the device (reference src/trained_compression.cpp:115-125): the keys and a hash
+    // table over them are staged with the first call (or by stageWords), a batch is resolved by one kernel enqueued
+    // on `stream`, and rowsDevice[i] (device memory, batch.size() entries) = the row resolveRows would give. The row
+    // ids never visit the host: hand them to rowsToDeviceBuffer.
+    void stageWords() const;
+    void resolveRowsToDevice(const WordBatch& batch, uint32_t* rowsDevice, void* stream) const;
+    // ... of words [firstWord, firstWord + count) of a batch whose jobs covering them are written (committed or not):
+    // lookups of finished jobs overlap the filling of later ones. rowsDevice is the whole batch's array.
+    void resolveRangeToDevice(const WordBatch& batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const;
 
 private:
     wire::TableView getIndexChecked() const;

@@ -104,6 +104,7 @@ class Reader(BaseReader):
             self._impl = _memb.Reader(name, num_threads, -1 if device is None else int(device), max_direct_decode_bits)
         if host_below is not None:
             self._impl.set_host_below(int(host_below))
+        self._word_batch = None   # packed query words of resolve_rows_device (pinned + device buffers, kept between calls)
 
     @property
     def dim(self):
@@ -215,11 +216,60 @@ class Reader(BaseReader):
             return keep[1]
         return call
 
-    def batch_embedding_device(self, words):
-        '''batch_embedding with the result left on the GPU as a torch.Tensor (DLPack capable)'''
+    def stage_words(self):
+        '''Copy the model's keys to the GPU and build the hash table over them there (once; resolve_rows_device does it
+        on first use). After this, info()['device_bytes'] includes the word index.'''
+        self._impl.stage_words()
+
+    def resolve_rows_device(self, words, out=None):
+        '''resolve_rows on the GPU: the words are packed into pinned memory by pooled host threads, copied once, and
+        looked up by one kernel in a hash table over the model's keys (the same answers as the host search -- the
+        reference's lower_bound + strcmp, src/trained_compression.cpp:115-125 -- misses as 0xFFFFFFFF). Returns a
+        torch.int32 tensor on this reader's device; nothing waits for the GPU, the row ids never visit the host.
+        out : optional contiguous int32 / uint32 tensor of len(words) entries on this reader's device'''
         import torch
-        rows = torch.from_numpy(self.resolve_rows(words).view('int32')).to('cuda:{}'.format(self.device))
-        return self.rows_embedding_device(rows)
+        index = self._impl.device()
+        n = len(words)
+        if out is None:
+            out = torch.empty((n,), dtype=torch.int32, device='cuda:{}'.format(index))
+        elif (out.device.type != 'cuda' or out.device.index != index or out.dtype not in (torch.int32, torch.uint32)
+              or not out.is_contiguous() or out.numel() != n):
+            raise TypeError('out must be a contiguous int32/uint32 tensor of len(words) entries on cuda:{}'.format(index))
+        if self._word_batch is None:
+            self._word_batch = _memb.WordBatch(index)
+        self._impl.words_to_rows_device(self._word_batch, words, out.data_ptr(), _current_stream(torch, index))
+        return out
+
+    def batch_embedding_device(self, words):
+        '''batch_embedding with the result left on the GPU as a torch.Tensor (DLPack capable). Words are resolved on
+        the GPU as well (resolve_rows_device): the only host work is packing the strings.'''
+        return self.rows_embedding_device(self.resolve_rows_device(words))
+
+    def rows_embedding_device_many(self, batches):
+        '''Several lookups in ONE kernel launch (memb_hip_decode_batches_device): `batches` is a sequence of
+        (rows, out) or (rows, out, col_off) with the tensors rows_embedding_device takes; results are those of one
+        rows_embedding_device call per entry. For serving loops whose batches are too small to fill the GPU: launch gap,
+        prologue and tail are paid once. Returns the list of `out` tensors.'''
+        import torch
+        index = self._impl.device()
+        descriptors = []
+        outs = []
+        for entry in batches:
+            rows, out = entry[0], entry[1]
+            col_off = entry[2] if len(entry) > 2 else 0
+            if rows.device.type != 'cuda' or rows.dtype not in (torch.int32, torch.uint32) or not rows.is_contiguous():
+                raise TypeError('rows must be a contiguous int32/uint32 tensor on the GPU')
+            n = rows.numel()
+            if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n:
+                raise TypeError('out must be a float32 (n, width) tensor with unit column stride')
+            if rows.device.index != index or out.device != rows.device:
+                raise ValueError('rows and out must be on cuda:{} (the device this reader is staged on)'.format(self.device))
+            if out.shape[1] < col_off + self.dim:
+                raise ValueError('out is narrower than col_off + dim')
+            descriptors.append((rows.data_ptr(), n, out.data_ptr(), out.stride(0) if n > 1 else out.shape[1], col_off))
+            outs.append(out)
+        self._impl.batches_to_device(descriptors, _current_stream(torch, index))
+        return outs
 
     def tokenizer_embedding_device(self, tokenizer):
         '''tokenizer_embedding with the weights left on the GPU: a torch.Tensor that

@@ -41,6 +41,7 @@ class ReadersUnion(BaseReader):
         self._readers = list(readers)
         self._mode = mode
         self._widths = widths
+        self._word_batch = None   # packed query words of batch_embedding_device, shared by the readers
 
     @property
     def dim(self):
@@ -80,15 +81,21 @@ class ReadersUnion(BaseReader):
             raise TypeError('device merge needs memb_amd.Reader instances')
         if len({reader.device for reader in readers}) != 1:
             raise ValueError('all readers of a union must be on one device')
+        from . import _memb
         device = 'cuda:{}'.format(readers[0].device)
-        row_ids = [torch.from_numpy(reader.resolve_rows(words).view('int32')).to(device) for reader in readers]
+        stream = torch.cuda.current_stream(torch.device(device)).cuda_stream
+        # the words are packed and copied ONCE and resolved on the GPU by every reader's own hash table
+        # (Reader.resolve_rows_device): the row ids never visit the host
+        row_ids = [torch.empty((len(words),), dtype=torch.int32, device=device) for _ in readers]
+        if self._word_batch is None:
+            self._word_batch = _memb.WordBatch(readers[0].device)
+        _memb.union_words_to_rows_device(
+            self._word_batch, words, [reader._impl for reader in readers], [ids.data_ptr() for ids in row_ids], stream)
         merged = torch.empty((len(words), self.dim), dtype=torch.float32, device=device)
         # one launch that decodes every reader's words of a tile and writes the merged rows once,
         # where the readers can share a kernel
-        from . import _memb
         concatenate = self._mode == CONCATENATE
         columns = [sum(self._widths[:i]) if concatenate else 0 for i in range(len(readers))]
-        stream = torch.cuda.current_stream(merged.device).cuda_stream
         if len(words) and _memb.union_rows_to_device(
                 [reader._impl for reader in readers], [ids.data_ptr() for ids in row_ids], columns,
                 len(words), merged.data_ptr(), merged.stride(0), stream, not concatenate):

@@ -47,6 +47,8 @@ def _load_oracle():
     lib.memb_oracle_key.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.memb_oracle_resolve.restype = ctypes.c_int
     lib.memb_oracle_resolve.argtypes = [ctypes.c_void_p, ctypes.c_char_p, _u32p]
+    lib.memb_oracle_resolve_many.restype = None
+    lib.memb_oracle_resolve_many.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t, _u32p]
     lib.memb_oracle_word_embedding.argtypes = [ctypes.c_void_p, ctypes.c_char_p, _f32p]
     lib.memb_oracle_batch_embedding.argtypes = [
         ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t, _f32p]
@@ -182,10 +184,11 @@ class OracleReader:
         return row.value if found else None
 
     def resolve_rows(self, words):
+        """the reference's search, word by word (memb_oracle_resolve); 0xFFFFFFFF = not in the model. A str is
+        searched as its UTF-8 bytes up to the first NUL, which is where strcmp stops"""
         rows = np.empty(len(words), dtype=np.uint32)
-        for i, word in enumerate(words):
-            row = self.resolve(word)
-            rows[i] = 0xFFFFFFFF if row is None else row
+        array = (ctypes.c_char_p * max(len(words), 1))(*[w.encode() if isinstance(w, str) else w for w in words])
+        self.lib.memb_oracle_resolve_many(self.handle, array, len(words), _ptr(rows, _u32p))
         return rows
 
     def word_embedding(self, word):

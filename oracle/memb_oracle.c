@@ -590,6 +590,18 @@ EXPORT int memb_oracle_resolve(const oracle_reader* r, const char* word, uint32_
     return 0;
 }
 
+/*
+ * The same search for a whole batch (tests of the device word search compare 2.2 M answers): words[i] NUL
+ * terminated; rows[i] = the row, or 0xFFFFFFFF for a miss.
+ */
+EXPORT void memb_oracle_resolve_many(const oracle_reader* r, const char* const* words, size_t count, uint32_t* rows)
+{
+    for (size_t i = 0; i < count; ++i) {
+        uint32_t row = 0;
+        rows[i] = memb_oracle_resolve(r, words[i], &row) ? row : 0xFFFFFFFFu;
+    }
+}
+
 /* decode of one present row */
 static void extract_row(const oracle_reader* r, size_t row, float* destination)
 {

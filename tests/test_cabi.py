@@ -24,6 +24,11 @@ def test_header_declares_the_expected_entry_points():
         'memb_hip_abi_version', 'memb_hip_ctx_set_option',
         'memb_hip_encoder_create', 'memb_hip_encoder_destroy', 'memb_hip_encoder_add_rows', 'memb_hip_encoder_counts',
         'memb_hip_encoder_pack', 'memb_hip_encoder_fetch', 'memb_hip_encoder_rows',
+        # round 5: word -> row on the device, several batches in one launch
+        'memb_hip_ctx_stage_words', 'memb_hip_words_create', 'memb_hip_words_destroy', 'memb_hip_words_pack',
+        'memb_hip_words_begin', 'memb_hip_words_commit', 'memb_hip_words_count', 'memb_hip_resolve_rows_device',
+        'memb_hip_resolve_range_device', 'memb_hip_resolve_packed_device',
+        'memb_hip_decode_batches_device',
     ])
 
 
@@ -65,6 +70,19 @@ def test_error_reporting_without_compute(native):
     assert not context.value
     assert library.memb_hip_sync(None) == 1
     library.memb_hip_ctx_destroy(None)  # harmless
+    library.memb_hip_words_destroy(None)
+    assert library.memb_hip_words_create(None, 0) == 1
+    assert library.memb_hip_ctx_stage_words(None, None, ctypes.c_uint64(0), None, ctypes.c_uint64(0)) == 1
+    assert library.memb_hip_resolve_rows_device(None, None, None, None) == 1
+    assert library.memb_hip_words_begin(None, ctypes.c_size_t(1), ctypes.c_size_t(0), None) == 1
+    assert library.memb_hip_words_commit(None) == 1
+    assert library.memb_hip_resolve_range_device(None, None, ctypes.c_size_t(0), ctypes.c_size_t(0), None, None) == 1
+    assert library.memb_hip_resolve_packed_device(None, None, None, ctypes.c_size_t(0), None, None) == 1
+    assert library.memb_hip_decode_batches_device(None, None, ctypes.c_size_t(0), None) == 1
+    if count.value == 0:
+        batch = ctypes.c_void_p()
+        assert library.memb_hip_words_create(ctypes.byref(batch), 0) == 2 and not batch.value   # ERR_DEVICE
+        assert b'no HIP device' in library.memb_hip_last_error()
     if count.value == 0:
         # a well-formed description still cannot be staged without a device
         import numpy as np

@@ -1,0 +1,378 @@
+"""Word -> row on the device: memb_hip_ctx_stage_words / memb_hip_words_* /
+memb_hip_resolve_rows_device and everything that is fed from them (Reader.resolve_rows_device,
+batch_embedding_device, tokenizer_embedding_device, ReadersUnion.batch_embedding_device), against the CPU
+checker's search -- the reference's lower_bound + strcmp (src/trained_compression.cpp:115-125) and LookupByKey
+(src/uniform_compression.cpp:56, src/full_compression.cpp:39) restated in oracle/memb_oracle.c. Bit-exact: row ids
+are integers. Also memb_hip_decode_batches_device (several batches in one launch)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+FULL_VOCAB = 2196017
+MISSING = 0xFFFFFFFF
+
+# keys that a hash + compare can get wrong where a binary search cannot: the empty word, prefixes of one another,
+# bytes above 0x7F (strcmp compares unsigned bytes; UTF-8 of two, three and four bytes), a word longer than a
+# wavefront's LDS stage, neighbours that differ in the last byte only
+TRICKY_KEYS = ['', 'a', 'ab', 'abc', 'abcd', 'th', 'the', 'then', 'theng', 'naïve', 'nai', 'naive',
+               '日本語', '日本', '日', '\U0001f600', '\U0001f601', 'zz', 'zzz',
+               'x' * 3000, 'x' * 2999 + 'y', 'q' * 40, 'q' * 41]
+
+
+def tricky_queries(keys, rng):
+    queries = list(keys)
+    queries += [key + 'z' for key in keys[:40]]                 # a key is a proper prefix of the query
+    queries += [key[:-1] for key in keys[:40] if key]           # the query is a proper prefix of a key
+    queries += ['\x01', '\x7f', 'ÿ' * 3, '\U0010ffff', '~~~~', ' ']   # sort before the first / after the last key
+    queries += ['the\x00n', 'abc\x00', '\x00abc']               # a word ends at its first NUL (strcmp)
+    queries += ['y' * 5000, 'x' * 3001, 'x' * 2998]             # longer than the LDS stage of a wavefront
+    queries += [queries[i] for i in rng.integers(0, len(queries), size=300)]   # repeats
+    order = rng.permutation(len(queries))
+    return [queries[i] for i in order]
+
+
+@pytest.fixture(scope='module')
+def tricky_models(native, tmp_path_factory):
+    """One small model per storage over TRICKY_KEYS + 700 synthetic words (several wavefronts of keys)."""
+    from memb_amd import synthetic
+    directory = tmp_path_factory.mktemp('words')
+    keys = TRICKY_KEYS + synthetic.make_words(700, seed=3)
+    rng = np.random.default_rng(5)
+    vectors = rng.standard_normal((len(keys), 20)).astype(np.float32)
+    paths = {}
+    for storage, bits in (('trained', 4), ('uniform', 8), ('full', 32)):
+        builder = native.Builder(20, storage, bits)
+        order = rng.permutation(len(keys))       # insertion order is not key order
+        builder.add_words([keys[i] for i in order], vectors[order])
+        paths[storage] = str(directory / (storage + '.bin'))
+        builder.save(paths[storage])
+    return paths, keys
+
+
+@pytest.mark.parametrize('storage', ['trained', 'uniform', 'full'])
+def test_tricky_words_on_every_storage(native, tricky_models, storage):
+    import torch
+    paths, keys = tricky_models
+    reader = native.Reader(paths[storage])
+    checker = oracle.OracleReader(paths[storage])
+    queries = tricky_queries(keys, np.random.default_rng(1))
+    expected = checker.resolve_rows(queries)
+    assert (expected != MISSING).sum() >= len(keys) and (expected == MISSING).sum() > 50
+    rows = reader.resolve_rows_device(queries)
+    assert rows.dtype == torch.int32 and rows.device.type == 'cuda'
+    got = rows.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, expected), [(queries[i][:20], got[i], expected[i]) for i in np.nonzero(got != expected)[0][:5]]
+    assert np.array_equal(reader.resolve_rows(queries), expected)        # the host search gives the same
+    info = reader.info()
+    assert info['word_index_keys'] == len(keys) and info['word_index_slots'] >= 2 * len(keys)
+    assert 0 < info['word_index_bytes'] <= info['device_bytes']
+    # the rows feed the decode without a host round trip
+    assert bits_equal(reader.batch_embedding_device(queries).cpu().numpy(), checker.batch_embedding(
+        [q.split('\x00')[0] for q in queries]))
+    # edge sizes: nothing, one word, one wavefront +- 1, one block +- 1
+    for count in (0, 1, 63, 64, 65, 255, 256, 257):
+        part = queries[:count]
+        assert np.array_equal(reader.resolve_rows_device(part).cpu().numpy().view(np.uint32), expected[:count]), count
+    with pytest.raises(TypeError):
+        reader.resolve_rows_device(['a', 7])
+    with pytest.raises(TypeError):
+        reader.resolve_rows_device(['a'], out=torch.empty(2, dtype=torch.int32, device='cuda'))
+
+
+@pytest.fixture(scope='module')
+def full_model(native):
+    from memb_amd import synthetic
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    path, _ = synthetic.cached_model(count, 300, 'trained', 4)   # shared with bench.py and test_gpu_full_size.py
+    return path, count
+
+
+def test_full_vocabulary_word_search(native, full_model):
+    """The 2.2 M-key model: all keys in key order, all keys shuffled, misses on both ends and in between, repeats."""
+    import torch
+    path, count = full_model
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    keys = reader.keys()
+    assert len(keys) == count
+    rows = reader.resolve_rows_device(keys)
+    assert torch.equal(rows, torch.arange(count, dtype=torch.int32, device='cuda'))
+    assert reader.info()['word_index_keys'] == count
+
+    rng = np.random.default_rng(23)
+    order = rng.permutation(count)
+    shuffled = [keys[i] for i in order]
+    got = reader.resolve_rows_device(shuffled).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, order.astype(np.uint32))
+
+    sample = rng.integers(0, count, size=300000)
+    mixed = [keys[i] for i in sample]
+    for i in range(0, len(mixed), 7):
+        mixed[i] = mixed[i] + '!'          # between keys
+    for i in range(3, len(mixed), 1001):
+        mixed[i] = '\x01' + mixed[i]       # before the first key
+    for i in range(5, len(mixed), 1003):
+        mixed[i] = '\U0010ffff' + mixed[i]  # after the last key: the reference's end() dereference
+    mixed[11] = ''
+    expected = checker.resolve_rows(mixed)
+    assert (expected == MISSING).sum() > 40000
+    got = reader.resolve_rows_device(mixed).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, expected)
+    assert np.array_equal(reader.resolve_rows(mixed), expected)
+    # the device API end to end on the model of BASELINE.json configs[1]
+    out = reader.batch_embedding_device(mixed[:50000])
+    assert bits_equal(out.cpu().numpy(), checker.rows_embedding(expected[:50000]))
+    assert reader.host_rows_decoded == 0
+
+
+def test_batch_sizes_around_every_packing_boundary(native, make_model):
+    """The packer splits a batch into jobs of 16 384 words and the jobs into copy chunks: sizes on both sides of every
+    boundary (round 5's first version waited forever on a chunk without jobs at 19 jobs)."""
+    path, words = make_model(6000, 300, 'trained', 4)
+    reader = native.Reader(path)
+    rng = np.random.default_rng(7)
+    pool = words + ['miss-{}'.format(i) for i in range(600)]
+    longest = [pool[i] for i in rng.integers(0, len(pool), size=25 * 16384 + 1)]
+    expected = reader.resolve_rows(longest)
+    assert (expected == MISSING).sum() > 1000
+    sizes = [16383, 16384, 16385, 2 * 16384 + 1, 100000]
+    sizes += [jobs * 16384 - delta for jobs in range(3, 26) for delta in (0, 16383)]
+    for size in sorted(set(sizes)) + [len(longest)]:
+        got = reader.resolve_rows_device(longest[:size]).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, expected[:size]), size
+
+
+def _library(native):
+    library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
+    library.memb_hip_last_error.restype = ctypes.c_char_p
+    return library
+
+
+class UniformRow(ctypes.Structure):
+    _fields_ = [('values', ctypes.c_void_p), ('n_values', ctypes.c_uint32),
+                ('min_value', ctypes.c_float), ('max_value', ctypes.c_float)]
+
+
+class UniformDesc(ctypes.Structure):
+    _fields_ = [('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64), ('rows', ctypes.c_void_p),
+                ('quantization_levels', ctypes.c_uint8)]
+
+
+def _uniform_context(library, count, dim=4):
+    payload = np.arange(count * dim, dtype=np.uint8)
+    rows = (UniformRow * count)()
+    for i in range(count):
+        rows[i] = UniformRow(payload.ctypes.data + i * dim, dim, 0.0, 1.0)
+    desc = UniformDesc(dim, count, ctypes.addressof(rows), 255)
+    context = ctypes.c_void_p()
+    assert library.memb_hip_ctx_create_uniform(ctypes.byref(context), 0, ctypes.byref(desc)) == 0, library.memb_hip_last_error()
+    return context
+
+
+def test_word_search_through_the_c_abi(native):
+    """stage_words / words_pack / resolve_rows_device / resolve_packed_device as a foreign caller binds them; a file
+    with REPEATED keys resolves to the first of them, as lower_bound does; the refusals."""
+    import torch
+    library = _library(native)
+    keys = [b'a', b'b', b'b', b'b', b'c', b'cc', b'cc', b'd']       # sorted, with repeats
+    packed = b''.join(key + b'\x00' for key in keys)
+    offsets = np.cumsum([0] + [len(key) + 1 for key in keys[:-1]]).astype(np.uint32)
+    context = _uniform_context(library, len(keys))
+    stage = library.memb_hip_ctx_stage_words
+    stage.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    # refusals first: a key count that is not the row count, keys without the final NUL, an offset outside
+    assert stage(context, packed, len(packed), offsets.ctypes.data, len(keys) - 1) == 1
+    assert stage(context, packed[:-1], len(packed) - 1, offsets.ctypes.data, len(keys)) == 1
+    bad = offsets.copy()
+    bad[3] = len(packed)
+    assert stage(context, packed, len(packed), bad.ctypes.data, len(keys)) == 1
+    batch = ctypes.c_void_p()
+    assert library.memb_hip_words_create(ctypes.byref(batch), 0) == 0
+    rows = torch.full((16,), 7, dtype=torch.int32, device='cuda')
+    resolve = library.memb_hip_resolve_rows_device
+    resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    queries = [b'b', b'cc', b'a', b'd', b'', b'bb', b'c', b'e', b'cc\x00x']
+    array = (ctypes.c_char_p * len(queries))(*queries)
+    pack = library.memb_hip_words_pack
+    pack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    assert resolve(context, batch, rows.data_ptr(), None) == 1        # nothing committed yet
+    assert pack(batch, array, None, len(queries)) == 0, library.memb_hip_last_error()
+    assert resolve(context, batch, rows.data_ptr(), None) == 1        # keys not staged yet
+    assert b'stage_words' in library.memb_hip_last_error()
+    assert stage(context, packed, len(packed), offsets.ctypes.data, len(keys)) == 0, library.memb_hip_last_error()
+    assert stage(context, packed, len(packed), offsets.ctypes.data, len(keys)) == 0   # idempotent
+    assert resolve(context, batch, rows.data_ptr(), None) == 0, library.memb_hip_last_error()
+    torch.cuda.synchronize()
+    assert rows.cpu().numpy().view(np.uint32).tolist()[:9] == [1, 5, 0, 7, MISSING, MISSING, 4, MISSING, 5]
+    assert rows[9:].eq(7).all()
+    count = ctypes.c_size_t()
+    assert library.memb_hip_words_count(batch, ctypes.byref(count)) == 0 and count.value == len(queries)
+    # explicit lengths (no terminators needed), and a second pack into the same object
+    joined = b'ccdab'
+    buffer = ctypes.create_string_buffer(joined, len(joined))
+    base = ctypes.addressof(buffer)
+    pointers = (ctypes.c_void_p * 4)(base, base + 2, base + 3, base + 4)
+    lengths = np.array([2, 1, 1, 1], dtype=np.uint32)
+    assert pack(batch, pointers, lengths.ctypes.data, 4) == 0, library.memb_hip_last_error()
+    assert resolve(context, batch, rows.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert rows.cpu().numpy().view(np.uint32).tolist()[:4] == [5, 7, 0, 1]
+
+    # a caller-filled batch (begin / write the jobs / commit), looked up job range by job range before the commit
+    class Plan(ctypes.Structure):
+        _fields_ = [('bytes', ctypes.c_void_p), ('offsets', ctypes.c_void_p), ('n', ctypes.c_size_t),
+                    ('job_words', ctypes.c_size_t), ('jobs', ctypes.c_size_t), ('job_bytes', ctypes.c_size_t)]
+    begin = library.memb_hip_words_begin
+    begin.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+    plan = Plan()
+    many = [b'cc', b'nope', b'a', b'', b'd', b'b'] * 100
+    assert begin(batch, len(many), 0, ctypes.byref(plan)) == 0, library.memb_hip_last_error()
+    assert plan.n == len(many) and plan.job_words % 64 == 0 and plan.jobs == -(-len(many) // plan.job_words) and plan.jobs > 2
+    assert plan.job_bytes % 16 == 0 and plan.job_bytes >= plan.job_words * 4
+    host_bytes = (ctypes.c_uint8 * (plan.jobs * plan.job_bytes)).from_address(plan.bytes)
+    host_offsets = (ctypes.c_uint32 * (plan.jobs * (plan.job_words + 1))).from_address(plan.offsets)
+    for job in range(plan.jobs):
+        at = job * plan.job_bytes
+        mine = many[job * plan.job_words:(job + 1) * plan.job_words]
+        for k, word in enumerate(mine):
+            host_offsets[job * (plan.job_words + 1) + k] = at
+            host_bytes[at:at + len(word)] = word
+            at += len(word)
+        host_offsets[job * (plan.job_words + 1) + len(mine)] = at
+    big = torch.full((len(many),), 7, dtype=torch.int32, device='cuda')
+    in_range = library.memb_hip_resolve_range_device
+    in_range.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    assert resolve(context, batch, big.data_ptr(), None) == 1          # not committed
+    assert in_range(context, batch, 1, 10, big.data_ptr(), None) == 1  # not the start of a job
+    assert in_range(context, batch, plan.job_words, len(many), big.data_ptr(), None) == 1   # past the end
+    assert in_range(context, batch, plan.job_words, plan.job_words, big.data_ptr(), None) == 0, library.memb_hip_last_error()
+    torch.cuda.synchronize()
+    want = np.array([{b'cc': 5, b'a': 0, b'd': 7, b'b': 1}.get(w, MISSING) for w in many], dtype=np.uint32)
+    got = big.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[plan.job_words:2 * plan.job_words], want[plan.job_words:2 * plan.job_words])
+    assert (got[:plan.job_words] == 7).all() and (got[2 * plan.job_words:] == 7).all()
+    assert library.memb_hip_words_commit(batch) == 0
+    assert resolve(context, batch, big.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(big.cpu().numpy().view(np.uint32), want)
+
+    # words that are on the device already; an UNALIGNED byte pointer takes the path without the LDS stage
+    packed_device = library.memb_hip_resolve_packed_device
+    packed_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    words = [b'cc', b'zebra', b'', b'b', b'a' * 100, b'd'] * 50
+    data = np.frombuffer(b''.join(words), dtype=np.uint8)
+    starts = np.cumsum([0] + [len(w) for w in words]).astype(np.uint32)
+    expected = [{b'cc': 5, b'b': 1, b'd': 7}.get(w, MISSING) for w in words]
+    for shift in (0, 1):
+        holder = torch.zeros(len(data) + 32, dtype=torch.uint8, device='cuda')
+        holder[shift:shift + len(data)] = torch.from_numpy(data.copy()).cuda()
+        device_offsets = torch.from_numpy(starts.view(np.int32).copy()).cuda()
+        out = torch.empty(len(words), dtype=torch.int32, device='cuda')
+        assert packed_device(context, holder.data_ptr() + shift, device_offsets.data_ptr(), len(words), out.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().view(np.uint32).tolist() == expected, shift
+
+    class Info(ctypes.Structure):
+        _fields_ = [('struct_size', ctypes.c_uint32), ('device', ctypes.c_int32), ('storage', ctypes.c_uint32),
+                    ('dim', ctypes.c_uint32), ('n_rows', ctypes.c_uint64), ('device_bytes', ctypes.c_uint64),
+                    ('trained', ctypes.c_uint32 * 8), ('kernel', ctypes.c_char * 96), ('row_layout', ctypes.c_uint32),
+                    ('row_bytes', ctypes.c_uint32), ('kernel_registers', ctypes.c_uint32),
+                    ('register_waves_per_cu', ctypes.c_uint32), ('batch_words', ctypes.c_uint64),
+                    ('tiles_per_wavefront', ctypes.c_uint32), ('reserved_abi3', ctypes.c_uint32 * 2),
+                    ('union_kernel', ctypes.c_char * 96), ('word_index_bytes', ctypes.c_uint64),
+                    ('word_index_slots', ctypes.c_uint32), ('word_index_keys', ctypes.c_uint32)]
+    info = Info()
+    info.struct_size = ctypes.sizeof(Info)
+    assert library.memb_hip_ctx_get_info(context, ctypes.byref(info)) == 0, library.memb_hip_last_error()
+    assert info.word_index_keys == 5 and info.word_index_slots == 16 and info.word_index_bytes > 0   # a, b, c, cc, d
+    assert info.struct_size == ctypes.sizeof(Info) and info.n_rows == len(keys)
+    # the ABI-4 declaration of this struct (union_kernel 8 bytes lower) is recognised by its size and refused
+    info.struct_size = ctypes.sizeof(Info) - 16 - 8
+    assert library.memb_hip_ctx_get_info(context, ctypes.byref(info)) == 1
+    assert b'ABI-4' in library.memb_hip_last_error()
+    library.memb_hip_words_destroy(batch)
+    library.memb_hip_ctx_destroy(context)
+
+
+def test_union_resolves_one_batch_against_every_reader(native, make_model):
+    import torch
+    path_a, words_a = make_model(6000, 300, 'trained', 4, seed=1)
+    path_b, words_b = make_model(5000, 300, 'trained', 4, seed=2)
+    # (both vocabularies come from one word generator: b knows the first 5000 of a's 6000 words and misses the rest)
+    readers = [native.Reader(path_a), native.Reader(path_b)]
+    checkers = [oracle.OracleReader(path_a), oracle.OracleReader(path_b)]
+    rng = np.random.default_rng(3)
+    batch = [words_a[i] for i in rng.integers(0, len(words_a), size=9000)]
+    batch += ['unknown-{}'.format(i) for i in range(500)] + ['']
+    for mode in ('concatenate', 'average'):
+        union = native.ReadersUnion(readers, mode)
+        out = union.batch_embedding_device(batch)
+        pieces = [checker.batch_embedding(batch) for checker in checkers]
+        expected = np.concatenate(pieces, axis=-1) if mode == 'concatenate' else np.mean(pieces, axis=0)
+        assert bits_equal(out.cpu().numpy(), expected), mode
+        assert bits_equal(union.batch_embedding(batch), expected), mode
+    assert all(reader.host_rows_decoded == 0 for reader in readers)
+
+
+def test_tokenizer_embedding_stays_on_the_device(native, make_model):
+    path, words = make_model(3000, 300, 'trained', 4)
+    reader = native.Reader(path)
+
+    class Tokenizer:
+        word_index = {word: index + 1 for index, word in enumerate(words[:500] + ['not-a-word'])}
+        num_words = 400
+    weights = reader.tokenizer_embedding_device(Tokenizer())
+    assert bits_equal(weights.cpu().numpy(), reader.tokenizer_embedding(Tokenizer()))
+    assert weights.shape == (400, 300) and not weights[0].any()
+
+
+@pytest.mark.parametrize('storage,bits', [('trained', 4), ('trained', 6), ('trained', 8), ('uniform', 8), ('full', 32)])
+def test_several_batches_in_one_launch(native, make_model, storage, bits):
+    """memb_hip_decode_batches_device: K in {1, 3, 8} ragged batches with misses, dense and strided outputs, against the
+    checker and against one launch per batch."""
+    import torch
+    path, words = make_model(4000, 300, storage, bits)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(31)
+    for sizes in ((1000,), (1, 777, 8), (513, 1, 64, 4099, 7, 8, 250, 1031)):
+        entries = []
+        host_rows = []
+        for k, size in enumerate(sizes):
+            rows = rng.integers(0, len(words), size=size).astype(np.uint32)
+            rows[rng.integers(0, size, size=max(1, size // 10))] = MISSING
+            host_rows.append(rows)
+            ids = torch.from_numpy(rows.view(np.int32)).cuda()
+            if k % 3 == 2:      # a column block of a wider matrix
+                out = torch.full((size, 640), 3.0, dtype=torch.float32, device='cuda')
+                entries.append((ids, out, 320))
+            else:
+                entries.append((ids, torch.full((size, 300), 3.0, dtype=torch.float32, device='cuda')))
+        outs = reader.rows_embedding_device_many(entries)
+        torch.cuda.synchronize()
+        for k, (rows, out) in enumerate(zip(host_rows, outs)):
+            expected = checker.rows_embedding(rows)
+            if k % 3 == 2:
+                assert bits_equal(out[:, 320:620].cpu().numpy(), expected), (sizes, k)
+                assert out[:, :320].eq(3.0).all() and out[:, 620:].eq(3.0).all()
+            else:
+                assert bits_equal(out.cpu().numpy(), expected), (sizes, k)
+    # an empty batch among the others, and an output whose rows are not 16-byte aligned (dim 300, ld 301)
+    ids = torch.from_numpy(host_rows[0].view(np.int32)).cuda()
+    odd = torch.zeros((len(host_rows[0]), 301), dtype=torch.float32, device='cuda')
+    empty = (torch.empty(0, dtype=torch.int32, device='cuda'), torch.empty((0, 300), dtype=torch.float32, device='cuda'))
+    dense = torch.zeros((len(host_rows[0]), 300), dtype=torch.float32, device='cuda')
+    reader.rows_embedding_device_many([(ids, odd), empty, (ids, dense)])
+    torch.cuda.synchronize()
+    expected = checker.rows_embedding(host_rows[0])
+    assert bits_equal(odd[:, :300].cpu().numpy(), expected) and bits_equal(dense.cpu().numpy(), expected)
+    with pytest.raises(ValueError):
+        reader.rows_embedding_device_many([(ids, torch.zeros((len(host_rows[0]), 200), dtype=torch.float32, device='cuda'))])
+    assert reader.host_rows_decoded == 0

@@ -513,6 +513,73 @@ def host_api_timings(reader, path, rows_host):
     }
 
 
+def word_search_timings(reader, path, torch, np, repeats=5):
+    """Word -> row, the step in front of the path (reference src/trained_compression.cpp:115-125,
+    python/memb_bindings.cpp:54-63): the host search (hash index on pooled threads, Reader.resolve_rows) against the
+    device search (Reader.resolve_rows_device: the words written once into pinned memory by pooled threads, read over
+    PCIe and looked up by resolve_words; timed from the call to the row ids being in HBM, synchronize included) on the
+    same Python lists, every answer compared with the host search and a sample with the CPU checker's binary search."""
+    import oracle
+    from memb_amd import _memb
+    keys = reader.keys()
+    count = len(keys)
+    rng = np.random.default_rng(41)
+    order = rng.permutation(count)
+    hundred = [keys[i] for i in rng.integers(0, count, size=min(100000, count))]
+    for i in range(0, len(hundred), 100):
+        hundred[i] = hundred[i] + '?'   # 1 % misses
+    batches = (('all keys, key order', keys), ('all keys, shuffled', [keys[i] for i in order]), ('100 000 random words, 1 % misses', hundred))
+    scratch = _memb.WordBatch(reader.device)
+    checker = oracle.OracleReader(path)
+    result = {'what': 'word -> row for Python lists of str: host = Reader.resolve_rows (hash index, pooled threads), device = '
+                      'Reader.resolve_rows_device (strings -> pinned memory on pooled threads, resolve_words reads them over PCIe; call to '
+                      'rows-in-HBM incl. synchronize); best of {} each'.format(repeats),
+              'index': {k: reader.info()[k] for k in ('word_index_bytes', 'word_index_slots', 'word_index_keys')}, 'batches': []}
+
+    def best(call):
+        times = []
+        for _ in range(repeats):
+            start = time.perf_counter()
+            call()
+            times.append(time.perf_counter() - start)
+        return min(times)
+
+    for name, words in batches:
+        rows = torch.empty(len(words), dtype=torch.int32, device='cuda')
+
+        def device():
+            reader.resolve_rows_device(words, out=rows)
+            torch.cuda.synchronize()
+
+        device()
+        expected = reader.resolve_rows(words)
+        agree = bool(np.array_equal(rows.cpu().numpy().view(np.uint32), expected))
+        picks = rng.choice(len(words), size=min(20000, len(words)), replace=False)
+        sample = [words[i] for i in picks]
+        agree_checker = bool(np.array_equal(checker.resolve_rows(sample), expected[picks]))
+        host_s = best(lambda: reader.resolve_rows(words))
+        device_s = best(device)
+        fill_s = best(lambda: _memb._word_fill_seconds(scratch, words))
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream().cuda_stream
+        kernel_ms = []
+        for _ in range(repeats):
+            begin.record()
+            reader._impl.resolve_batch_to_device(reader._word_batch, rows.data_ptr(), stream)
+            end.record()
+            torch.cuda.synchronize()
+            kernel_ms.append(begin.elapsed_time(end))
+        result['batches'].append({
+            'batch': name, 'words': len(words), 'host_ms': host_s * 1e3, 'device_ms': device_s * 1e3, 'speedup': host_s / device_s,
+            'device_breakdown_ms': {'strings -> pinned memory alone (no lookup)': fill_s * 1e3,
+                                    'resolve_words over the whole batch alone (reads the words over PCIe)': min(kernel_ms)},
+            'words_per_s_device': len(words) / device_s,
+            'parity': ('device == host search on every word; host == CPU checker (lower_bound + strcmp) on {} sampled words'.format(len(sample))
+                       if agree and agree_checker else 'MISMATCH'),
+        })
+    return result
+
+
 def prebuild_models(synthetic, models, workers=3):
     """Write the synthetic models this run needs and the box does not have yet, a few at a time (the builder
     releases the GIL while it works; the device writer streams every model's vectors to the GPU as they are drawn).
@@ -527,9 +594,15 @@ def prebuild_models(synthetic, models, workers=3):
 
 
 def open_reader(memb_amd, path, device, batch_words=0):
+    """Open + stage on this rank's GPU: the model (info() stages it) and the word -> row index (the keys and the hash
+    table over them, memb_hip_ctx_stage_words), so that `reader_open_s` and `device_bytes` are what a rank that serves
+    words -- not only row ids -- pays."""
     start = time.time()
     reader = memb_amd.Reader(path, device=device)
-    info = reader.info(batch_words)   # stages the model to HBM; the kernel named is the one a batch of that size runs
+    reader.info(batch_words)   # stages the model to HBM
+    if os.environ.get('MEMB_BENCH_REHEARSAL') != 'cpu':
+        reader.stage_words()
+    info = reader.info(batch_words)   # the kernel named is the one a batch of that size runs
     return reader, info, time.time() - start
 
 
@@ -595,18 +668,81 @@ def rotating_batches(reader, timer, library, torch, np, repeated, batch=100000, 
     averages = timer.bursts(call, 15 * sets)
     median = averages[len(averages) // 2]
     nbytes = sum(algorithmic_bytes(library, reader, rows) for rows, _, _ in batches) / sets
+    # several of those batches in ONE launch (memb_hip_decode_batches_device / Reader.rows_embedding_device_many): launch gap,
+    # prologue and tail once for all of them. Two groups of `sets` batches alternate, so that nothing is cached here either.
+    more = []
+    for k in range(sets):
+        rng = np.random.default_rng(210 + k)
+        rows = rng.integers(0, count, size=batch).astype(np.uint32)
+        rows[rng.integers(0, batch, size=batch // 100)] = MISSING
+        more.append((rows, torch.from_numpy(rows.view(np.int32)).cuda(),
+                     torch.empty((batch, reader.dim), dtype=torch.float32, device='cuda')))
+    groups = [[(ids, out) for _, ids, out in batches], [(ids, out) for _, ids, out in more]]
+
+    def many():
+        reader.rows_embedding_device_many(groups[turn[0] % 2])
+        turn[0] += 1
+
+    many_averages = timer.bursts(many, 30)
+    many_median = many_averages[len(many_averages) // 2]
+    many_bytes = sum(algorithmic_bytes(library, reader, rows) for rows, _, _ in batches + more) / 2
+    import oracle
+    checker = oracle.OracleReader(reader_path(reader), os.cpu_count() or 1) if reader_path(reader) else None
+    many_parity = 'skipped'
+    if checker is not None:
+        torch.cuda.synchronize()
+        picks = np.arange(0, batch, 37)
+        many_parity = 'bit-exact ({} sampled rows of each of the {} batches)'.format(len(picks), 2 * sets)
+        for rows, _, out in batches + more:
+            if not np.array_equal(out[torch.from_numpy(picks).cuda()].cpu().numpy().view(np.uint32),
+                                  checker.rows_embedding(np.ascontiguousarray(rows[picks])).view(np.uint32)):
+                many_parity = 'MISMATCH'
+    hbm = {
+        'what': '{} different batches of {} rows round-robin into {} output buffers ({} MB in flight): nothing of a launch is still cached at its next turn'.format(
+            sets, batch, sets, sets * batch * reader.dim * 4 // 1000000),
+        'kernel_ms': median, 'kernel_min_ms': averages[0],
+        'kernel_ms_timing': 'median / minimum of 5 bursts of {} launches, one HIP event pair per burst'.format(15 * sets),
+        'algorithmic_GBps': nbytes / (median * 1e-3) / 1e9,
+        'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        'against_repeated_buffer': median / repeated['kernel_ms'],
+    }
     return {
-        'frac_is': 'cache-assisted: one batch decoded again and again into one buffer (output and row regions of a launch still in the 256 MB Infinity Cache at the next)',
-        'hbm': {
-            'what': '{} different batches of {} rows round-robin into {} output buffers ({} MB in flight): nothing of a launch is still cached at its next turn'.format(
-                sets, batch, sets, sets * batch * reader.dim * 4 // 1000000),
-            'kernel_ms': median, 'kernel_min_ms': averages[0],
-            'kernel_ms_timing': 'median / minimum of 5 bursts of {} launches, one HIP event pair per burst'.format(15 * sets),
-            'algorithmic_GBps': nbytes / (median * 1e-3) / 1e9,
-            'frac': nbytes / (median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            'against_repeated_buffer': median / repeated['kernel_ms'],
+        'hbm': hbm,
+        'batches_in_one_launch': {
+            'what': '{} such batches in ONE launch (memb_hip_decode_batches_device: tiles numbered through, one prologue and one tail), two groups of '
+                    '{} batches and buffers alternating ({} MB in flight)'.format(sets, sets, 2 * sets * batch * reader.dim * 4 // 1000000),
+            'kernel': 'decode_trained_batches', 'batches': sets, 'launch_ms': many_median, 'launch_min_ms': many_averages[0],
+            'ms_per_batch': many_median / sets,
+            'algorithmic_GBps': many_bytes / (many_median * 1e-3) / 1e9,
+            'frac': many_bytes / (many_median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'against_one_batch_per_launch': (many_median / sets) / median,
+            'parity': many_parity,
         },
     }
+
+
+_READER_PATHS = {}
+
+
+def reader_path(reader):
+    return _READER_PATHS.get(id(reader))
+
+
+def primary_is_hbm(entry):
+    """configs[1]: the figure of the configuration is the one in which every byte comes from and goes to HBM (four
+    batches round-robin into four buffers); the cache-assisted one (one batch re-decoded into one buffer) moves to
+    `repeated_buffer`."""
+    hbm = entry.pop('hbm')
+    entry['repeated_buffer'] = {
+        'what': 'cache-assisted: ONE batch decoded again and again into ONE buffer (output and row regions of a launch still in the 256 MB Infinity Cache at the next)',
+        'kernel_ms': entry['kernel_ms'], 'kernel_min_ms': entry['kernel_min_ms'], 'kernel_ms_timing': entry['kernel_ms_timing'],
+        'algorithmic_GBps': entry['algorithmic_GBps'], 'frac': entry['frac'], 'embeddings_per_s': entry['embeddings_per_s'],
+    }
+    entry['frac_is'] = 'HBM regime: ' + hbm['what']
+    for key in ('kernel_ms', 'kernel_min_ms', 'kernel_ms_timing', 'algorithmic_GBps', 'frac'):
+        entry[key] = hbm[key]
+    entry['embeddings_per_s'] = entry['batch'] / (hbm['kernel_ms'] * 1e-3)
+    entry['against_repeated_buffer'] = hbm['against_repeated_buffer']
 
 
 def measure_union(reader_a, path_a, reader_b, path_b, timer, library, torch, np, batch=500000, launches=15):
@@ -676,7 +812,7 @@ def recorded_traffic(results, names):
                 entry['traffic_source'] = 'static: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over --workload {})'.format(key)
 
 
-def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, sizes):
+def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, sizes, ceilings=None):
     """Every BASELINE.json configuration, measured on cuda:0 outside the timed region."""
     glove, fasttext = sizes
     reader4, path4 = headline
@@ -697,7 +833,9 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     results.append(measure_config(
         'glove840b-300d-4bit-100k (BASELINE.json configs[1])', '100 000 uniformly random rows of the 2.2 M-word 4-bit model, 1 % misses',
         reader4, path4, rows, timer, library, torch, np, launches=30))
+    _READER_PATHS[id(reader4)] = path4
     results[-1].update(rotating_batches(reader4, timer, library, torch, np, results[-1]))
+    primary_is_hbm(results[-1])
     # device-resident latency of small batches of the same model: the kernel is chosen by batch size (one tile per
     # wavefront / decode_records_persistent / large-batch kernel), each timed as a burst of back-to-back launches
     small = []
@@ -707,14 +845,21 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
         target = torch.empty((count, reader4.dim), dtype=torch.float32, device='cuda')
         ms = timer.burst(lambda: reader4.rows_embedding_device(ids, out=target), 100 if count <= 100000 else 30)
         nbytes = algorithmic_bytes(library, reader4, picks)
-        small.append({'batch': count, 'kernel': reader4.info(count)['kernel'], 'us_per_launch': ms * 1e3,
+        small.append({'batch': count, 'kernel': reader4.info(count)['kernel'], 'lanes_per_word': reader4.info(count)['lanes_per_word'], 'us_per_launch': ms * 1e3,
                       'embeddings_per_s': count / (ms * 1e-3), 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
-        if count <= 10000:
-            # the same batch through Reader.prepared_lookup: the tensors are checked once, a call is the launch
-            prepared = reader4.prepared_lookup(ids, target)
-            small[-1]['prepared_us_per_launch'] = timer.burst(prepared, 100) * 1e3
         del ids, target
     results[-1]['small_batches_of_the_same_model'] = small
+
+    # the headline's batch in RANDOM order (token streams are: reference src/reader.cpp:49-57 takes words in any order): every
+    # row region is then two 128-byte lines of its own where a key-order dump reads 1.25 lines per row
+    shuffled4 = np.random.default_rng(77).permutation(len(reader4)).astype(np.uint32)
+    results.append(measure_config(
+        'glove840b-300d-4bit-fullvocab-shuffled (the headline batch in random order)',
+        'every row of the 2.2 M-word 4-bit model once, in shuffled order', reader4, path4, shuffled4, timer, library, torch, np))
+    if ceilings and ceilings.get('tile_fill_random_records'):
+        results[-1]['pattern_ceiling'] = {'tile_fill_random_records_ms': ceilings['tile_fill_random_records']['ms'],
+                                          'kernel_over_ceiling': results[-1]['kernel_ms'] / ceilings['tile_fill_random_records']['ms']}
+    del shuffled4
 
     path, spent = synthetic.cached_model(fasttext, 300, 'trained', 6)
     build_seconds += spent
@@ -722,6 +867,10 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     results.append(measure_config(
         'fasttext2m-300d-6bit-fullvocab (BASELINE.json configs[2])', 'full dump of a 2.0 M-word 6-bit model (byte keys, codes up to 10 bits)',
         reader, path, np.arange(len(reader), dtype=np.uint32), timer, library, torch, np))
+    results.append(measure_config(
+        'fasttext2m-300d-6bit-fullvocab-shuffled (configs[2]\'s batch in random order)',
+        'every row of the 2.0 M-word 6-bit model once, in shuffled order', reader, path,
+        np.random.default_rng(78).permutation(len(reader)).astype(np.uint32), timer, library, torch, np))
     del reader
 
     path, spent = synthetic.cached_model(glove, 300, 'trained', 2)
@@ -1101,7 +1250,8 @@ def main():
         kernel_timing = ('5 bursts of {} back-to-back launches, one HIP event pair per burst, after the timed region: average per launch over the bursts '
                          '(kernel_min_ms / kernel_median_ms: fastest / median burst; event pairs around every launch of the timed region averaged {:.4f} ms)').format(args.steps, per_launch_avg)
     fill_ms = sorted(begin.elapsed_time(end) for begin, end in fills[FILL_LAUNCHES // 2:])   # the settled half
-    rank_summary = {'rank': rank, 'device': local_rank, 'batch': n, 'kernel_avg_ms': kernel_avg_ms, 'kernel_min_ms': kernel_min_ms}
+    rank_summary = {'rank': rank, 'device': local_rank, 'batch': n, 'kernel_avg_ms': kernel_avg_ms, 'kernel_min_ms': kernel_min_ms,
+                    'reader_open_s': open_seconds, 'device_bytes': info.get('device_bytes'), 'word_index_bytes': info.get('word_index_bytes')}
     if distributed:
         per_rank = [None] * world_size
         dist.all_gather_object(per_rank, rank_summary)
@@ -1141,8 +1291,11 @@ def main():
     # Not part of `value`: what a caller of the reference's API sees (words in, numpy out; word search,
     # PCIe and host memory included), next to the restated CPU Reader on the same words and host cores.
     host_api = None
+    word_search = None
     if cpu_legs:
         host_api = host_api_timings(reader, path, rows_host)
+        if not cpu_rehearsal:
+            word_search = word_search_timings(reader, path, torch, np)
 
     # the box's own ceilings for this memory pattern (no decoder): same buffer, same run-in
     ceilings = None
@@ -1154,7 +1307,7 @@ def main():
     configs = None
     if world_size == 1 and not args.no_configs:
         del out, rows
-        configs, spent = all_configs(args, memb_amd, synthetic, (reader, path), timer, library, torch, np, (glove, fasttext))
+        configs, spent = all_configs(args, memb_amd, synthetic, (reader, path), timer, library, torch, np, (glove, fasttext), ceilings)
         build_seconds += spent
 
     achieved_gbps = nbytes / (kernel_avg_ms * 1e-3) / 1e9
@@ -1231,9 +1384,10 @@ def main():
         'strong_scaling': strong,
         'configs': configs,
         'host_api': host_api,
+        'word_search': word_search,
         'kernel_embeddings_per_s': n / (kernel_avg_ms * 1e-3),
         'geometry': {k: info.get(k) for k in ('waves_per_block', 'tiles_per_wavefront', 'lanes_per_word', 'segment_symbols', 'lds_bytes_per_block', 'root_bits',
-                                              'max_code_bits', 'max_stream_bytes', 'device_bytes', 'row_layout', 'row_bytes')},
+                                              'max_code_bits', 'max_stream_bytes', 'device_bytes', 'word_index_bytes', 'row_layout', 'row_bytes')},
         'model_build_s': build_seconds,
         'model_writer': 'host (memb_amd.Builder)' if args.host_writer else 'device (memb_amd.Builder(device={}): memb_hip_encoder_*)'.format(local_rank),
         'reader_open_s': open_seconds,

@@ -183,6 +183,9 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
  *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
  *                     decodes K tiles one after the other behind one copy of the tables into LDS
+ *   "fine_lanes"      0 (default) = batches of at most 0.62 tiles per 16 wavefronts per CU (20 000 words on 256 CUs) of a
+ *                     row-record model are decoded with its finer segment index (about sixteen lanes per word instead of
+ *                     eight: the chain of dependent lookups of a batch too small to hide it is shorter), 1 = never, 2 = always
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
  *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)

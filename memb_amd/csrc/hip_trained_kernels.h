@@ -49,6 +49,9 @@ struct TrainedParams {
     uint32_t indexLanes;      // OUT_INDEX: lanes per word of the index being built
     uint32_t indexSegmentSymbols;
     uint32_t indexWide;       // segment index entries are uint32_t rather than uint16_t
+    uint32_t fineIndex;       // row records whose segment offsets come from `segmentIndex` ([nRows][lanesPerWord - 1], the FINER
+                              // index of small batches: more lanes per word than the record in front of a row's stream has
+                              // offsets for) instead of from that record; both loads hang off the row id, side by side
     uint32_t debugFlags;      // measurement builds only (MEMB_HIP_MEASURE; see measureFlags below)
     uint32_t tilesPerWave;    // decode_trained / decode_union_split: tiles a wavefront decodes one after the other (>= 1):
                               // the block's copy of table and codebook into LDS is paid once for all of them
@@ -150,6 +153,9 @@ __device__ __forceinline__ WordMeta loadWordMeta(const TrainedParams& p, uint32_
     }
     if (p.recordPieces) {   // row records: the address is arithmetic, the offsets come with the stream
         meta.start = row < p.nRows ? row * p.recordPieces : 0u;
+        if (p.fineIndex && row < p.nRows && role.segment > 0) {   // ... or from the finer index, in parallel with it
+            meta.segmentBits = p.segmentIndex[static_cast<unsigned long long>(row) * (p.lanesPerWord - 1) + role.segment - 1];
+        }
         return meta;
     }
     if (row < p.nRows && p.rowMeta) {
@@ -266,7 +272,7 @@ __device__ __forceinline__ void writeStreams(
 __device__ __forceinline__ void recordSegmentBits(
     const TrainedParams& p, const uint32_t* slots, const LaneRole& role, WordMeta& meta)
 {
-    if (p.recordPieces) {
+    if (p.recordPieces && !p.fineIndex) {
         const uint32_t* slot = slots + role.word * p.slotDwords;
         meta.segmentBits = segmentField(role.segment, slot[1], slot[2], slot[3]);
     }
@@ -294,7 +300,8 @@ __device__ __forceinline__ void decodeSegment(
     const TrainedParams& p, const TableEntry* tableLds, const uint32_t* slots, uint32_t* keyTile,
     const LaneRole& role, const WordMeta& meta, uint32_t rootBits = 0)   // rootBits: of the lane's table when lanes differ
 {
-    static_assert(!(FAST && PACKED), "nibble keys use the 8-byte table");
+    // (FAST && PACKED: nibble keys through the 4-byte table -- one ds_read_b32 per symbol and half the table to copy into
+    // LDS, the symbol moved into its nibble by a bit-field extract and a shift-or instead of one and-or with a mask)
     constexpr int GROUP = FAST ? 8 : 4;
     constexpr uint32_t KEY_BITS = FAST ? 4 : 8;
     constexpr uint32_t KEY_MASK = FAST ? 0xFu : 0xFFu;
@@ -359,11 +366,15 @@ __device__ __forceinline__ void decodeSegment(
                     }
                 }
                 window <<= (entry & 63);
-                lengths += entry;   // the low byte sums the lengths (4 x 16 at most), the symbols pile up above it
-                // symbol (byte 1 of the entry) into byte s of the group: one v_perm_b32
-                // (selector bytes 0..3 pick bytes of `keys`, 5 picks byte 1 of `entry`)
-                const uint32_t select = s == 0 ? 0x03020105u : s == 1 ? 0x03020500u : s == 2 ? 0x03050100u : 0x05020100u;
-                keys = __builtin_amdgcn_perm(entry, keys, select);
+                lengths += entry;   // the low byte sums the lengths (4 x 16 or 8 x 8 at most), the symbols pile up above it
+                if (FAST) {
+                    keys |= ((entry >> 8) & 0xFu) << (4 * s);
+                } else {
+                    // symbol (byte 1 of the entry) into byte s of the group: one v_perm_b32
+                    // (selector bytes 0..3 pick bytes of `keys`, 5 picks byte 1 of `entry`)
+                    const uint32_t select = s == 0 ? 0x03020105u : s == 1 ? 0x03020500u : s == 2 ? 0x03050100u : 0x05020100u;
+                    keys = __builtin_amdgcn_perm(entry, keys, select);
+                }
             }
             lengths &= 0xff;
         } else {
@@ -1119,7 +1130,8 @@ __global__ void decode_trained_union(UnionParams u)
 // lane against the lane's model here and arrive as MISSING or valid); u.keyTileOffsetDwords[1] = where the upper half's rows begin inside the one symbol tile.
 // FAST: nibble keys in both models (8-byte table entries); else byte keys for both (a nibble-key model through its
 // byte-key forms), decoded through 4-byte PACKED tables.
-template <bool HAS_SUB, bool FAST, bool AVERAGE>
+// COMPACT (nibble keys only): the models' 4-byte tables (memb_hip_ctx::table32) instead of the 8-byte ones.
+template <bool HAS_SUB, bool FAST, bool AVERAGE, bool COMPACT = false>
 __global__ void decode_union_split(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1278,7 +1290,7 @@ __global__ void decode_union_split(UnionParams u)
         recordSegmentBits(both, slots, role, meta);
         const uint32_t* table = lds + (upper ? u.tableOffsetDwords[1] : u.tableOffsetDwords[0]);
         if (!(measure & 1)) {
-            decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST>(
+            decodeSegment<HAS_SUB, OUT_VEC4, FAST, !FAST || COMPACT>(
                 both, reinterpret_cast<const TableEntry*>(table), slots, waveLds + u.keyTileOffsetDwords[0], role, meta,
                 upper ? u.model[1].rootBits : u.model[0].rootBits);
         }

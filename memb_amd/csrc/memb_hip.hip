@@ -120,6 +120,9 @@ struct Switches {
                                    // 0 = never, 1 = whenever the pair qualifies
     uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: tiles a wavefront of the one-tile kernels decodes one after the
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
+    uint32_t unionCompact = 0;     // MEMB_HIP_UNION_COMPACT: decode_union_split of two nibble-key models through their 4-byte tables
+    uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
+                                   // 2 = every batch of a model that has one (tests, measurements)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -160,6 +163,12 @@ struct memb_hip_ctx {
     uint16_t* segmentIndex = nullptr;    // [nRows][lanesPerWord - 1]; uint32_t entries when indexWide
     bool indexWide = false;              // some row is longer than 65535 bits
     uint32_t* rowMeta = nullptr;         // 16-byte records {start, 13-bit segment offsets}: what lookups read (or null)
+    // The finer index of small batches (row-record models): [nRows][fineLanes - 1] uint16_t offsets at which symbols
+    // fineSymbols, 2 fineSymbols, ... of each row start -- about sixteen lanes decode a word side by side where the records
+    // have offsets for eight, which shortens the one chain of dependent LDS lookups a small batch has nothing to hide behind
+    uint16_t* fineIndex = nullptr;
+    uint32_t fineLanes = 0;
+    uint32_t fineSymbols = 0;
     uint32_t recordPieces = 0;           // non-zero: row records (TrainedParams::recordPieces); `streams` is that array
     char unionKernel[96] = {0};            // what the last union launch with this context as its first model ran
     uint32_t lanesPerWord = 1;           // G: lanes that share one word
@@ -527,15 +536,22 @@ struct Epilogue {
     float divisor = 0.f;
 };
 
-// The parameters of a lookup kernel that do not depend on the batch.
-TrainedParams lookupParams(const memb_hip_ctx* ctx)
+// The parameters of a lookup kernel that do not depend on the batch. fine: decode with the finer index (more lanes per
+// word, fewer words per wavefront; memb_hip_ctx::fineIndex).
+TrainedParams lookupParams(const memb_hip_ctx* ctx, bool fine = false)
 {
-    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    const uint32_t lanesPerWord = fine ? ctx->fineLanes : ctx->lanesPerWord;
+    const uint32_t wordsPerWave = WAVE / lanesPerWord;
     TrainedParams params = baseTrainedParams(ctx);
-    params.lanesPerWord = ctx->lanesPerWord;
-    params.laneMagic = magicFor(ctx->lanesPerWord, WAVE);
+    if (fine) {
+        params.segmentIndex = ctx->fineIndex;
+        params.fineIndex = 1;
+        params.slotMagic = magicFor(params.loadPieces, 64ull * params.loadPieces * 5);
+    }
+    params.lanesPerWord = lanesPerWord;
+    params.laneMagic = magicFor(lanesPerWord, WAVE);
     params.wordsPerWave = wordsPerWave;
-    params.segmentSymbols = ctx->segmentSymbols;
+    params.segmentSymbols = fine ? ctx->fineSymbols : ctx->segmentSymbols;
     params.keyRowBytes = keyRowBytes(ctx);
     params.keyTileDwords = keyTileDwords(ctx, wordsPerWave);
     params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(wordsPerWave) * (ctx->dim / 4));
@@ -556,7 +572,7 @@ bool lookupParamsConsistent(const memb_hip_ctx* ctx, const TrainedParams& params
     return wordsPerWave >= 1 && wordsPerWave * params.lanesPerWord <= WAVE &&
         params.slotDwords >= 4 && params.slotDwords % 4 == 0 && params.segmentSymbols % group == 0 &&
         params.loadPieces >= 1 && params.loadPieces * 4 <= params.slotDwords &&
-        (!params.recordPieces || (params.lanesPerWord <= ROW_META_MAX_LANES && params.slotDwords >= 4 * params.recordPieces + 3)) &&
+        (!params.recordPieces || ((params.fineIndex || params.lanesPerWord <= ROW_META_MAX_LANES) && params.slotDwords >= 4 * params.recordPieces + 3)) &&
         uint64_t(params.lanesPerWord) * params.segmentSymbols >= params.dim &&
         uint64_t(params.lanesPerWord - 1) * params.segmentSymbols < params.dim &&
         params.keyRowBytes * (ctx->fast ? 2u : 1u) >= params.dim &&
@@ -589,6 +605,7 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
 
 // Which kernel a batch of this output shape runs, and with what launch geometry.
 struct TrainedPlan {
+    bool fine = false;                   // decode_trained with the finer index (small batches)
     bool persistent = false;             // decode_records_persistent (else decode_trained)
     TrainedGeometry geometry{};
     TrainedKernel kernel = nullptr;      // persistent only
@@ -597,6 +614,7 @@ struct TrainedPlan {
 };
 
 constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below (times the CUs)
+constexpr uint64_t FINE_TILES_PER_R_PERCENT = 62;   // the finer index up to 0.62 R tiles (20 000 words on 256 CUs)
 
 // (the context's device is current)
 // Which kernel by batch size (n words): a STATIC rule. t = tiles of the batch, R = 16 x CUs. Round 4 measured every
@@ -613,18 +631,32 @@ constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below
 // so they keep four. The price: full-size batches in SHUFFLED order +1.2..1.8 % (4-bit; 2-bit -2.1 %).
 // force: -1 = by the rule, 0 = one tile per wavefront, 1 = decode_records_persistent where the layout allows
 int planTrained(
-    const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1)
+    const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1,
+    bool mayBeFine = true)
 {
-    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+    uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint64_t R = uint64_t(ctx->cuCount) * PIPELINE_WAVES_PER_CU;
+    // Small batches -- at most FINE_TILES_PER_R_PERCENT % of R tiles: every wavefront has one tile and most CUs are not full --
+    // are one chain of dependent steps per wavefront with nothing to hide it behind; the finer index shortens the longest
+    // link, the decode. Round 5, batch 3 (tools/perf/r5/batch3.sh; eight lanes per word = 100 %): 1 000 / 5 000 / 10 000 /
+    // 16 000 / 20 000 rows: 4-bit -11 / -14 / -13 / -3 / -5 %, 6-bit -22 / -24 / -17 / -8 / -16 %, 2-bit -8 / -13 / -12 / -4 /
+    // -5 %; 30 000 and 40 000 rows +8 / +1 % (4-bit), +3 / -1 % (6-bit), +10 / +7 % (2-bit); 100 000 rows +4..+14 %, with
+    // nothing cached +21..+41 %. (50 000 rows -10 / -15 / -3 %: an island at 1.5 R tiles that the rule leaves alone.)
+    // (a forced kernel -- option persistent = 2, force = 1 -- wins over the rule, a forced finer index over both)
+    plan->fine = mayBeFine && ctx->fineIndex && force != 1 &&
+        (ctx->switches.fineLanes == 2 ||
+         (ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && tiles * 100 <= R * FINE_TILES_PER_R_PERCENT));
+    if (plan->fine) {
+        wordsPerWave = WAVE / ctx->fineLanes;
+    }
     // the pipeline keeps a tile's row regions in two registers per lane: the slot image must fit two 64-lane rounds
     const bool recordsFit = ctx->recordPieces && wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
     bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > 2 * R && tiles <= 4 * R);
     if (force >= 0) {
         wantPersistent = force != 0;
     }
-    plan->persistent = recordsFit && wantPersistent;
+    plan->persistent = recordsFit && wantPersistent && !plan->fine;
     const uint32_t preferred = !plan->persistent && ctx->fast && tiles > 16 * R ? 8u : 4u;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, 32, preferred);
     if (keysOut) {
@@ -642,6 +674,10 @@ int planTrained(
         plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, plan->registerWavesPerCu);
         plan->geometry.mode = mode;
     }
+    if (plan->fine && !plan->geometry.waves) {   // (cannot happen: fewer words per wavefront need less LDS)
+        plan->fine = false;
+        return planTrained(ctx, n, ld, colOff, out, keysOut, plan, force, false);
+    }
     return MEMB_HIP_OK;
 }
 
@@ -651,19 +687,19 @@ int launchTrained(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
     const Epilogue& epilogue, bool keysOut = false, int force = -1)
 {
-    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     TrainedPlan plan;
     int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
+    const uint32_t wordsPerWave = WAVE / (plan.fine ? ctx->fineLanes : ctx->lanesPerWord);
     const bool persistent = plan.persistent;
     TrainedGeometry geometry = plan.geometry;
     TrainedKernel kernel = plan.kernel;
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
-    TrainedParams params = lookupParams(ctx);
+    TrainedParams params = lookupParams(ctx, plan.fine);
     params.rows = rows;
     params.out = out;
     params.n = n;
@@ -734,7 +770,7 @@ int launchTrainedBatches(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_
     }
     list.firstTile[list.count] = tiles;
     TrainedPlan plan;
-    const int planned = planTrained(ctx, words, ctx->dim, 0, nullptr, false, &plan, 0);
+    const int planned = planTrained(ctx, words, ctx->dim, 0, nullptr, false, &plan, 0, false);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
@@ -895,8 +931,10 @@ int launchTrainedUnion(
     auto chooseWaves = [&](uint32_t sharedDwords, uint32_t perWaveDwords, uint32_t registerWaves, uint32_t* waves, uint32_t* ldsBytes) {
         double bestResident = -1;
         *waves = 0;
-        for (uint32_t candidate : {4u, 8u, 2u, 1u}) {
-            if (first->switches.waves && candidate != first->switches.waves) {
+        // (a forced block size -- option waves_per_block, 1 .. 16 -- is the only candidate, as in chooseGeometry)
+        const uint32_t forced = first->switches.waves;
+        for (uint32_t candidate : {forced ? forced : 4u, 8u, 2u, 1u}) {
+            if (forced && candidate != forced) {
                 continue;
             }
             const uint32_t bytes = 4u * (sharedDwords + candidate * perWaveDwords);
@@ -933,8 +971,24 @@ int launchTrainedUnion(
     }
     if (split) {
         UnionParams sp = params;
-        const uint32_t shared = sharedDwords;
+        uint32_t shared = sharedDwords;
         const bool packedSub = !allFast && hasSub;
+        // nibble keys through the 4-byte tables (option union_compact): half the table bytes in the block's LDS image
+        const bool compact = allFast && first->switches.unionCompact != 0 && ctxs[0]->table32 && ctxs[1]->table32 &&
+            !ctxs[0]->byteTable.hasSubTables && !ctxs[1]->byteTable.hasSubTables;
+        if (compact) {
+            shared = 0;
+            for (size_t m = 0; m < 2; ++m) {
+                sp.model[m].table = ctxs[m]->table32;
+                sp.model[m].tableDwords = packedTableDwords(ctxs[m]);
+                sp.model[m].rootBits = ctxs[m]->byteTable.rootBits;
+                sp.tableOffsetDwords[m] = shared;
+                shared += sp.model[m].tableDwords;
+            }
+            sp.codebookOffsetDwords = shared;
+            shared += 2 * 512;
+            sp.sharedDwords = shared;
+        }
         const uint32_t half = wordsPerWave / 2;
         sp.model[2] = sp.model[larger];
         sp.model[2].nRows = 0xFFFFFFFFu;   // (rows reach the decoder checked against their own model, or MISSING)
@@ -942,7 +996,8 @@ int launchTrainedUnion(
         sp.keyTileOffsetDwords[0] = roundUp4(wordsPerWave * ctxs[larger]->slotDwords);
         sp.keyTileOffsetDwords[1] = sp.keyTileOffsetDwords[0] + half * sp.model[0].keyRowBytes / 4;
         sp.perWaveDwords = sp.keyTileOffsetDwords[0] + roundUp4(sp.model[0].keyTileDwords);
-        kernel = allFast ? (average ? &decode_union_split<false, true, true> : &decode_union_split<false, true, false>)
+        kernel = compact ? (average ? &decode_union_split<false, true, true, true> : &decode_union_split<false, true, false, true>)
+            : allFast ? (average ? &decode_union_split<false, true, true> : &decode_union_split<false, true, false>)
             : packedSub ? (average ? &decode_union_split<true, false, true> : &decode_union_split<true, false, false>)
                         : (average ? &decode_union_split<false, false, true> : &decode_union_split<false, false, false>);
         hipError_t status = registerWavesPerCu(reinterpret_cast<TrainedKernel>(kernel), &registerWaves, &numRegs);
@@ -969,8 +1024,8 @@ int launchTrainedUnion(
             if (status != hipSuccess) {
                 return fail(MEMB_HIP_ERR_DEVICE, std::string("decode_union_split launch: ") + hipGetErrorString(status));
             }
-            std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_union_split<%s, %s, %s>",
-                          packedSub ? "true" : "false", allFast ? "true" : "false", average ? "true" : "false");
+            std::snprintf(ctxs[0]->unionKernel, sizeof(ctxs[0]->unionKernel), "decode_union_split<%s, %s, %s, %s>",
+                          packedSub ? "true" : "false", allFast ? "true" : "false", average ? "true" : "false", compact ? "true" : "false");
             return MEMB_HIP_OK;
         }
         // (does not fit: the forms below lay their areas out afresh)
@@ -1009,14 +1064,15 @@ int launchTrainedUnion(
 // One pass over every row with one lane per word: records the bit position at
 // which each segment of each row starts (segmentIndex), so that lanesPerWord
 // lanes can later decode a row side by side.
-int buildSegmentIndex(memb_hip_ctx* ctx)
+// (lanes, symbols, target: the index to build -- the context's own, or the finer one of small batches)
+int buildSegmentIndex(memb_hip_ctx* ctx, uint32_t lanes, uint32_t symbols, uint16_t* target)
 {
-    if (ctx->lanesPerWord <= 1 || ctx->nRows == 0) {
+    if (lanes <= 1 || ctx->nRows == 0) {
         return MEMB_HIP_OK;
     }
     TrainedParams params = baseTrainedParams(ctx);
     params.segmentIndex = nullptr;
-    params.segmentIndexOut = ctx->segmentIndex;
+    params.segmentIndexOut = target;
     params.rows = nullptr;
     params.n = ctx->nRows;
     params.lanesPerWord = 1;
@@ -1024,8 +1080,8 @@ int buildSegmentIndex(memb_hip_ctx* ctx)
     params.segmentSymbols = (ctx->dim + 7) / 8 * 8;
     params.keyRowBytes = 0;
     params.keyTileDwords = 0;
-    params.indexLanes = ctx->lanesPerWord;
-    params.indexSegmentSymbols = ctx->segmentSymbols;
+    params.indexLanes = lanes;
+    params.indexSegmentSymbols = symbols;
 
     // one lane per word, normally 64 words per wavefront; fewer (the other lanes idle) when
     // 64 bitstream slots are more than LDS holds
@@ -1062,6 +1118,31 @@ uint32_t rowwiseWordsPerBlock(uint32_t dim)
     return std::max<uint32_t>(1, std::min<uint32_t>(ROWWISE_MAX_WORDS, 4096 / std::max<uint32_t>(dim, 1)));
 }
 
+// Whether a batch of this output shape runs dequant_uniform_tile (one tile per wavefront, row regions through LDS), and
+// with what geometry: output pieces of 16 bytes, a tile's regions fitting LDS (blocks of four wavefronts, fewer for very
+// wide rows), 32-bit piece numbers; option `persistent` = 0 keeps the block kernel (tests). launchUniform and
+// memb_hip_ctx_get_info both ask here.
+struct UniformTilePlan {
+    bool tiled = false;
+    uint32_t waves = 0;
+    uint32_t tileWords = 0;
+};
+
+UniformTilePlan planUniform(const memb_hip_ctx* ctx, size_t ld, size_t colOff, const float* out)
+{
+    UniformTilePlan plan;
+    const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
+        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    plan.tileWords = std::max<uint32_t>(1, std::min<uint32_t>(WAVE, (9600 + ctx->dim * 4 - 1) / (ctx->dim * 4)));
+    plan.waves = 4;
+    while (plan.waves > 1 && uint64_t(plan.waves) * plan.tileWords * ctx->regionPieces * 16 > ctx->ldsLimit) {
+        plan.waves /= 2;
+    }
+    plan.tiled = vec && ctx->switches.persistent != 0 && uint64_t(ctx->nRows + 1) * ctx->regionPieces < (1ull << 32) &&
+        uint64_t(plan.waves) * plan.tileWords * ctx->regionPieces * 16 <= ctx->ldsLimit;
+    return plan;
+}
+
 int launchUniform(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, hipStream_t stream,
     const Epilogue& epilogue)
@@ -1082,15 +1163,10 @@ int launchUniform(
     params.levels = ctx->levels;
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    // One tile per wavefront (dequant_uniform_tile) whenever output pieces are 16 bytes and a tile's row regions fit into
-    // LDS (blocks of four wavefronts, fewer for very wide rows); `persistent` = 0 keeps the block kernel (tests).
-    const uint32_t tileWords = std::max<uint32_t>(1, std::min<uint32_t>(WAVE, (9600 + ctx->dim * 4 - 1) / (ctx->dim * 4)));
-    uint32_t waves = 4;
-    while (waves > 1 && uint64_t(waves) * tileWords * ctx->regionPieces * 16 > ctx->ldsLimit) {
-        waves /= 2;
-    }
-    if (vec && ctx->switches.persistent != 0 && uint64_t(ctx->nRows + 1) * ctx->regionPieces < (1ull << 32) &&
-        uint64_t(waves) * tileWords * ctx->regionPieces * 16 <= ctx->ldsLimit) {
+    const UniformTilePlan tilePlan = planUniform(ctx, ld, colOff, out);
+    const uint32_t tileWords = tilePlan.tileWords;
+    const uint32_t waves = tilePlan.waves;
+    if (tilePlan.tiled) {
         params.wordsPerWave = tileWords;
         params.regionMagic = magicFor(ctx->regionPieces, uint64_t(tileWords) * ctx->regionPieces + WAVE);
         params.pieceMagic = magicFor(ctx->dim / 4, uint64_t(tileWords) * (ctx->dim / 4));
@@ -1308,6 +1384,8 @@ Switches readSwitches()
     switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
     switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
     switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
+    switches.fineLanes = std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES", 0), 2);
+    switches.unionCompact = std::min<uint32_t>(envUint("MEMB_HIP_UNION_COMPACT", switches.unionCompact), 1);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1733,7 +1811,7 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
             size_t(desc->n_rows) * (ctx->lanesPerWord - 1) * (ctx->indexWide ? sizeof(uint32_t) : sizeof(uint16_t)));
     }
     if (code == MEMB_HIP_OK) {
-        code = buildSegmentIndex(ctx);
+        code = buildSegmentIndex(ctx, ctx->lanesPerWord, ctx->segmentSymbols, ctx->segmentIndex);
     }
     // Lookups read a row's stream start and segment offsets as one 16-byte record with one load
     // per lane: one request per word of a random batch (the two arrays cost two or three), one
@@ -1769,6 +1847,27 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         }
         if (lengths) {
             (void)hipFree(lengths);
+        }
+    }
+    // The finer index of small batches (memb_hip_ctx::fineIndex): about sixteen lanes per word for models staged as row
+    // records -- a second pass of the index kernel, 2 bytes per offset (53 MB for the 2.2 M-word model of dim 300: a
+    // seventh of its footprint on a 288 GB part).
+    if (code == MEMB_HIP_OK && records && desc->n_rows && !ctx->indexWide && envUint("MEMB_HIP_FINE_INDEX", 1)) {
+        const uint32_t group = ctx->fast ? 8 : 4;
+        const uint32_t wanted = std::max<uint32_t>(2, std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES_TARGET", 16), WAVE));
+        const uint32_t symbols = std::max<uint32_t>(group, ((desc->dim + wanted - 1) / wanted + group - 1) / group * group);
+        const uint32_t lanes = (desc->dim + symbols - 1) / symbols;
+        if (lanes > ctx->lanesPerWord && lanes <= WAVE) {
+            code = deviceAlloc(ctx, &ctx->fineIndex, size_t(desc->n_rows) * (lanes - 1) * sizeof(uint16_t) + 16);
+            if (code == MEMB_HIP_OK) {
+                code = buildSegmentIndex(ctx, lanes, symbols, ctx->fineIndex);
+            }
+            if (code == MEMB_HIP_OK) {
+                ctx->fineLanes = lanes;
+                ctx->fineSymbols = symbols;
+            } else {
+                ctx->fineIndex = nullptr;
+            }
         }
     }
     return code;
@@ -1967,6 +2066,10 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "tiles_per_wave" && value <= 64) {
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
+    } else if (key == "union_compact" && value <= 1) {
+        ctx->switches.unionCompact = static_cast<uint32_t>(value);
+    } else if (key == "fine_lanes" && value <= 2) {
+        ctx->switches.fineLanes = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {
         ctx->switches.unionSplit = static_cast<uint32_t>(value);
     } else if (key == "persistent" && value <= 2) {
@@ -2015,8 +2118,8 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         std::snprintf(info->union_kernel, sizeof(info->union_kernel), "%s", ctx->unionKernel);
         info->kernel_registers = static_cast<uint32_t>(plan.numRegs);
         info->register_waves_per_cu = plan.persistent ? plan.registerWavesPerCu : 0;
-        info->lanes_per_word = ctx->lanesPerWord;
-        info->segment_symbols = ctx->segmentSymbols;
+        info->lanes_per_word = plan.fine ? ctx->fineLanes : ctx->lanesPerWord;
+        info->segment_symbols = plan.fine ? ctx->fineSymbols : ctx->segmentSymbols;
         info->lds_bytes_per_block = geometry.ldsBytes;
         info->row_layout = ctx->recordPieces ? 2u : (ctx->rowMeta ? 1u : 0u);
         info->row_bytes = ctx->recordPieces * 16;
@@ -2026,15 +2129,18 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
             ctx->fast ? "true" : "false");
         if (!plan.persistent) {
-            const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
+            const uint32_t wordsPerWave = WAVE / info->lanes_per_word;
             const uint64_t words = batchWords ? batchWords : uint64_t(1) << 30;
             info->tiles_per_wavefront = oneTileSteps(
                 ctx, (words + wordsPerWave - 1) / wordsPerWave,
                 4u * ((ctx->fast ? ctx->tableDwords : packedTableDwords(ctx)) + codebookDwords(ctx)), false);
         }
     } else {
-        info->waves_per_block = ROWWISE_THREADS / WAVE;
-        const bool tiled = ctx->storage == memb::wire::Storage_Uniform && ctx->dim % 4 == 0 && ctx->switches.persistent != 0;
+        // (a dense, aligned device-resident batch: what bench.py and the tests report for)
+        const UniformTilePlan tilePlan = ctx->storage == memb::wire::Storage_Uniform ? planUniform(ctx, ctx->dim, 0, nullptr) : UniformTilePlan();
+        const bool tiled = tilePlan.tiled;
+        info->waves_per_block = tiled ? tilePlan.waves : ROWWISE_THREADS / WAVE;
+        info->lds_bytes_per_block = tiled ? tilePlan.waves * tilePlan.tileWords * ctx->regionPieces * 16 : 0;
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<true>",
             tiled ? "dequant_uniform_tile" : ctx->storage == memb::wire::Storage_Uniform ? "dequant_uniform" : "gather_full");

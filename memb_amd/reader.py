@@ -55,7 +55,10 @@ def _current_stream(torch, index):
     without building a Stream object: a microsecond per lookup)'''
     raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
     if raw is not None:
-        return raw(index)
+        try:
+            return raw(index)
+        except TypeError:   # (a private entry point: should its signature change, the public one still works)
+            pass
     return torch.cuda.current_stream(index).cuda_stream
 
 
@@ -189,32 +192,6 @@ class Reader(BaseReader):
         self._impl.rows_to_device(
             rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, _current_stream(torch, index), accumulate, float(divisor))
         return out
-
-    def prepared_lookup(self, rows, out, col_off=0, accumulate=False, divisor=0.0):
-        '''The same lookup as rows_embedding_device(rows, out=out, ...), checked ONCE: returns a function of no arguments
-        that enqueues it on torch's current stream each time it is called -- for serving loops that refill the same `rows`
-        tensor and read the same `out` (a small batch is then the launch and little else: the checks of two tensors cost
-        as much as the kernel of a 1 000-row batch). The tensors must stay alive and in place while the function is used.'''
-        import torch
-        device = rows.device
-        if device.type != 'cuda' or rows.dtype not in (torch.int32, torch.uint32) or not rows.is_contiguous():
-            raise TypeError('rows must be a contiguous int32/uint32 tensor on the GPU')
-        n = rows.numel()
-        if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[0] != n:
-            raise TypeError('out must be a float32 (n, width) tensor with unit column stride')
-        index = device.index
-        if index != self._impl.device() or out.device != device:
-            raise ValueError('rows and out must be on cuda:{} (the device this reader is staged on), got {} and {}'.format(
-                self.device, device, out.device))
-        launch = self._impl.rows_to_device
-        arguments = (rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off)
-        tail = (bool(accumulate), float(divisor))
-        keep = (rows, out)
-
-        def call():
-            launch(*arguments, _current_stream(torch, index), *tail)
-            return keep[1]
-        return call
 
     def stage_words(self):
         '''Copy the model's keys to the GPU and build the hash table over them there (once; resolve_rows_device does it

@@ -42,13 +42,24 @@ def host_group(group=None, force_new=False):
     exchange step, so nothing of it may enter RCCL -- also when the job's default group is `nccl`.
     Creating the group is collective over the ranks of `group` only (`use_local_synchronization`; ranks
     outside a sub-group neither call nor wait): all of them must reach their first gather_rows call, or
-    call host_group(group) themselves at a point they all pass. Groups are remembered by their ranks.'''
+    call host_group(group) themselves at a point they all pass. Groups are remembered by their ranks and by the
+    default group they were made under: after destroy_process_group / init_process_group the remembered ones are of a
+    world that no longer exists and are dropped; a group replaced with force_new is destroyed (its sockets with it).'''
     import torch.distributed as dist
     if dist.get_backend(group) == 'gloo' and not force_new:
         return group
+    world = dist.group.WORLD
+    if _host_groups.get('world') is not world:
+        _host_groups.clear()
+        _host_groups['world'] = world
     ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else None
     key = ranks if ranks is not None and len(ranks) != dist.get_world_size() else None
-    if key not in _host_groups or force_new:
+    if force_new and key in _host_groups:
+        try:
+            dist.destroy_process_group(_host_groups.pop(key))
+        except Exception:   # (a group whose backend is already gone: nothing left to release)
+            pass
+    if key not in _host_groups:
         if key is None:
             _host_groups[key] = dist.new_group(backend='gloo')
         else:

@@ -89,7 +89,7 @@ def test_the_process_group_never_carries_data(native):
             text = open(os.path.join(REPO, 'memb_amd', name)).read()
             used = set(re.findall(r'\bdist\.([a-z_]+)\(', text))
             if name == 'sharding.py':
-                assert used <= {'get_backend', 'get_process_group_ranks', 'get_world_size', 'new_group', 'get_rank', 'get_global_rank', 'gather'}, used
+                assert used <= {'get_backend', 'get_process_group_ranks', 'get_world_size', 'new_group', 'destroy_process_group', 'get_rank', 'get_global_rank', 'gather'}, used
             else:
                 assert not used, (name, used)
 
@@ -124,6 +124,20 @@ def test_single_gpu_line_and_configuration_array(native, tmp_path):
     for entry in line['configs']:
         assert entry['parity'].startswith('bit-exact'), entry
         assert entry['kernel_ms'] > 0 and entry['algorithmic_bytes'] > 0
+    # round 5: full-size batches in random order beside the dumps; configs[1]'s own figure is the HBM-regime one, the
+    # cache-assisted one a sub-field; several batches in one launch; the word search on the device
+    assert sum('shuffled' in name for name in workloads) == 2, workloads
+    config1 = next(entry for entry in line['configs'] if 'configs[1]' in entry['workload'])
+    assert config1['frac_is'].startswith('HBM regime') and config1['repeated_buffer']['frac'] > 0
+    assert config1['batches_in_one_launch']['parity'].startswith('bit-exact'), config1['batches_in_one_launch']
+    assert config1['batches_in_one_launch']['batches'] == 4 and config1['batches_in_one_launch']['frac'] > 0
+    search = line['word_search']
+    assert len(search['batches']) == 3 and search['index']['word_index_keys'] == 50000
+    for entry in search['batches']:
+        assert entry['parity'].startswith('device == host search'), entry
+        assert entry['host_ms'] > 0 and entry['device_ms'] > 0
+    rank0 = line['per_rank'][0]
+    assert rank0['reader_open_s'] > 0 and rank0['device_bytes'] > rank0['word_index_bytes'] > 0   # the index is staged with the reader
 
 
 @gpu

@@ -721,32 +721,6 @@ def test_large_tables_take_two_tiles_per_wavefront_by_default(native, make_model
         assert bits_equal(reader.rows_embedding_device(ids).cpu().numpy(), checker.rows_embedding(rows)), count
 
 
-def test_prepared_lookup(native, make_model):
-    """Reader.prepared_lookup: the checks once, then a function that only launches -- same rows as the checked call,
-    refilled ids are picked up (the function keeps pointers, not values), bad arguments are refused when it is made."""
-    import torch
-    path, words = make_model(20000, 300, 'trained', 4)
-    reader = native.Reader(path, device=0)
-    checker = oracle.OracleReader(path)
-    rng = np.random.default_rng(41)
-    rows = rng.integers(0, len(words), size=1000).astype(np.uint32)
-    rows[::50] = 0xFFFFFFFF
-    ids = torch.from_numpy(rows.view(np.int32)).cuda()
-    out = torch.full((1000, 320), 5.0, dtype=torch.float32, device='cuda')
-    call = reader.prepared_lookup(ids, out, col_off=20)
-    for _ in range(3):
-        assert call() is out
-    assert bits_equal(out[:, 20:].cpu().numpy(), checker.rows_embedding(rows)) and bool((out[:, :20] == 5.0).all())
-    other = rng.integers(0, len(words), size=1000).astype(np.uint32)
-    ids.copy_(torch.from_numpy(other.view(np.int32)))
-    call()
-    assert bits_equal(out[:, 20:].cpu().numpy(), checker.rows_embedding(other))
-    with pytest.raises(TypeError):
-        reader.prepared_lookup(ids.cpu(), out)
-    with pytest.raises(TypeError):
-        reader.prepared_lookup(ids, out[:10])
-
-
 def test_batch_split_like_two_ranks(native, make_model):
     # the N > 1 split (memb_amd/sharding.py) through the HIP path, slices concatenated on the host
     from memb_amd.sharding import lookup_shard
@@ -1167,3 +1141,42 @@ def test_uniform_tile_kernel(native, make_model):
         assert bits_equal(accumulated.cpu().numpy(), (np.float32(0.5) + expected) / np.float32(2.0))
         assert bits_equal(reader.rows_embedding(rows), expected)   # host buffers
     reader.set_option('persistent', 1)
+
+
+@pytest.mark.parametrize('bits,dim', [(4, 300), (2, 300), (6, 300), (8, 300), (4, 128), (6, 100), (4, 52), (4, 1024), (4, 20)])
+def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim):
+    """Row-record models carry a second, finer segment index (about sixteen lanes per word; memb_hip.hip: stageIndex,
+    planTrained): batches of up to half a tile per 16 wavefronts per CU run decode_trained with it. Same rows as the
+    checker with the index forced on (2), off (1) and by rule (0), for batch sizes on both sides of a tile and of the
+    rule's edge, misses included. Reference: src/huffman_table_decoder.h:102-118 (the serial chain being split)."""
+    import torch
+    path, words = make_model(20000, dim, 'trained', bits)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    large, small = reader.info(), reader.info(1000)
+    assert small['kernel'].startswith('decode_trained<')
+    if dim >= 100:
+        # a finer index exists and small batches use it: more lanes per word, fewer symbols per lane
+        assert small['lanes_per_word'] > large['lanes_per_word'], (small, large)
+        assert small['segment_symbols'] < large['segment_symbols']
+    rng = np.random.default_rng(bits * 1000 + dim)
+    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    edge = resident * 62 // 100 * (64 // large['lanes_per_word'])     # words at the rule's edge (0.62 R tiles: 20 312 on 256 CUs)
+    for count in (1, 3, 4, 5, 64, 1000, edge - 1, edge, edge + 9, 3 * edge):
+        rows = rng.integers(0, len(words), size=count).astype(np.uint32)
+        rows[rng.integers(0, count, size=max(1, count // 20))] = 0xFFFFFFFF
+        expected = checker.rows_embedding(rows)
+        ids = torch.from_numpy(rows.view(np.int32)).cuda()
+        for fine in (2, 1, 0):
+            reader.set_option('fine_lanes', fine)
+            out = torch.full((count, dim), 5.0, dtype=torch.float32, device='cuda')
+            reader.rows_embedding_device(ids, out=out)
+            torch.cuda.synchronize()
+            assert bits_equal(out.cpu().numpy(), expected), (count, fine, reader.info(count)['lanes_per_word'])
+            by_rule = reader.info(count)['lanes_per_word']
+            if fine == 0 and dim >= 100:
+                assert by_rule == (small['lanes_per_word'] if count <= edge else large['lanes_per_word']), (count, by_rule)
+        # host buffers take the same path (centroid indices over PCIe for trained storages)
+        assert bits_equal(reader.rows_embedding(rows), expected), count
+    reader.set_option('fine_lanes', 0)
+    assert reader.host_rows_decoded == 0

@@ -22,20 +22,29 @@ def kernels():
 
 def test_no_kernel_holds_a_non_temporal_load(kernels):
     # round 3 made non-temporal stream loads a template argument and measured them for real (+28..48 % on 100 000
-    # rows); round 4 removed the variant -- no lookup kernel loads or stores non-temporally (the writer's quantise_rows
-    # does: it reads every staged vector exactly once)
+    # rows); round 4 removed the variant -- no lookup kernel loads or stores non-temporally, at ANY width (round 4's
+    # version of this test counted 16-byte loads only). One named exception: the block kernel of the uniform storage,
+    # dequant_uniform<true> (unaligned / very wide outputs; hip_rowwise_kernels.h), reads a row's bytes -- used once per
+    # lookup -- with non-temporal dword loads: 500 k random rows 0.167 against 0.178 ms, one per piece in flight.
+    # (The writer's quantise_rows does too: it reads every staged vector exactly once.)
     for name, facts in kernels.items():
-        if 'decode_' in name or 'dequant_' in name or 'gather_' in name:
-            assert facts['load_x4_nt'] == 0 and facts['store_x4_nt'] == 0, (name, facts)
+        if 'decode_' in name or 'dequant_' in name or 'gather_' in name or 'resolve_' in name:
+            if 'dequant_uniform<true>' in name:
+                assert facts['load_nt'] == 4 and facts['store_nt'] == 0, (name, facts)   # ROWWISE_BATCH loads in flight
+            else:
+                assert facts['load_nt'] == 0 and facts['store_nt'] == 0, (name, facts)
 
 
 def test_the_kernel_zoo_is_what_design_md_says(kernels):
     # which kernels exist at all. A single trained model runs decode_trained or, for two to
     # four tiles per 16 wavefronts per CU, decode_records_persistent; unions decode_union_split or decode_trained_union.
     families = {name.split('(anonymous namespace)::')[1].split('<')[0].split('(')[0] for name in kernels}
+    # round 5: decode_trained_batches (decode_trained's body over the tiles of several batches), and word -> row on the
+    # device: build_word_table at staging, resolve_words per batch
     assert families == {
-        'decode_trained', 'decode_records_persistent', 'decode_union_split', 'decode_trained_union',
+        'decode_trained', 'decode_trained_batches', 'decode_records_persistent', 'decode_union_split', 'decode_trained_union',
         'dequant_uniform', 'dequant_uniform_tile', 'gather_full',
+        'build_word_table', 'resolve_words',
         'repack_streams', 'pack_row_meta',
         'quantise_rows', 'stream_lengths', 'pack_streams'}, families
 

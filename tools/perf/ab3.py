@@ -36,7 +36,7 @@ run_in_ms = float(os.environ.get('AB3_RUN_IN_MS', '20'))
 cases = os.environ.get('AB3_CASES', 'sorted,random,100k').split(',')
 placement = int(os.environ.get('AB3_PLACEMENT', '0'))
 out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
-DEFAULTS = {'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': int(os.environ.get('MEMB_HIP_TILES_PER_WAVE', '0')), 'waves_per_block': 0,
+DEFAULTS = {'union_compact': int(os.environ.get('MEMB_HIP_UNION_COMPACT', '0')), 'fine_lanes': int(os.environ.get('MEMB_HIP_FINE_LANES', '0')), 'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': int(os.environ.get('MEMB_HIP_TILES_PER_WAVE', '0')), 'waves_per_block': 0,
             'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1'))}
 
 print('package: %s   model: %d words, %d-bit seed %s %s   rounds %d x %d launches after %.0f ms run-in' % (
@@ -50,7 +50,9 @@ generator = torch.Generator(device='cuda')
 generator.manual_seed(5)
 perm = torch.randperm(n, device='cuda', generator=generator).to(torch.int32)
 batches = {'100k': perm[:100000].contiguous(), '10k': perm[100000:110000].contiguous(), '1k': perm[110000:111000].contiguous(),
-           '500k': perm[200000:700000].contiguous(), '250k': perm[700000:950000].contiguous(), '50k': perm[950000:1000000].contiguous()}
+           '500k': perm[200000:700000].contiguous(), '250k': perm[700000:950000].contiguous(), '50k': perm[950000:1000000].contiguous(),
+           '5k': perm[1000000:1005000].contiguous(), '20k': perm[1010000:1030000].contiguous(), '30k': perm[1030000:1060000].contiguous(),
+           '16k': perm[1060000:1076384].contiguous(), '40k': perm[1080000:1120000].contiguous()}
 flush = torch.empty(1 << 28, dtype=torch.float32, device='cuda') if any(c.startswith('cold') for c in cases) else None
 
 

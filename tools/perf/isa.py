@@ -59,12 +59,17 @@ def kernel_table(extra_flags=()):
         meta = metadata.group(1) if metadata else ''
         loads = re.findall(r'^\s*global_load_dwordx4\s.*$', code, flags=re.M)
         stores = re.findall(r'^\s*global_store_dwordx4\s.*$', code, flags=re.M)
+        any_loads = re.findall(r'^\s*(?:global|flat|buffer)_load_\w+\s.*$', code, flags=re.M)
+        any_stores = re.findall(r'^\s*(?:global|flat|buffer)_store_\w+\s.*$', code, flags=re.M)
         table[pretty] = {
             'symbol': name,
             'load_x4': len(loads),
             'load_x4_nt': sum(1 for line in loads if re.search(r'\bnt\b', line)),
             'store_x4': len(stores),
             'store_x4_nt': sum(1 for line in stores if re.search(r'\bnt\b', line)),
+            # of EVERY width (round 4's test counted x4 loads only and missed a non-temporal dword load)
+            'load_nt': sum(1 for line in any_loads if re.search(r'\bnt\b', line)),
+            'store_nt': sum(1 for line in any_stores if re.search(r'\bnt\b', line)),
             'lds_dma': len(re.findall(r'^\s*(global|buffer)_load_lds_\w+', code, flags=re.M)) +
                        len(re.findall(r'^\s*buffer_load_\w+ .*\blds\b', code, flags=re.M)),
             'scratch_ops': len(re.findall(r'^\s*scratch_(load|store)_', code, flags=re.M)),

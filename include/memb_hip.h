@@ -186,6 +186,8 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *   "fine_lanes"      0 (default) = batches of at most 0.62 tiles per 16 wavefronts per CU (20 000 words on 256 CUs) of a
  *                     row-record model are decoded with its finer segment index (about sixteen lanes per word instead of
  *                     eight: the chain of dependent lookups of a batch too small to hide it is shorter), 1 = never, 2 = always
+ *   "union_compact"   1 (default) = decode_union_split decodes two nibble-key models through their 4-byte table entries
+ *                     (round 5: -2.5 % at 500 000 and 1 000 000 words), 0 = through the 8-byte ones
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
  *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)

@@ -89,6 +89,7 @@ __device__ __forceinline__ u32x4 loadPiece(const u32x4* source)
 // out of pinned memory anyway expand them (memb_hip.hip: expandKeyRows).
 enum OutputMode { OUT_SCALAR = 0, OUT_VEC4 = 1, OUT_FLAT = 2, OUT_INDEX = 3, OUT_KEYS = 4 };
 
+
 // Device form of one lookup-table entry (logical layout: memb::DecodeTable).
 //   x: leaf    -> code length                       (bits 8..31 zero)
 //      pointer -> TABLE_POINTER_FLAG | extra bits | first sub-table entry << 8
@@ -623,7 +624,10 @@ __device__ __forceinline__ TrainedParams batchOfTile(const TrainedParams& p, con
 template <bool HAS_SUB, int MODE, bool FAST, bool BATCHES>
 __device__ __forceinline__ void decodeTilesOfBlock(const TrainedParams& p, const BatchList& list, uint32_t* lds)
 {
-    constexpr bool PACKED = !FAST && MODE != OUT_INDEX;   // byte keys; the index pass keeps the 8-byte table
+    // byte keys: 4-byte table entries; the index pass keeps the 8-byte table. (Nibble keys through the 4-byte entries here
+    // as well -- round 5, batch 5, two builds alternating: 4-bit dumps -0.1..-0.2 %, shuffled +0.1 %, 100 000 cached rows
+    // -3 %, uncached +-0, 2-bit dump +0.9 %: not taken; decode_union_split, whose decode is NOT hidden, takes them.)
+    constexpr bool PACKED = !FAST && MODE != OUT_INDEX;
     uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
     // (Round 4, batch 4: giving every XCD one contiguous run of the batch instead of every eighth block: +3.2 % on the

@@ -120,7 +120,8 @@ struct Switches {
                                    // 0 = never, 1 = whenever the pair qualifies
     uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: tiles a wavefront of the one-tile kernels decodes one after the
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
-    uint32_t unionCompact = 0;     // MEMB_HIP_UNION_COMPACT: decode_union_split of two nibble-key models through their 4-byte tables
+    uint32_t unionCompact = 1;     // MEMB_HIP_UNION_COMPACT: decode_union_split of two nibble-key models through their 4-byte tables
+                                   // (6 KiB of LDS image per block instead of 8, one ds_read_b32 per symbol): 1 (default) / 0
     uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers

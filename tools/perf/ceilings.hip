@@ -288,6 +288,62 @@ __global__ void tile_experiment(Params p, int rowsPerTile, int delay, int order)
     }
 }
 
+// Round 5: wavefronts that STORE are not the ones that LOAD. A persistent block of W wavefronts, the
+// first `loaders` of which do nothing but fetch row records into an LDS double buffer while the others do nothing but
+// drain finished tiles with stores (the write-only persistent pattern, which is the fastest tile pattern some boxes
+// have), one block barrier per round: in round g the storers write the S = W - loaders tiles of round g out of buffer
+// g % 2 and the loaders fill buffer (g + 1) % 2 with the records of round g + 1's tiles, S / loaders tiles each, all of a
+// loader's loads in flight before the first is written to LDS. The stored values depend on the loaded bytes, as everywhere here.
+template <int MODE>   // 1 = sequential records, 2 = random records
+__global__ void tiles_specialised(Params p, uint32_t loaders)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
+    constexpr uint32_t MAX_TILES_PER_LOADER = 7;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t storers = blockDim.x / WAVE - loaders;
+    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
+    constexpr uint32_t SLOT = 4 * TILE_RECORD_PIECES;   // dwords of one tile's records
+    auto buffer = [&](unsigned long long round) { return dynamicLds + (round & 1) * storers * SLOT; };
+    auto firstTile = [&](unsigned long long round) { return (static_cast<unsigned long long>(blockIdx.x) + round * gridDim.x) * storers; };
+    auto loadRound = [&](unsigned long long round) {
+        u32x4 a[MAX_TILES_PER_LOADER], b[MAX_TILES_PER_LOADER];
+#pragma unroll
+        for (uint32_t i = 0; i < MAX_TILES_PER_LOADER; ++i) {
+            const uint32_t s = wave + i * loaders;
+            a[i] = u32x4{0, 0, 0, 0};
+            b[i] = u32x4{0, 0, 0, 0};
+            if (s < storers && firstTile(round) + s < tiles) {
+                loadTile<MODE == 2>(p, firstTile(round) + s, lane, a[i], b[i], p.records, p.ids);
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < MAX_TILES_PER_LOADER; ++i) {
+            const uint32_t s = wave + i * loaders;
+            if (s < storers) {
+                stageTile(buffer(round) + s * SLOT, lane, a[i], b[i]);
+            }
+        }
+    };
+    if (wave < loaders) {
+        loadRound(0);
+    }
+    __syncthreads();
+    for (unsigned long long round = 0; firstTile(round) < tiles; ++round) {
+        if (wave < loaders) {
+            if (firstTile(round + 1) < tiles) {
+                loadRound(round + 1);
+            }
+        } else {
+            const unsigned long long tile = firstTile(round) + (wave - loaders);
+            if (tile < tiles) {
+                storeTile<true>(p.out, p.words, tile, lane, buffer(round) + (wave - loaders) * SLOT);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // union: 4 words per tile, each 600 floats wide; records of the 4 words from both arrays (slots 0-3 / 4-7)
 __global__ void union_tile_per_wave(Params p)
 {
@@ -415,6 +471,36 @@ int memb_ceiling_tile_experiment(
         raised = true;
     }
     hipLaunchKernelGGL(tile_experiment, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, rowsPerTile, delay, order);
+    return static_cast<int>(hipGetLastError());
+}
+
+// tools/perf/r5/specialised.py: see tiles_specialised. wavesPerBlock 2 .. 16, 1 <= loaders < wavesPerBlock with at most seven
+// tiles per loader, wavesPerCu resident wavefronts per CU (the grid); ids null = consecutive rows.
+int memb_ceiling_specialised(
+    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int wavesPerBlock,
+    int loaders, int wavesPerCu, void* stream, int computeUnits)
+{
+    if (!out || !records || words == 0 || wavesPerBlock < 2 || wavesPerBlock > 16 || loaders < 1 || loaders >= wavesPerBlock ||
+        (wavesPerBlock - loaders + loaders - 1) / loaders > 7 || wavesPerCu < wavesPerBlock) {
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    Params p{};
+    p.out = out;
+    p.words = words;
+    p.records = static_cast<const u32x4*>(records);
+    p.rows = rows;
+    p.ids = ids;
+    const uint32_t storers = static_cast<uint32_t>(wavesPerBlock - loaders);
+    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
+    const unsigned long long rounds = (tiles + storers - 1) / storers;
+    const unsigned long long resident = static_cast<unsigned long long>(computeUnits) * (wavesPerCu / wavesPerBlock);
+    const uint32_t blocks = static_cast<uint32_t>(rounds < resident ? rounds : resident);
+    const uint32_t ldsBytes = 2 * storers * 4 * TILE_RECORD_PIECES * 4;
+    if (ids) {
+        hipLaunchKernelGGL(tiles_specialised<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, static_cast<uint32_t>(loaders));
+    } else {
+        hipLaunchKernelGGL(tiles_specialised<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, static_cast<uint32_t>(loaders));
+    }
     return static_cast<int>(hipGetLastError());
 }
 

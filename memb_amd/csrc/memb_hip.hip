@@ -270,38 +270,49 @@ uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t words
     return 4u * (ctx->tableDwords + codebookDwords(ctx) + waves * perWave);
 }
 
-// Waves per block: as many resident wavefronts per CU as LDS allows (the decode is a chain of dependent LDS
-// lookups, so occupancy is what hides it); on ties blocks of four wavefronts, then larger ones. `preferred`
-// (planTrained: eight for the dumps of nibble-key models) wins a tie instead; MEMB_HIP_WAVES / option
-// waves_per_block forces a size. registerWavesPerCu: how many wavefronts of the kernel about to be launched its
-// registers let a CU hold (32 when unknown): a block size whose LDS would allow more resident wavefronts than the
-// registers do gains nothing by it.
+// Wavefronts per block: the PREFERRED size (planTrained: eight for batches of more than 16 R tiles, else four), unless
+// another size lets a CU hold at least a quarter more resident wavefronts (LDS is handed out per block: the 8-bit model's
+// 33 KiB of tables leave 12 wavefronts per CU in blocks of four and 16 in blocks of eight, which is worth 10-17 %; the
+// 6-bit model's 28 against 32 is not worth leaving the preference: round 5, batch 7). Where the preferred size does not
+// fit: the size with the most resident wavefronts, in the order 4, 8, 2, 1. MEMB_HIP_WAVES / option waves_per_block forces a
+// size. registerWavesPerCu: how many wavefronts of the kernel about to be launched its registers let a CU hold (32 when
+// unknown): a block size whose LDS would allow more resident wavefronts than the registers do gains nothing by it.
 TrainedGeometry chooseGeometry(
     const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out,
     uint32_t registerWavesPerCu = 32, uint32_t preferred = 4)
 {
     TrainedGeometry best{};
-    double bestWaves = -1;
     const uint32_t forcedWaves = ctx->switches.waves;   // (1 .. 16; anything but 1, 2, 4, 8: measurements)
-    const uint32_t order[5] = {forcedWaves ? forcedWaves : preferred, 4u, 8u, 2u, 1u};
-    for (uint32_t waves : order) {
-        if (forcedWaves && waves != forcedWaves) {
-            continue;
-        }
-        uint32_t ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true);
-        if (ldsBytes > ctx->ldsLimit) {
-            continue;
+    auto residentWith = [&](uint32_t waves, uint32_t* ldsBytes) -> uint32_t {
+        *ldsBytes = trainedLdsBytes(ctx, waves, wordsPerWave, true);
+        if (*ldsBytes > ctx->ldsLimit) {
+            return 0;
         }
         // LDS is handed out in 1 KiB steps of a 160 KiB pool; at most 32 waves per CU, fewer when the kernel's
         // registers say so (512 per lane and SIMD, MI355X_MICROARCH.md "Register files")
-        uint32_t blocksPerCu = std::min<uint32_t>(
-            ctx->ldsLimit / ((ldsBytes + 1023) / 1024 * 1024), std::max<uint32_t>(1, std::min<uint32_t>(32, registerWavesPerCu) / waves));
-        double residentWaves = blocksPerCu * waves;
-        if (residentWaves > bestWaves) {
-            bestWaves = residentWaves;
+        const uint32_t blocksPerCu = std::min<uint32_t>(
+            ctx->ldsLimit / ((*ldsBytes + 1023) / 1024 * 1024), std::max<uint32_t>(1, std::min<uint32_t>(32, registerWavesPerCu) / waves));
+        return blocksPerCu * waves;
+    };
+    uint32_t preferredLds = 0;
+    const uint32_t wanted = forcedWaves ? forcedWaves : preferred;
+    const uint32_t preferredResident = residentWith(wanted, &preferredLds);
+    uint32_t bestResident = 0;
+    for (uint32_t waves : {4u, 8u, 2u, 1u}) {
+        if (forcedWaves) {
+            break;
+        }
+        uint32_t ldsBytes = 0;
+        const uint32_t resident = residentWith(waves, &ldsBytes);
+        if (resident > bestResident) {
+            bestResident = resident;
             best.waves = waves;
             best.ldsBytes = ldsBytes;
         }
+    }
+    if (preferredResident && (forcedWaves || 4 * bestResident < 5 * preferredResident)) {
+        best.waves = wanted;
+        best.ldsBytes = preferredLds;
     }
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -626,10 +637,12 @@ constexpr uint64_t FINE_TILES_PER_R_PERCENT = 62;   // the finer index up to 0.6
 //       100 000 rows -4.3..-6 % (4-bit), -8..-9 % (6-bit), -1.5 % (2-bit); at 500 k rows it is 3-11 % BEHIND.
 // The general persistent pipeline lost every dump (+2.3 % 4-bit, +4.9 % 2-bit; 6-bit -1.8 % on one box) and every
 // shuffled batch (+1.7..+9.4 %); with it went the per-context timing that chose between the two ("autotune").
-// Block size: four wavefronts; EIGHT for batches of more than 16 R tiles of nibble-key models -- dumps: the reference's
-// own large batch is keys() in key order (python/memb/reader.py:27-28) -- measured on two boxes: 4-bit key order
-// -3.7 / -4.1 %, 2-bit -6.2 %, Student-t like 4-bit; byte-key models +-0.6 % (6-bit) and -2.4 % / +3.5 % (9-bit code),
-// so they keep four. The price: full-size batches in SHUFFLED order +1.2..1.8 % (4-bit; 2-bit -2.1 %).
+// Block size: four wavefronts; EIGHT for batches of more than 16 R tiles (524 000 words on 256 CUs) -- dumps: the
+// reference's own large batch is keys() in key order (python/memb/reader.py:27-28). Round 5, batch 7 (one box, every model
+// kind, both orders; eight against four): key-order dumps 4-bit -2.4 %, 2-bit -5.0 %, 6-bit -1.0 %, 9-bit-code 4-bit
+// -1.1 %, Student-t -2.5 %; the same batches SHUFFLED +3.4 %, -1.3 %, +3.6 %, +3.5 %, +2.9 %; 1 M random rows +2.0 %, -1.5 %,
+// +2.5 %, +2.7 %, +2.1 %: the rule takes the dump's side for every key format and says what it costs the other order
+// (DESIGN.md section 5.0 has the table). The 8-bit model runs blocks of eight at every size: chooseGeometry.
 // force: -1 = by the rule, 0 = one tile per wavefront, 1 = decode_records_persistent where the layout allows
 int planTrained(
     const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1,
@@ -658,7 +671,7 @@ int planTrained(
         wantPersistent = force != 0;
     }
     plan->persistent = recordsFit && wantPersistent && !plan->fine;
-    const uint32_t preferred = !plan->persistent && ctx->fast && tiles > 16 * R ? 8u : 4u;
+    const uint32_t preferred = !plan->persistent && tiles > 16 * R ? 8u : 4u;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, 32, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;

@@ -62,12 +62,15 @@ def test_full_vocabulary_dump(native, full_model):
 
 
 def expected_kernel_class(tiles, resident):
-    """The kernel a dense batch of `tiles` tiles runs with default options (memb_hip.hip planTrained; DESIGN.md
-    section 5 "which kernel owns which configuration"): resident = 16 wavefronts per CU x CUs; blocks of four
-    wavefronts, eight for batches of more than 16 x resident tiles of a nibble-key model."""
+    """The kernel a dense batch of `tiles` tiles (of eight words) runs with default options (memb_hip.hip planTrained,
+    chooseGeometry; DESIGN.md section 5.0 "which kernel owns which configuration") for a row-record model of dim 300 whose
+    tables leave the block sizes about the same residency -- the 2-, 4- and 6-bit models, nibble or byte keys:
+    resident = 16 wavefronts per CU x CUs; decode_records_persistent for 2 R < tiles <= 4 R, else decode_trained in blocks
+    of four wavefronts, eight for batches of more than 16 R tiles; up to 0.62 R tiles with the finer index (more lanes per
+    word). Returns (kernel family, wavefronts per block or None where the rule does not pin them, finer index?)."""
     if 2 * resident < tiles <= 4 * resident:
-        return 'decode_records_persistent<', None
-    return 'decode_trained<', 8 if tiles > 16 * resident else 4
+        return 'decode_records_persistent<', None, False
+    return 'decode_trained<', 8 if tiles > 16 * resident else 4, tiles * 100 <= resident * 62
 
 
 def test_default_path_of_every_batch_size_class(native, full_model):
@@ -87,9 +90,10 @@ def test_default_path_of_every_batch_size_class(native, full_model):
     def check(rows, label):
         tiles = (len(rows) + words_per_tile - 1) // words_per_tile
         info = reader.info(len(rows))
-        family, waves = expected_kernel_class(tiles, resident)
+        family, waves, fine = expected_kernel_class(tiles, resident)
         assert info['kernel'].startswith(family), (label, len(rows), info['kernel'])
         assert waves is None or info['waves_per_block'] == waves, (label, len(rows), info['waves_per_block'])
+        assert (info['lanes_per_word'] > 64 // words_per_tile) == fine, (label, len(rows), info['lanes_per_word'])
         ids = torch.from_numpy(rows.view(np.int32)).cuda()
         out = torch.full((len(rows), 300), 7.0, dtype=torch.float32, device='cuda')
         reader.rows_embedding_device(ids, out=out)
@@ -107,6 +111,12 @@ def test_default_path_of_every_batch_size_class(native, full_model):
 
     rng = np.random.default_rng(12)
     seen = set()
+    fine_edge = resident * 62 // 100
+    for tiles in (fine_edge, fine_edge + 1):   # the finer index on one side, eight lanes per word on the other
+        batch = tiles * words_per_tile
+        rows = rng.integers(0, count, size=batch).astype(np.uint32)
+        rows[rng.integers(0, batch, size=batch // 100)] = 0xFFFFFFFF
+        check(rows, 'fine edge {}'.format(tiles))
     for multiple in (2, 4, 16):
         for delta in (-1, 0, 1):
             if multiple != 2 and delta == -1:
@@ -121,6 +131,39 @@ def test_default_path_of_every_batch_size_class(native, full_model):
             seen.add(check(rows, '{}R{:+d}'.format(multiple, delta)).split('<')[0])
     assert {'decode_trained', 'decode_records_persistent'} <= seen, seen
     assert reader.host_rows_decoded == 0
+
+
+@pytest.mark.parametrize('bits,words,seed', [(6, 1999995, 1234), (4, FULL_VOCAB, 99)])
+def test_block_size_rule_on_the_byte_key_models(native, bits, words, seed):
+    """The 6-bit model (BASELINE.json configs[2]) and the byte-key 4-bit one: kernel class, block size and lanes per word
+    by batch size as DESIGN.md section 5.0 states them (round 4's text said byte-key models keep blocks of four while the
+    6-bit dump ran eight), and rows on both sides of the 16 R edge against the checker (sampled)."""
+    import torch
+    from memb_amd import synthetic
+    os.environ.setdefault('MEMB_SYNTH_DEVICE', '0')
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', words))
+    path, _ = synthetic.cached_model(count, 300, 'trained', bits, seed=seed)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    assert reader.info()['kernel'].rstrip('>').split(',')[2].strip() == 'false'   # byte keys
+    words_per_tile = 64 // reader.info()['lanes_per_word']
+    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    rng = np.random.default_rng(bits)
+    for tiles in (1, resident * 62 // 100, resident * 62 // 100 + 1, 2 * resident, 2 * resident + 1, 4 * resident, 4 * resident + 1,
+                  16 * resident, 16 * resident + 1, (count + words_per_tile - 1) // words_per_tile):
+        batch = min(tiles * words_per_tile, 4 * count)
+        info = reader.info(batch)
+        family, waves, fine = expected_kernel_class((batch + words_per_tile - 1) // words_per_tile, resident)
+        assert info['kernel'].startswith(family), (tiles, info['kernel'])
+        assert waves is None or info['waves_per_block'] == waves, (tiles, info['waves_per_block'])
+        assert (info['lanes_per_word'] > 64 // words_per_tile) == fine, (tiles, info['lanes_per_word'])
+        if tiles in (16 * resident, 16 * resident + 1, 1):
+            rows = rng.integers(0, count, size=batch).astype(np.uint32)
+            rows[rng.integers(0, batch, size=max(1, batch // 100))] = 0xFFFFFFFF
+            out = reader.rows_embedding_device(torch.from_numpy(rows.view(np.int32)).cuda())
+            picks = np.sort(rng.choice(batch, size=min(batch, 20000), replace=False))
+            got = out[torch.from_numpy(picks).cuda()].cpu().numpy()
+            assert bits_equal(got, checker.rows_embedding(np.ascontiguousarray(rows[picks]))), tiles
 
 
 def test_full_dump_of_a_byte_key_4bit_model(native):

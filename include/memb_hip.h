@@ -344,6 +344,15 @@ int memb_hip_resolve_rows_device(memb_hip_ctx* ctx, const memb_hip_words* batch,
 int memb_hip_resolve_range_device(
     memb_hip_ctx* ctx, const memb_hip_words* batch, size_t first_word, size_t n_words, uint32_t* rows_dev, void* stream);
 /*
+ * Words in, host rows out -- the reference's own calling convention (Reader::batchEmbeddingToBuffer, src/reader.cpp:59-86)
+ * with both of its halves on the device: the words of a committed batch are looked up by resolve_words and decoded as
+ * memb_hip_decode_rows decodes row ids (same staging, same host threads; the row ids come back over PCIe once, 4 bytes per
+ * word, for the threads that zero the rows of unknown words). The context's keys must be staged. Synchronous. Returns
+ * MEMB_HIP_UNSUPPORTED for a batch so large that the result is staged in slices (4 GiB of fp32 rows and more).
+ */
+int memb_hip_decode_words(memb_hip_ctx* ctx, const memb_hip_words* batch, float* out, size_t ld, size_t col_off);
+
+/*
  * The same lookup for callers whose words are on the device already: word i = bytes_dev[offsets_dev[i] ..
  * offsets_dev[i + 1]) (n + 1 offsets, ascending; no NUL inside a word).
  */

@@ -266,6 +266,30 @@ struct WordFiller {
     }
 };
 
+// batch_embedding / batch_embedding_into: a list of str -> rows in host memory. From a few thousand words on (and when no
+// other call of this Reader holds its word batch) the str objects are written straight into the reader's pinned word
+// batch by pooled threads and BOTH the word search and the decode run on the device (memb_hip_decode_words); otherwise the
+// host search on UTF-8 pointers, as before. The GIL is held while the str objects are read, released for the device work.
+void wordsToHostRows(memb::Reader& reader, const py::sequence& wordList, size_t count, float* destination, size_t ld, size_t colOff)
+{
+    memb::Reader::WordBatchLease lease = reader.leaseWordBatch(count);
+    if (lease.batch) {
+        WordFiller::fill(*lease.batch, wordList, [](size_t, size_t) {});
+        bool done;
+        {
+            py::gil_scoped_release release;
+            done = reader.leasedWordsToBuffer(lease, destination, ld, colOff);
+        }
+        if (done) {
+            return;
+        }
+    }
+    lease = memb::Reader::WordBatchLease();
+    WordPointers words(wordList);
+    py::gil_scoped_release release;
+    reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, ld, colOff);
+}
+
 py::dict contextInfo(memb::Reader& reader, uint64_t batchWords)
 {
     if (reader.device() == memb::CompressedStorage::HOST_DEVICE) {
@@ -424,15 +448,12 @@ PYBIND11_MODULE(_memb, m) {
             "batch_embedding",
             [](memb::Reader& reader, const py::sequence& wordList)
             {
-                WordPointers words(wordList);
-                py::array_t<float> result({words.size(), reader.dim()});
+                const size_t count = static_cast<size_t>(py::len(wordList));
+                py::array_t<float> result({count, reader.dim()});
                 auto buffer = result.request();
                 float* destination = reinterpret_cast<float*>(buffer.ptr);
-                adviseHugePages(destination, words.size() * reader.dim() * sizeof(float));
-                {
-                    py::gil_scoped_release release;
-                    reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), destination, reader.dim(), 0);
-                }
+                adviseHugePages(destination, count * reader.dim() * sizeof(float));
+                wordsToHostRows(reader, wordList, count, destination, reader.dim(), 0);
                 return result;
             })
         .def("keys", [](memb::Reader& reader) { return reader.keys(); })
@@ -522,13 +543,12 @@ PYBIND11_MODULE(_memb, m) {
                const py::array& out,
                size_t colOff)
             {
-                WordPointers words(wordList);
+                const size_t count = static_cast<size_t>(py::len(wordList));
                 const OutputMatrix matrix = outputMatrix(out);
-                if (matrix.rows != words.size() || matrix.columns < colOff + reader.dim()) {
+                if (matrix.rows != count || matrix.columns < colOff + reader.dim()) {
                     throw std::runtime_error("Output must be a (len(words), >= col_off + dim) float32 matrix");
                 }
-                py::gil_scoped_release release;
-                reader.batchEmbeddingToStridedBuffer(words.data(), words.size(), matrix.data, matrix.ld, colOff);
+                wordsToHostRows(reader, wordList, count, matrix.data, matrix.ld, colOff);
             })
         .def(
             "rows_embedding",

@@ -200,6 +200,19 @@ void CompressedStorage::resolveRangeDevice(
     }
 }
 
+bool CompressedStorage::decodeWords(const memb_hip_words* batch, float* out, size_t ld, size_t colOff) const
+{
+    stageWords();
+    const int code = memb_hip_decode_words(deviceContext(), batch, out, ld, colOff);
+    if (code == MEMB_HIP_UNSUPPORTED) {
+        return false;
+    }
+    if (code != MEMB_HIP_OK) {
+        throwDeviceError("HIP batch lookup failed");
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // Hash index over the keys: open addressing, 64-bit slots {hash tag : 32, row : 32},
 // FNV-1a over the word's bytes; a hit is confirmed with strcmp, so the answer is

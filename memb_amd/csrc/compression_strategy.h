@@ -81,6 +81,9 @@ public:
     void stageWords() const;
     void resolveRowsDevice(const memb_hip_words* batch, uint32_t* rowsDevice, void* stream) const;
     void resolveRangeDevice(const memb_hip_words* batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const;
+    // Words in, host rows out, both halves on the device (memb_hip_decode_words): false when the batch is too large for
+    // one staging slice (the caller then looks the words up on the host and passes row ids).
+    bool decodeWords(const memb_hip_words* batch, float* out, size_t ld, size_t colOff) const;
 
 protected:
     virtual memb_hip_ctx* createDeviceContext(int device) const = 0;

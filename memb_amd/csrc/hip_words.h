@@ -425,6 +425,31 @@ int resolve_rows_device_checked(memb_hip_ctx* ctx, const memb_hip_words* batch, 
     return resolve_range_device_checked(ctx, batch, 0, batch->count, rows, stream);
 }
 
+// for decode_rows_checked (memb_hip.hip), which sits above this header: the context's mutex is held, its device current
+int resolveBatchOnContextStream(memb_hip_ctx* ctx, const memb_hip_words* batch, uint32_t* rowsDevice)
+{
+    if (!batch->committed) {
+        return fail(MEMB_HIP_ERR_INVALID, "the word batch is not committed");
+    }
+    if (batch->device != ctx->device) {
+        return fail(MEMB_HIP_ERR_INVALID, "the word batch lives on another device than the context");
+    }
+    const int code = launchResolve(
+        ctx, batch->deviceBytes, uint64_t(batch->plan.jobs) * batch->plan.job_bytes, batch->deviceOffsets, batch->jobShift, 0,
+        batch->count, rowsDevice, ctx->stream);
+    if (code == MEMB_HIP_OK && batch->count) {
+        memb_hip_words* mutableBatch = const_cast<memb_hip_words*>(batch);
+        HIP_TRY(hipEventRecord(mutableBatch->lastUse, ctx->stream));
+        mutableBatch->inUse = true;
+    }
+    return code;
+}
+
+size_t wordBatchCount(const memb_hip_words* batch)
+{
+    return batch->committed ? batch->count : 0;
+}
+
 int resolve_packed_device_checked(
     memb_hip_ctx* ctx, const uint8_t* bytes, const uint32_t* offsets, size_t n, uint32_t* rows, hipStream_t stream)
 {

@@ -197,6 +197,8 @@ struct memb_hip_ctx {
     size_t stagedCapacity = 0;    // words
     size_t stagedRowBytes = 0;
     std::vector<float> hostCodebook;   // the device codebook's host copy (256 centroids or 256 pairs)
+    uint32_t* hostRowsPinned = nullptr;   // memb_hip_decode_words: the row ids the device looked up, for the host threads
+    size_t hostRowsCapacity = 0;
     // small batches: pinned host memory the kernel reads row ids from and writes rows to directly
     void* smallHost = nullptr;
     void* smallDevice = nullptr;
@@ -1425,6 +1427,9 @@ void destroy(memb_hip_ctx* ctx)
     if (ctx->smallHost) {
         (void)hipHostFree(ctx->smallHost);
     }
+    if (ctx->hostRowsPinned) {
+        (void)hipHostFree(ctx->hostRowsPinned);
+    }
     for (int i = 0; i < memb_hip_ctx::RING; ++i) {
         if (ctx->ring[i]) {
             (void)hipHostFree(ctx->ring[i]);
@@ -2240,10 +2245,19 @@ int decode_batches_device_checked(memb_hip_ctx* ctx, const memb_hip_batch* batch
     return MEMB_HIP_OK;
 }
 
+// (hip_words.h, included below: the lookup of a committed word batch into device memory, enqueued on the context's stream)
+int resolveBatchOnContextStream(memb_hip_ctx* ctx, const memb_hip_words* batch, uint32_t* rowsDevice);
+size_t wordBatchCount(const memb_hip_words* batch);
+
+// memb_hip_decode_rows (host row ids in `rows`) and memb_hip_decode_words (`batch`: the row ids are looked up on the
+// device and fetched into pinned memory for the host threads that zero the rows of unknown words).
 int decode_rows_checked(
-    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
+    memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, const memb_hip_words* batch = nullptr)
 {
-    if (!ctx || (n && (!rows || !out))) {
+    if (batch) {
+        n = wordBatchCount(batch);
+    }
+    if (!ctx || (n && ((!rows && !batch) || !out))) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
     if (ld < col_off + ctx->dim) {
@@ -2264,7 +2278,7 @@ int decode_rows_checked(
     const size_t rowBytes = size_t(ctx->dim) * sizeof(float);
     // (at most 2 MiB of rows that way: very wide rows leave the small path after fewer words)
     const size_t smallWords = std::min<size_t>(SMALL_WORDS, (size_t(2) << 20) / rowBytes);
-    if (n <= smallWords && !ctx->smallUnavailable) {
+    if (n <= smallWords && !ctx->smallUnavailable && !batch) {
         // row ids first, rows from the next 256-byte boundary
         constexpr size_t outOffset = (SMALL_WORDS * sizeof(uint32_t) + 255) / 256 * 256;
         if (!ctx->smallHost) {
@@ -2307,6 +2321,20 @@ int decode_rows_checked(
     const size_t stagedRowBytes = asKeys ? keyRowBytes(ctx) : dim * sizeof(float);
     const size_t sliceLimit = std::min<size_t>((size_t(4) << 30) / (dim * sizeof(float)), ctx->switches.sliceWords);
     const size_t sliceWords = std::max<size_t>(1, std::min<size_t>(n, sliceLimit));
+    if (batch && sliceWords < n) {
+        return fail(MEMB_HIP_UNSUPPORTED, "a word batch of this size is decoded in slices: look the words up first and pass row ids");
+    }
+    if (batch && ctx->hostRowsCapacity < n) {
+        if (ctx->hostRowsPinned) {
+            (void)hipHostFree(ctx->hostRowsPinned);
+            ctx->hostRowsPinned = nullptr;
+            ctx->hostRowsCapacity = 0;
+        }
+        void* pinned = nullptr;
+        HIP_TRY(hipHostMalloc(&pinned, (n + n / 4) * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->hostRowsPinned = static_cast<uint32_t*>(pinned);
+        ctx->hostRowsCapacity = n + n / 4;
+    }
     if (ctx->stagedCapacity < sliceWords || ctx->stagedRowBytes < stagedRowBytes) {
         if (ctx->stagedRows) {
             (void)hipFree(ctx->stagedRows);
@@ -2328,8 +2356,20 @@ int decode_rows_checked(
     int result = MEMB_HIP_OK;
     for (size_t start = 0; start < n && result == MEMB_HIP_OK; start += sliceWords) {
         const size_t words = std::min(sliceWords, n - start);
-        hipError_t status = hipMemcpyAsync(
-            ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        hipError_t status;
+        if (batch) {
+            // word -> row on the device, straight into the staging array; the ids also go to pinned host memory, for the
+            // threads that expand the result (an unknown word's row is zeroed there). Every copy of result chunks is
+            // enqueued behind this one, so the ids have landed when the first chunk's event fires.
+            result = resolveBatchOnContextStream(ctx, batch, ctx->stagedRows);
+            if (result != MEMB_HIP_OK) {
+                break;
+            }
+            status = hipMemcpyAsync(ctx->hostRowsPinned, ctx->stagedRows, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            rows = ctx->hostRowsPinned;
+        } else {
+            status = hipMemcpyAsync(ctx->stagedRows, rows + start, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        }
         if (status != hipSuccess) {
             result = fail(MEMB_HIP_ERR_DEVICE, std::string("row id copy: ") + hipGetErrorString(status));
             break;
@@ -2554,6 +2594,16 @@ int memb_hip_decode_batches_device(memb_hip_ctx* ctx, const memb_hip_batch* batc
 int memb_hip_decode_rows(memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off)
 {
     return guarded([&] { return decode_rows_checked(ctx, rows, n, out, ld, col_off); });
+}
+
+int memb_hip_decode_words(memb_hip_ctx* ctx, const memb_hip_words* batch, float* out, size_t ld, size_t col_off)
+{
+    return guarded([&] {
+        if (!ctx || !batch) {
+            return fail(MEMB_HIP_ERR_INVALID, "null argument");
+        }
+        return decode_rows_checked(ctx, nullptr, 0, out, ld, col_off, batch);
+    });
 }
 
 int memb_hip_decode_rows_union_device(

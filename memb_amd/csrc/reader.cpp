@@ -258,6 +258,9 @@ void Reader::wordEmbeddingToBuffer(const std::string& word, float* buffer) const
 namespace {
 
 const size_t MIN_JOB_SIZE = 1024;
+// Host-buffer batches from here on are searched on the device (round 5: 10 000 words 0.07 against 0.28 ms, 100 000
+// words 0.14 against 0.9 ms, 2.2 M words 1.1 against 11 ms; at 1 000 words the host's hash index is the faster one)
+const size_t DEVICE_SEARCH_THRESHOLD = 4096;
 const size_t INDEX_THRESHOLD = 4096;      // smaller batches do not pay for building the hash index
 const size_t MAX_POOL_THREADS = 64;
 const size_t OVERLAP_THRESHOLD = 262144;  // batches from here on search and decode at the same time
@@ -321,11 +324,44 @@ void Reader::resolveRows(const std::vector<std::string>& words, uint32_t* rows) 
     resolveRows(pointers.data(), pointers.size(), rows);
 }
 
+Reader::WordBatchLease Reader::leaseWordBatch(size_t count) const
+{
+    WordBatchLease lease;
+    if (compressedStorage_->onHost() || count < DEVICE_SEARCH_THRESHOLD || count <= compressedStorage_->hostBelow()) {
+        return lease;
+    }
+    lease.lock = std::unique_lock<std::mutex>(wordBatchMutex_, std::try_to_lock);
+    if (!lease.lock.owns_lock()) {
+        return lease;
+    }
+    if (!wordBatch_ || wordBatch_->device() != compressedStorage_->device()) {
+        wordBatch_.reset(new WordBatch(compressedStorage_->device()));
+    }
+    lease.batch = wordBatch_.get();
+    return lease;
+}
+
+bool Reader::leasedWordsToBuffer(const WordBatchLease& lease, float* buffer, size_t ld, size_t colOff) const
+{
+    return compressedStorage_->decodeWords(lease.batch->handle(), buffer, ld, colOff);
+}
+
 void Reader::batchEmbeddingToStridedBuffer(
     const char* const* words, size_t count, float* buffer, size_t ld, size_t colOff) const
 {
     if (count == 0) {
         return;
+    }
+    {
+        // word search AND decode on the device: the words are packed into pinned memory by pooled threads
+        // (memb_hip_words_pack), looked up by resolve_words and decoded from the row ids that leaves in HBM
+        WordBatchLease lease = leaseWordBatch(count);
+        if (lease.batch) {
+            lease.batch->pack(words, nullptr, count);
+            if (leasedWordsToBuffer(lease, buffer, ld, colOff)) {
+                return;
+            }
+        }
     }
     std::vector<uint32_t> rows(count);
     if (count >= OVERLAP_THRESHOLD && numThreads_ > 2) {

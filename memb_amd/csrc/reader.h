@@ -112,6 +112,18 @@ public:
     memb_hip_ctx* deviceContext() const;
     bool hasWordIndex() const;   // whether lookups go through the hash index by now
 
+    // The Reader's own word batch, for host-buffer lookups that search on the device (batchEmbeddingToBuffer from
+    // DEVICE_SEARCH_THRESHOLD words on): held by one call at a time. `batch` is null when the reader decodes on the host
+    // or another call holds the batch -- that caller then searches on the host, as before.
+    struct WordBatchLease {
+        std::unique_lock<std::mutex> lock;
+        WordBatch* batch = nullptr;
+    };
+    WordBatchLease leaseWordBatch(size_t count) const;
+    // Rows of a filled (committed) lease into buffer[i * ld + colOff ..]; false: too large for the device path, the
+    // caller falls back to resolveRows + rowsToBuffer.
+    bool leasedWordsToBuffer(const WordBatchLease& lease, float* buffer, size_t ld, size_t colOff) const;
+
     // Word -> row on the device (reference src/trained_compression.cpp:115-125): the keys and a hash
     // table over them are staged with the first call (or by stageWords), a batch is resolved by one kernel enqueued
     // on `stream`, and rowsDevice[i] (device memory, batch.size() entries) = the row resolveRows would give. The row
@@ -139,6 +151,8 @@ private:
     mutable std::atomic<size_t> wordsResolved_{0};
     mutable std::mutex poolMutex_;
     mutable std::unique_ptr<WorkerPool> pool_;
+    mutable std::mutex wordBatchMutex_;
+    mutable std::unique_ptr<WordBatch> wordBatch_;
     MappedFile mappedFile_;
     wire::TableView flatIndex_;
     size_t dim_ = 0;

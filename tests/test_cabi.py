@@ -28,7 +28,7 @@ def test_header_declares_the_expected_entry_points():
         'memb_hip_ctx_stage_words', 'memb_hip_words_create', 'memb_hip_words_destroy', 'memb_hip_words_pack',
         'memb_hip_words_begin', 'memb_hip_words_commit', 'memb_hip_words_count', 'memb_hip_resolve_rows_device',
         'memb_hip_resolve_range_device', 'memb_hip_resolve_packed_device',
-        'memb_hip_decode_batches_device',
+        'memb_hip_decode_batches_device', 'memb_hip_decode_words',
     ])
 
 
@@ -79,6 +79,7 @@ def test_error_reporting_without_compute(native):
     assert library.memb_hip_resolve_range_device(None, None, ctypes.c_size_t(0), ctypes.c_size_t(0), None, None) == 1
     assert library.memb_hip_resolve_packed_device(None, None, None, ctypes.c_size_t(0), None, None) == 1
     assert library.memb_hip_decode_batches_device(None, None, ctypes.c_size_t(0), None) == 1
+    assert library.memb_hip_decode_words(None, None, None, ctypes.c_size_t(0), ctypes.c_size_t(0)) == 1
     if count.value == 0:
         batch = ctypes.c_void_p()
         assert library.memb_hip_words_create(ctypes.byref(batch), 0) == 2 and not batch.value   # ERR_DEVICE

@@ -76,6 +76,15 @@ def test_tricky_words_on_every_storage(native, tricky_models, storage):
     # the rows feed the decode without a host round trip
     assert bits_equal(reader.batch_embedding_device(queries).cpu().numpy(), checker.batch_embedding(
         [q.split('\x00')[0] for q in queries]))
+    # the reference's own API -- words in, numpy out -- searches on the device too from 4096 words on
+    many = queries * (4096 // len(queries) + 2)
+    assert len(many) >= 4096
+    expected_many = checker.batch_embedding([q.split('\x00')[0] for q in many])
+    assert bits_equal(reader[many], expected_many)
+    wide = np.full((len(many), 50), 3.0, dtype=np.float32)
+    reader.batch_embedding_into(many, wide, 30)
+    assert bits_equal(wide[:, 30:], expected_many) and (wide[:, :30] == 3.0).all()
+    assert reader.host_rows_decoded == 0
     # edge sizes: nothing, one word, one wavefront +- 1, one block +- 1
     for count in (0, 1, 63, 64, 65, 255, 256, 257):
         part = queries[:count]
@@ -278,6 +287,19 @@ def test_word_search_through_the_c_abi(native):
         assert packed_device(context, holder.data_ptr() + shift, device_offsets.data_ptr(), len(words), out.data_ptr(), None) == 0
         torch.cuda.synchronize()
         assert out.cpu().numpy().view(np.uint32).tolist() == expected, shift
+
+    # words in, host rows out (memb_hip_decode_words): the same rows as memb_hip_decode_rows gives for the looked-up ids
+    decode_words = library.memb_hip_decode_words
+    decode_words.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    decode_rows = library.memb_hip_decode_rows
+    decode_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    from_words = np.full((len(many), 6), 9.0, dtype=np.float32)
+    assert decode_words(context, batch, from_words.ctypes.data, 6, 1) == 0, library.memb_hip_last_error()
+    from_rows = np.full((len(many), 6), 9.0, dtype=np.float32)
+    assert decode_rows(context, want.ctypes.data, len(many), from_rows.ctypes.data, 6, 1) == 0, library.memb_hip_last_error()
+    assert np.array_equal(from_words.view(np.uint32), from_rows.view(np.uint32))
+    assert not from_words[want == MISSING, 1:5].any() and (from_words[:, 0] == 9.0).all() and (from_words[:, 5] == 9.0).all()
+    assert decode_words(context, batch, from_words.ctypes.data, 3, 0) == 1   # ld < dim
 
     class Info(ctypes.Structure):
         _fields_ = [('struct_size', ctypes.c_uint32), ('device', ctypes.c_int32), ('storage', ctypes.c_uint32),

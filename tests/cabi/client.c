@@ -88,6 +88,32 @@ int main(void)
         }
         printf("info: kernel %s, union_kernel '%s'\n", whole.info.kernel, whole.info.union_kernel);
     }
+    {
+        /* word -> row on the device and words in / host rows out, as a C caller binds them: the two rows get keys,
+           five C strings are packed, looked up and decoded in one call */
+        static const char keys_packed[] = "alpha\0beta";        /* row 0 = "alpha", row 1 = "beta"; sizeof counts the final NUL */
+        const uint32_t key_offsets[2] = {0, 6};
+        const char* queries[5] = {"beta", "gamma", "alpha", "", "beta"};
+        memb_hip_words* batch = NULL;
+        size_t count = 0;
+        float rows_out[5][4];
+        if (memb_hip_ctx_stage_words(ctx, keys_packed, sizeof keys_packed, key_offsets, 2) != MEMB_HIP_OK ||
+            memb_hip_words_create(&batch, 0) != MEMB_HIP_OK ||
+            memb_hip_words_pack(batch, queries, NULL, 5) != MEMB_HIP_OK ||
+            memb_hip_words_count(batch, &count) != MEMB_HIP_OK || count != 5 ||
+            memb_hip_decode_words(ctx, batch, &rows_out[0][0], 4, 0) != MEMB_HIP_OK) {
+            printf("word search failed: %s\n", memb_hip_last_error());
+            return 8;
+        }
+        for (i = 0; i < 5; ++i) {
+            printf("words:");
+            for (j = 0; j < 4; ++j) {
+                printf(" %g", rows_out[i][j]);
+            }
+            printf("\n");
+        }
+        memb_hip_words_destroy(batch);
+    }
     memb_hip_ctx_destroy(ctx);
     return 0;
 }

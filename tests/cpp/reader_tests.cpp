@@ -118,6 +118,30 @@ void threadedEqualsSerial()
     }
 }
 
+// Beyond the reference's cases: a batch large enough for the word search to run on the device (memb::Reader searches
+// host batches of 4096 words and more with resolve_words, include/memb_hip.h: memb_hip_decode_words; on a host reader
+// the batch takes the reference's threaded path) equals the same words looked up one at a time, misses included, for
+// every storage.
+void largeBatchEqualsSingleWords(memb::wire::Storage storage, const char* name)
+{
+    std::printf("a 5000-word batch equals single words (%s)\n", name);
+    writeModel(storage);
+    memb::Reader reader(MODEL_FILE, 4);
+    std::vector<std::string> batch;
+    for (size_t i = 0; i < 5000; ++i) {
+        batch.push_back(i % 7 == 3 ? std::string("o") : SAMPLES[i % SAMPLES.size()].word);   // "o": the reference's missing word
+    }
+    batch[11] = "";
+    batch[12] = std::string("the\0suffix", 10);   // a std::string ends at its first NUL for strcmp: "the"
+    const std::vector<float> rows = reader.batchEmbedding(batch);
+    CHECK(rows.size() == 5000 * 3);
+    for (size_t i = 0; i < 5000 && rows.size() == 5000 * 3; i += (i < 20 ? 1 : 53)) {
+        const std::vector<float> alone = reader.wordEmbedding(batch[i].c_str());
+        CHECK(std::memcmp(alone.data(), rows.data() + 3 * i, 3 * sizeof(float)) == 0);
+    }
+    CHECK(rows.size() == 5000 * 3 && rows[3 * 3] == 0.f && rows[3 * 3 + 1] == 0.f && rows[3 * 3 + 2] == 0.f);   // "o" -> zeros
+}
+
 // reference src/tests.cpp:115-153; none of these needs a device
 void refusals()
 {
@@ -240,6 +264,9 @@ int main(int argc, char** argv)
             roundTrip("trained storage, first-level table of 1 bit", memb::wire::Storage_Trained,
                       std::make_shared<memb::TrainedCompressionStrategy>(1));
             threadedEqualsSerial();
+            largeBatchEqualsSingleWords(memb::wire::Storage_Trained, "trained");
+            largeBatchEqualsSingleWords(memb::wire::Storage_Uniform, "uniform");
+            largeBatchEqualsSingleWords(memb::wire::Storage_Full, "full");
         }
     } catch (const std::exception& error) {
         std::printf("  FAILED with exception: %s\n", error.what());

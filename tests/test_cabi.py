@@ -127,6 +127,9 @@ def test_pure_c_client(native, tmp_path):
         '9 2.25 2.25 -1.5 -1.5 9',
     ], run.stdout
     assert lines[4] == 'error: ld must be at least col_off + dim'
+    # round 5: five C strings through stage_words / words_pack / decode_words: beta, (unknown), alpha, (empty), beta
+    assert [line for line in lines if line.startswith('words:')] == [
+        'words: 2.25 2.25 -1.5 -1.5', 'words: 0 0 0 0', 'words: -1.5 2.25 -1.5 2.25', 'words: 0 0 0 0', 'words: 2.25 2.25 -1.5 -1.5'], run.stdout
 
 
 def test_malformed_trained_descriptions_are_refused_before_any_device_work(native):

@@ -90,7 +90,9 @@ int growPinned(T** buffer, const T** deviceView, size_t* capacity, size_t wanted
     }
     const size_t entries = std::max(wanted + wanted / 4, size_t(4096));   // (a quarter of headroom: batches of one loop vary a little)
     void* raw = nullptr;
-    HIP_TRY(hipHostMalloc(&raw, entries * sizeof(T), hipHostMallocMapped | hipHostMallocPortable));
+    // (coherent: host threads write a batch, the kernel of the next launch reads it over PCIe -- nothing of it may sit in a
+    // device cache from the batch before)
+    HIP_TRY(hipHostMalloc(&raw, entries * sizeof(T), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
     void* device = nullptr;
     hipError_t status = hipHostGetDevicePointer(&device, raw, 0);
     if (status != hipSuccess) {

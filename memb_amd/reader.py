@@ -206,6 +206,8 @@ class Reader(BaseReader):
         out : optional contiguous int32 / uint32 tensor of len(words) entries on this reader's device'''
         import torch
         index = self._impl.device()
+        if index == _memb.HOST_DEVICE:
+            raise RuntimeError("this reader decodes on the host (device 'cpu'): the device word search needs a reader on a HIP device")
         n = len(words)
         if out is None:
             out = torch.empty((n,), dtype=torch.int32, device='cuda:{}'.format(index))
@@ -229,6 +231,8 @@ class Reader(BaseReader):
         prologue and tail are paid once. Returns the list of `out` tensors.'''
         import torch
         index = self._impl.device()
+        if index == _memb.HOST_DEVICE:
+            raise RuntimeError("this reader decodes on the host (device 'cpu'): device buffers need a reader on a HIP device")
         descriptors = []
         outs = []
         for entry in batches:

@@ -113,6 +113,17 @@ def test_host_below_keeps_small_host_batches_on_the_host(native, monkeypatch):
     if native.hip_device_count() == 0:
         with pytest.raises(RuntimeError, match='no HIP device available'):   # 9 words: the device's, and there is none
             reader[keys[:9]]
+        with pytest.raises(RuntimeError, match='no HIP device available'):   # 5000 words: searched on the device too
+            reader[[keys[i % len(keys)] for i in range(5000)]]
+    # the device word search and device buffers are not for readers that decode on the host, and say so
+    host = native.Reader(path, device='cpu')
+    with pytest.raises(RuntimeError, match="decodes on the host"):
+        host.resolve_rows_device(keys[:3])
+    with pytest.raises(RuntimeError, match="decodes on the host"):
+        host.rows_embedding_device_many([])
+    with pytest.raises(RuntimeError, match="decodes on the host"):
+        host.stage_words()
+    assert bits_equal(host[[keys[i % len(keys)] for i in range(5000)]], checker.batch_embedding([keys[i % len(keys)] for i in range(5000)]))
     monkeypatch.setenv('MEMB_HOST_BELOW', '5')
     assert native.Reader(path)._impl.host_below() == 5
     monkeypatch.setenv('MEMB_HIP_DEVICE', 'cpu')

@@ -113,7 +113,7 @@ struct WordFiller {
 
     enum JobState : int { FILLED = 0, NEEDS_API = 1, TOO_LONG = 2 };
 
-    // One job of the plan; returns its state (and, for OVERFLOW, the bytes it needs in *needed).
+    // One job of the plan; returns its state (and, for TOO_LONG, the bytes it needs in *needed).
     static JobState fillJob(const memb_hip_words_plan& plan, PyObject** items, size_t job, uint64_t* needed)
     {
         constexpr size_t AHEAD = 12;
@@ -137,7 +137,9 @@ struct WordFiller {
             if (ready && PyUnicode_IS_COMPACT_ASCII(item)) {
                 text = reinterpret_cast<const char*>(reinterpret_cast<PyASCIIObject*>(item) + 1);
                 size = PyUnicode_GET_LENGTH(item);
-            } else if (ready && PyUnicode_IS_COMPACT(item) && reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8) {
+            } else if (ready && reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8) {
+                // (every str that is not compact ASCII -- compact or not -- begins with a PyCompactUnicodeObject, whose
+                // utf8 / utf8_length hold the cached UTF-8 form once PyUnicode_AsUTF8AndSize has been asked for it)
                 text = reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8;
                 size = reinterpret_cast<PyCompactUnicodeObject*>(item)->utf8_length;
             }

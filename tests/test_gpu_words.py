@@ -147,7 +147,9 @@ def test_batch_sizes_around_every_packing_boundary(native, make_model):
     path, words = make_model(6000, 300, 'trained', 4)
     reader = native.Reader(path)
     rng = np.random.default_rng(7)
-    pool = words + ['miss-{}'.format(i) for i in range(600)]
+    # (fresh non-ASCII str objects have no cached UTF-8 form: the first -- pooled -- fill meets them, has the calling thread
+    # prepare them through the API and fills again)
+    pool = words + ['miss-{}'.format(i) for i in range(600)] + ['fehlt-ä{}ß'.format(i) for i in range(200)] + ['没有{}'.format(i) for i in range(100)]
     longest = [pool[i] for i in rng.integers(0, len(pool), size=25 * 16384 + 1)]
     expected = reader.resolve_rows(longest)
     assert (expected == MISSING).sum() > 1000

@@ -201,7 +201,7 @@ def install_host_stand_ins(torch, memb_amd):
         def __init__(self, filename, num_threads=0, device=None, **kwargs):
             super().__init__(filename, num_threads, device='cpu', **kwargs)
 
-        def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0):
+        def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0, order=None):
             ids = np.ascontiguousarray(rows.numpy()).view(np.uint32)
             if out is None:
                 out = torch.empty((len(ids), self.dim), dtype=torch.float32)
@@ -582,7 +582,7 @@ def word_search_timings(reader, path, torch, np, repeats=5):
     return result
 
 
-def live_traffic(workload, kernel_name, cache_dir, timeout=150):
+def live_traffic(workload, kernel_name, cache_dir, timeout=90):
     """HBM bytes per launch of the timed kernel from the PMC counters, collected in THIS run: two child processes,
     `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (separate passes, no trace domain: MI355X_MICROARCH.md),
     each over `python3 bench.py --workload <this one> --steps 3 --warmup 1` with everything but the timed step switched off;
@@ -659,7 +659,7 @@ def open_reader(memb_amd, path, device, batch_words=0):
 # one configuration of BASELINE.json: kernel time, algorithmic bytes, parity sample
 # --------------------------------------------------------------------------------------------
 
-def measure_config(name, what, reader, path, rows_host, timer, library, torch, np, launches=15):
+def measure_config(name, what, reader, path, rows_host, timer, library, torch, np, launches=15, random_order_hint=False):
     rows = torch.from_numpy(rows_host.view(np.int32)).cuda()
     out = torch.empty((len(rows_host), reader.dim), dtype=torch.float32, device='cuda')
     ms = timer.launches(lambda: reader.rows_embedding_device(rows, out=out), launches)
@@ -690,6 +690,17 @@ def measure_config(name, what, reader, path, rows_host, timer, library, torch, n
         'parity': parity,
     }
     result['launch'] = {'waves_per_block': info.get('waves_per_block'), 'tiles_per_wavefront': info.get('tiles_per_wavefront')}
+    if random_order_hint:
+        # the same batch with the caller's hint MEMB_HIP_ROWS_IN_RANDOM_ORDER (Reader.rows_embedding_device(order='random')):
+        # blocks of four wavefronts instead of the eight that key-order dumps like. The configuration's own figure above is
+        # WITHOUT the hint -- what a caller who says nothing gets.
+        out.zero_()
+        hinted = timer.launches(lambda: reader.rows_embedding_device(rows, out=out, order='random'), launches)
+        hinted_median = hinted[len(hinted) // 2]
+        result['with_random_order_hint'] = {
+            'what': 'order=\'random\' (MEMB_HIP_ROWS_IN_RANDOM_ORDER): blocks of four wavefronts', 'kernel_ms': hinted_median,
+            'kernel_min_ms': hinted[0], 'frac': nbytes / (hinted_median * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'parity': sampled_parity(path, rows_host, lambda picks: out[torch.from_numpy(picks).cuda()].cpu().numpy())}
     del rows, out
     return result
 
@@ -904,7 +915,8 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     shuffled4 = np.random.default_rng(77).permutation(len(reader4)).astype(np.uint32)
     results.append(measure_config(
         'glove840b-300d-4bit-fullvocab-shuffled (the headline batch in random order)',
-        'every row of the 2.2 M-word 4-bit model once, in shuffled order', reader4, path4, shuffled4, timer, library, torch, np))
+        'every row of the 2.2 M-word 4-bit model once, in shuffled order', reader4, path4, shuffled4, timer, library, torch, np,
+        random_order_hint=True))
     if ceilings and ceilings.get('tile_fill_random_records'):
         results[-1]['pattern_ceiling'] = {'tile_fill_random_records_ms': ceilings['tile_fill_random_records']['ms'],
                                           'kernel_over_ceiling': results[-1]['kernel_ms'] / ceilings['tile_fill_random_records']['ms']}
@@ -919,7 +931,7 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
     results.append(measure_config(
         'fasttext2m-300d-6bit-fullvocab-shuffled (configs[2]\'s batch in random order)',
         'every row of the 2.0 M-word 6-bit model once, in shuffled order', reader, path,
-        np.random.default_rng(78).permutation(len(reader)).astype(np.uint32), timer, library, torch, np))
+        np.random.default_rng(78).permutation(len(reader)).astype(np.uint32), timer, library, torch, np, random_order_hint=True))
     del reader
 
     path, spent = synthetic.cached_model(glove, 300, 'trained', 2)

@@ -234,6 +234,13 @@ int memb_hip_decode_rows_device(
  * the same additions in the same order and the same single division as numpy.mean.
  */
 #define MEMB_HIP_ACCUMULATE 1u
+/*
+ * A hint, never a requirement (results do not depend on it): the rows of this batch come in no particular order (token
+ * ids, shuffled keys). The library does not look at the ids; for batches of more than 524 000 words it launches blocks of
+ * eight wavefronts, which key-order dumps like (1-5 %) and random rows do not (3 %): with this flag such a batch keeps
+ * blocks of four.
+ */
+#define MEMB_HIP_ROWS_IN_RANDOM_ORDER 2u
 int memb_hip_decode_rows_device_ex(
     memb_hip_ctx* ctx, const uint32_t* rows, size_t n, float* out, size_t ld, size_t col_off, void* stream,
     uint32_t flags, float divisor);

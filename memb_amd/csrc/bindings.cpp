@@ -603,7 +603,8 @@ PYBIND11_MODULE(_memb, m) {
                size_t colOff,
                uintptr_t stream,
                bool accumulate,
-               float divisor)
+               float divisor,
+               bool randomOrder)
             {
                 reader.rowsToDeviceBuffer(
                     reinterpret_cast<const uint32_t*>(rows),
@@ -613,7 +614,8 @@ PYBIND11_MODULE(_memb, m) {
                     colOff,
                     reinterpret_cast<void*>(stream),
                     accumulate,
-                    divisor);
+                    divisor,
+                    randomOrder);
             },
             py::arg("rows_ptr"),
             py::arg("n"),
@@ -622,7 +624,8 @@ PYBIND11_MODULE(_memb, m) {
             py::arg("col_off") = 0,
             py::arg("stream") = 0,
             py::arg("accumulate") = false,
-            py::arg("divisor") = 0.0f);
+            py::arg("divisor") = 0.0f,
+            py::arg("random_order") = false);
 
     m.def("available_compression_strategies", &memb::availableCompressionStrategies);
 

@@ -124,13 +124,14 @@ void CompressedStorage::decodeRows(const uint32_t* rows, size_t n, float* out, s
 
 void CompressedStorage::decodeRowsDevice(
     const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream, bool accumulate,
-    float divisor) const
+    float divisor, bool randomOrder) const
 {
     if (onHost()) {
         throw std::runtime_error("this reader decodes on the host (device 'cpu'): device buffers need a reader on a HIP device");
     }
     if (memb_hip_decode_rows_device_ex(
-            deviceContext(), rows, n, out, ld, colOff, stream, accumulate ? MEMB_HIP_ACCUMULATE : 0u, divisor) !=
+            deviceContext(), rows, n, out, ld, colOff, stream,
+            (accumulate ? MEMB_HIP_ACCUMULATE : 0u) | (randomOrder ? MEMB_HIP_ROWS_IN_RANDOM_ORDER : 0u), divisor) !=
         MEMB_HIP_OK) {
         throwDeviceError("HIP batch lookup failed");
     }

@@ -56,9 +56,10 @@ public:
     void decodeRows(const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff) const;
     // Same with device buffers, enqueued on `stream` (hipStream_t, may be null).
     // `accumulate` / `divisor`: see memb_hip_decode_rows_device_ex.
+    // randomOrder: the hint MEMB_HIP_ROWS_IN_RANDOM_ORDER (launch geometry of very large batches; never the result).
     void decodeRowsDevice(
         const uint32_t* rows, size_t n, float* out, size_t ld, size_t colOff, void* stream,
-        bool accumulate = false, float divisor = 0.f) const;
+        bool accumulate = false, float divisor = 0.f, bool randomOrder = false) const;
 
     // device == HOST_DEVICE: rows are decoded by extractRowHost on host threads
     static constexpr int HOST_DEVICE = -2;

@@ -548,6 +548,7 @@ TrainedParams baseTrainedParams(const memb_hip_ctx* ctx)
 struct Epilogue {
     uint32_t accumulate = 0;
     float divisor = 0.f;
+    bool randomOrder = false;   // the caller's hint MEMB_HIP_ROWS_IN_RANDOM_ORDER (launch geometry only)
 };
 
 // The parameters of a lookup kernel that do not depend on the batch. fine: decode with the finer index (more lanes per
@@ -648,7 +649,7 @@ constexpr uint64_t FINE_TILES_PER_R_PERCENT = 62;   // the finer index up to 0.6
 // force: -1 = by the rule, 0 = one tile per wavefront, 1 = decode_records_persistent where the layout allows
 int planTrained(
     const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1,
-    bool mayBeFine = true)
+    bool mayBeFine = true, bool randomOrder = false)
 {
     uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
@@ -673,7 +674,9 @@ int planTrained(
         wantPersistent = force != 0;
     }
     plan->persistent = recordsFit && wantPersistent && !plan->fine;
-    const uint32_t preferred = !plan->persistent && tiles > 16 * R ? 8u : 4u;
+    // (randomOrder: the caller says the rows come in no particular order -- MEMB_HIP_ROWS_IN_RANDOM_ORDER -- and eight
+    // wavefronts per block only pay for key order)
+    const uint32_t preferred = !plan->persistent && tiles > 16 * R && !randomOrder ? 8u : 4u;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, 32, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;
@@ -692,7 +695,7 @@ int planTrained(
     }
     if (plan->fine && !plan->geometry.waves) {   // (cannot happen: fewer words per wavefront need less LDS)
         plan->fine = false;
-        return planTrained(ctx, n, ld, colOff, out, keysOut, plan, force, false);
+        return planTrained(ctx, n, ld, colOff, out, keysOut, plan, force, false, randomOrder);
     }
     return MEMB_HIP_OK;
 }
@@ -704,7 +707,7 @@ int launchTrained(
     const Epilogue& epilogue, bool keysOut = false, int force = -1)
 {
     TrainedPlan plan;
-    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force);
+    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force, true, epilogue.randomOrder);
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
@@ -2191,7 +2194,7 @@ int decode_rows_device_ex_checked(
     if (ld < col_off + ctx->dim) {
         return fail(MEMB_HIP_ERR_INVALID, "ld must be at least col_off + dim");
     }
-    if ((flags & ~uint32_t(MEMB_HIP_ACCUMULATE)) || !(divisor == divisor)) {
+    if ((flags & ~uint32_t(MEMB_HIP_ACCUMULATE | MEMB_HIP_ROWS_IN_RANDOM_ORDER)) || !(divisor == divisor)) {
         return fail(MEMB_HIP_ERR_INVALID, "unknown flags or NaN divisor");
     }
     DeviceScope deviceScope(ctx->device);
@@ -2199,6 +2202,7 @@ int decode_rows_device_ex_checked(
     Epilogue epilogue;
     epilogue.accumulate = (flags & MEMB_HIP_ACCUMULATE) ? 1u : 0u;
     epilogue.divisor = divisor;
+    epilogue.randomOrder = (flags & MEMB_HIP_ROWS_IN_RANDOM_ORDER) != 0;
     return launch(ctx, rows, n, out, ld, col_off, static_cast<hipStream_t>(stream), epilogue);
 }
 

@@ -419,9 +419,9 @@ void Reader::rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t 
 
 void Reader::rowsToDeviceBuffer(
     const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream, bool accumulate,
-    float divisor) const
+    float divisor, bool randomOrder) const
 {
-    compressedStorage_->decodeRowsDevice(rows, n, buffer, ld, colOff, stream, accumulate, divisor);
+    compressedStorage_->decodeRowsDevice(rows, n, buffer, ld, colOff, stream, accumulate, divisor, randomOrder);
 }
 
 std::vector<float> Reader::wordEmbedding(const std::string& word) const

@@ -104,7 +104,7 @@ public:
     void rowsToBuffer(const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff) const;
     void rowsToDeviceBuffer(
         const uint32_t* rows, size_t n, float* buffer, size_t ld, size_t colOff, void* stream,
-        bool accumulate = false, float divisor = 0.f) const;
+        bool accumulate = false, float divisor = 0.f, bool randomOrder = false) const;
 
     // Several device-buffer lookups in one kernel launch (include/memb_hip.h: memb_hip_decode_batches_device).
     void batchesToDeviceBuffers(const memb_hip_batch* batches, size_t count, void* stream) const;

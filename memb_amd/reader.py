@@ -165,7 +165,7 @@ class Reader(BaseReader):
         '''Write the batch into columns [col_off, col_off + dim) of a wider float32 matrix'''
         self._impl.batch_embedding_into(words, out, col_off)
 
-    def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0):
+    def rows_embedding_device(self, rows, out=None, col_off=0, accumulate=False, divisor=0.0, order=None):
         '''Lookup that never leaves the GPU.
         Parameters
         ----------
@@ -173,6 +173,9 @@ class Reader(BaseReader):
         out : torch.Tensor float32 (n, >= col_off + dim) on the same device, optional
         accumulate : add the rows to what `out` holds instead of overwriting it
         divisor : if non-zero, divide the (accumulated) rows by it
+        order : None, or 'random' -- a hint that the rows come in no particular order (token ids, shuffled keys): batches
+            of more than 524 000 rows then keep blocks of four wavefronts, 3 % faster for such rows (key-order dumps like
+            the default of eight). Never changes a result.
         '''
         # (a small batch is seven microseconds of which the kernel is three: every attribute is fetched once)
         import torch
@@ -190,7 +193,8 @@ class Reader(BaseReader):
             raise ValueError('rows and out must be on cuda:{} (the device this reader is staged on), got {} and {}'.format(
                 self.device, device, out.device))
         self._impl.rows_to_device(
-            rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, _current_stream(torch, index), accumulate, float(divisor))
+            rows.data_ptr(), n, out.data_ptr(), out.stride(0), col_off, _current_stream(torch, index), accumulate, float(divisor),
+            order == 'random')
         return out
 
     def stage_words(self):

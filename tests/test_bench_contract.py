@@ -127,6 +127,9 @@ def test_single_gpu_line_and_configuration_array(native, tmp_path):
     # round 5: full-size batches in random order beside the dumps; configs[1]'s own figure is the HBM-regime one, the
     # cache-assisted one a sub-field; several batches in one launch; the word search on the device
     assert sum('shuffled' in name for name in workloads) == 2, workloads
+    for entry in line['configs']:
+        if 'shuffled' in entry['workload']:
+            assert entry['with_random_order_hint']['parity'].startswith('bit-exact') and entry['with_random_order_hint']['kernel_ms'] > 0
     config1 = next(entry for entry in line['configs'] if 'configs[1]' in entry['workload'])
     assert config1['frac_is'].startswith('HBM regime') and config1['repeated_buffer']['frac'] > 0
     assert config1['batches_in_one_launch']['parity'].startswith('bit-exact'), config1['batches_in_one_launch']

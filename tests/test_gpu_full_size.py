@@ -60,6 +60,15 @@ def test_full_vocabulary_dump(native, full_model):
     assert torch.equal(shuffled[valid].view(torch.int32), out[perm[valid].long()].view(torch.int32))
     assert not bool(shuffled[~valid].any())
 
+    # (5) the whole vocabulary in shuffled order, with and without the caller's hint that it is (order='random': blocks of
+    # four wavefronts where a batch this large gets eight by default) -- the same rows either way
+    everything = torch.randperm(count, device='cuda', generator=generator).to(torch.int32)
+    plain = reader.rows_embedding_device(everything)
+    hinted = reader.rows_embedding_device(everything, order='random')
+    torch.cuda.synchronize()
+    assert torch.equal(plain.view(torch.int32), hinted.view(torch.int32))
+    assert torch.equal(plain.view(torch.int32), out[everything.long()].view(torch.int32))
+
 
 def expected_kernel_class(tiles, resident):
     """The kernel a dense batch of `tiles` tiles (of eight words) runs with default options (memb_hip.hip planTrained,

@@ -758,7 +758,8 @@ def test_boundary_argument_errors(native, make_model):
     call = library.memb_hip_decode_rows_device_ex
     args = [context, ctypes.c_void_p(rows.data_ptr()), ctypes.c_size_t(4), ctypes.c_void_p(out.data_ptr()),
             ctypes.c_size_t(8), ctypes.c_size_t(0), ctypes.c_void_p(0)]
-    assert call(*args, ctypes.c_uint32(2), ctypes.c_float(0.0)) == 1 and b'flags' in library.memb_hip_last_error()
+    assert call(*args, ctypes.c_uint32(4), ctypes.c_float(0.0)) == 1 and b'flags' in library.memb_hip_last_error()   # 1 and 2 exist
+    assert call(*args, ctypes.c_uint32(2), ctypes.c_float(0.0)) == 0   # MEMB_HIP_ROWS_IN_RANDOM_ORDER: a hint, same rows
     assert call(*args, ctypes.c_uint32(0), ctypes.c_float(float('nan'))) == 1
     assert call(*args, ctypes.c_uint32(0), ctypes.c_float(0.0)) == 0
     torch.cuda.synchronize()

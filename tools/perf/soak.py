@@ -23,13 +23,28 @@ while time.time()-start < seconds:
         # round 3: the kernels are chosen by batch size; force other choices now and then (results never depend on them)
         reader.set_option('tiles_per_wave', int(rng.choice([0,0,1,2,3,7]))); reader.set_option('persistent', int(rng.integers(0,3)))
         reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
+        reader.set_option('fine_lanes', int(rng.integers(0,3)))   # round 5: the finer segment index by rule / never / always
     for _ in range(int(rng.integers(1,6))):
         n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
         if rng.random()<0.5: batch[::7]=['?']*len(batch[::7])
         want=checker.batch_embedding(batch)
-        kind=int(rng.integers(0,4))
-        if kind==0: check(reader.batch_embedding(batch), want, 'host')
+        kind=int(rng.integers(0,7))
+        if kind==4:
+            # round 5: word -> row on the device against the checker's binary search
+            got=reader.resolve_rows_device(batch).cpu().numpy().view(np.uint32)
+            if not np.array_equal(got, checker.resolve_rows(batch)): print('MISMATCH resolve', n, flush=True); os._exit(1)
+        elif kind==5:
+            # several batches in one launch: the batch cut into ragged pieces
+            rows=reader.resolve_rows_device(batch)
+            cuts=sorted(set([0,n]+[int(c) for c in rng.integers(0,n+1,size=int(rng.integers(0,6)))]))
+            pieces=[(rows[a:b].contiguous(), torch.empty((b-a,reader.dim),dtype=torch.float32,device='cuda')) for a,b in zip(cuts[:-1],cuts[1:])]
+            outs=reader.rows_embedding_device_many(pieces)
+            check(torch.cat(outs).cpu().numpy() if outs else np.zeros((0,reader.dim),dtype=np.float32), want, 'many')
+        elif kind==6:
+            rows=reader.resolve_rows_device(batch)
+            check(reader.rows_embedding_device(rows, order='random').cpu().numpy(), want, 'order hint')
+        elif kind==0: check(reader.batch_embedding(batch), want, 'host')
         elif kind==1: check(reader.batch_embedding_device(batch).cpu().numpy(), want, 'device')
         elif kind==2:
             wide=np.zeros((n,reader.dim+9),dtype=np.float32); reader.batch_embedding_into(batch,wide,5); check(np.ascontiguousarray(wide[:,5:5+reader.dim]), want, 'strided')
@@ -46,6 +61,7 @@ while time.time()-start < seconds:
         pool=models[0][1][:2000]+models[1][1][:2000]
         if rng.random()<0.5: a.set_option('tiles_per_wave', int(rng.choice([0,1,2,3])))
         a.set_option('union_split', int(rng.integers(0,2))); a.set_option('persistent', int(rng.integers(0,3)))
+        a.set_option('union_compact', int(rng.integers(0,2)))
         batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000,90000])))]
         for mode in ('concatenate','average'):
             u=memb_amd.ReadersUnion([a,b],mode)

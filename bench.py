@@ -497,7 +497,8 @@ def host_api_timings(reader, path, rows_host):
     checker = oracle.OracleReader(path, os.cpu_count() or 1)
     cpu_part = best_of(lambda: checker.batch_embedding(sample))
     return {
-        'note': 'words in, numpy float32 out (word search, PCIe, host memory, result allocation included); never part of value',
+        'note': 'words in, numpy float32 out (word search -- on the device from 4096 words on: memb_hip_decode_words --, PCIe, host memory, '
+                'result allocation included); never part of value. The breakdown times the HOST search and the decode of resolved rows on their own',
         'batch_words': len(words),
         'batch_seconds': whole,
         'batch_embeddings_per_s': len(words) / whole,

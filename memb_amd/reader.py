@@ -145,6 +145,19 @@ class Reader(BaseReader):
         """weights for an Embedding layer indexed like the keras Tokenizer"""
         return self.batch_embedding(tokenizer_word_list(tokenizer))
 
+    def to_keyed_vectors(self):
+        """The whole model as a gensim KeyedVectors. The reference looks every key up again (python/memb/reader.py:27-28:
+        batch_embedding(keys())); keys() IS the row order, so the rows are decoded by number and nothing is searched
+        (SURVEY 8f-1's fast path) -- the same matrix."""
+        try:
+            from gensim.models import KeyedVectors
+        except ImportError:
+            raise ImportError('You must install gensim for KeyedVectors export')
+        vocabulary = self.keys()
+        exported = KeyedVectors(self.dim)
+        exported.add(vocabulary, self.rows_embedding(np.arange(len(vocabulary), dtype=np.uint32)))
+        return exported
+
     # ---- additions: row ids and device-resident results ----
 
     def resolve_rows(self, words):

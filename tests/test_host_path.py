@@ -171,3 +171,37 @@ def test_reference_cpp_cases_on_the_host_path(native, tmp_path):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert run.returncode == 0, run.stdout
     assert 'trained storage, first-level table of 1 bit' in run.stdout and run.stdout.strip().endswith('ok (0 failed checks)')
+
+
+def test_to_keyed_vectors_decodes_rows_by_number(native, monkeypatch):
+    """BaseReader.to_keyed_vectors (reference python/memb/reader.py:19-30) with a stand-in gensim (not installed here):
+    Reader decodes rows 0 .. N-1 instead of looking every key up again -- the same vocabulary and matrix as the
+    reference's batch_embedding(keys()); a ReadersUnion goes the reference's way."""
+    import sys
+    import types
+
+    class KeyedVectors:
+        def __init__(self, vector_size):
+            self.vector_size = vector_size
+
+        def add(self, keys, vectors):
+            self.keys, self.vectors = list(keys), np.asarray(vectors)
+
+    gensim = types.ModuleType('gensim')
+    gensim.models = types.ModuleType('gensim.models')
+    gensim.models.KeyedVectors = KeyedVectors
+    monkeypatch.setitem(sys.modules, 'gensim', gensim)
+    monkeypatch.setitem(sys.modules, 'gensim.models', gensim.models)
+    path = os.path.join(GOLDEN, 'synthetic_4bit.bin')
+    reader = native.Reader(path, device='cpu')
+    checker = oracle.OracleReader(path)
+    exported = reader.to_keyed_vectors()
+    assert exported.vector_size == reader.dim and exported.keys == checker.keys()
+    assert bits_equal(exported.vectors, checker.batch_embedding(checker.keys()))
+    union = native.ReadersUnion([reader, reader], 'concatenate').to_keyed_vectors()
+    assert union.vector_size == 2 * reader.dim and bits_equal(union.vectors[:, :reader.dim], exported.vectors)
+    monkeypatch.delitem(sys.modules, 'gensim')
+    monkeypatch.delitem(sys.modules, 'gensim.models')
+    monkeypatch.setitem(sys.modules, 'gensim', None)   # import gensim -> ImportError
+    with pytest.raises(ImportError, match='install gensim'):
+        reader.to_keyed_vectors()

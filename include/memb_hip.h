@@ -351,6 +351,14 @@ int memb_hip_resolve_rows_device(memb_hip_ctx* ctx, const memb_hip_words* batch,
 int memb_hip_resolve_range_device(
     memb_hip_ctx* ctx, const memb_hip_words* batch, size_t first_word, size_t n_words, uint32_t* rows_dev, void* stream);
 /*
+ * The same for `count` (1 .. 4) contexts of one device in ONE launch -- a ReadersUnion's readers: every word is fetched
+ * and hashed once and probed in each model's table; rows_dev[m][i] = row of word i in model m. rows_dev[m] is the whole
+ * batch's array of model m, as above.
+ */
+int memb_hip_resolve_range_union_device(
+    memb_hip_ctx* const* ctxs, size_t count, const memb_hip_words* batch, size_t first_word, size_t n_words,
+    uint32_t* const* rows_dev, void* stream);
+/*
  * Words in, host rows out -- the reference's own calling convention (Reader::batchEmbeddingToBuffer, src/reader.cpp:59-86)
  * with both of its halves on the device: the words of a committed batch are looked up by resolve_words and decoded as
  * memb_hip_decode_rows decodes row ids (same staging, same host threads; the row ids come back over PCIe once, 4 bytes per

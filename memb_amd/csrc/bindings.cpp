@@ -713,14 +713,16 @@ PYBIND11_MODULE(_memb, m) {
             if (readers.size() != rows.size()) {
                 throw std::runtime_error("One row-id array per reader is needed");
             }
-            for (const auto& reader : readers) {
-                reader->stageWords();
+            std::vector<const memb::Reader*> models;
+            std::vector<uint32_t*> targets;
+            for (size_t i = 0; i < readers.size(); ++i) {
+                readers[i]->stageWords();
+                models.push_back(readers[i].get());
+                targets.push_back(reinterpret_cast<uint32_t*>(rows[i]));
             }
+            // one launch per finished run of jobs: every word fetched and hashed once, probed in each reader's table
             return WordFiller::fill(batch, wordList, [&](size_t firstWord, size_t words) {
-                for (size_t i = 0; i < readers.size(); ++i) {
-                    readers[i]->resolveRangeToDevice(
-                        batch, firstWord, words, reinterpret_cast<uint32_t*>(rows[i]), reinterpret_cast<void*>(stream));
-                }
+                memb::Reader::resolveRangeToDevice(models, batch, firstWord, words, targets, reinterpret_cast<void*>(stream));
             });
         },
         py::arg("batch"),

@@ -355,12 +355,24 @@ int stage_words_checked(
     return MEMB_HIP_OK;
 }
 
+// One launch for `count` contexts of one device (a ReadersUnion: the words are read and hashed once, probed per model).
 int launchResolve(
-    memb_hip_ctx* ctx, const uint8_t* bytes, uint64_t totalBytes, const uint32_t* offsets, uint32_t jobShift, size_t first,
-    size_t n, uint32_t* rows, hipStream_t stream)
+    memb_hip_ctx* const* ctxs, uint32_t* const* rows, size_t count, const uint8_t* bytes, uint64_t totalBytes,
+    const uint32_t* offsets, uint32_t jobShift, size_t first, size_t n, hipStream_t stream)
 {
-    if (!ctx->wordSlots) {
-        return fail(MEMB_HIP_ERR_INVALID, "the context's keys are not on the device: call memb_hip_ctx_stage_words first");
+    if (count == 0 || count > RESOLVE_MAX_MODELS) {
+        return fail(MEMB_HIP_ERR_INVALID, "one to four contexts per word lookup");
+    }
+    for (size_t m = 0; m < count; ++m) {
+        if (!ctxs[m] || (n && !rows[m])) {
+            return fail(MEMB_HIP_ERR_INVALID, "null argument");
+        }
+        if (ctxs[m]->device != ctxs[0]->device) {
+            return fail(MEMB_HIP_ERR_INVALID, "the contexts of one word lookup must live on one device");
+        }
+        if (!ctxs[m]->wordSlots) {
+            return fail(MEMB_HIP_ERR_INVALID, "the context's keys are not on the device: call memb_hip_ctx_stage_words first");
+        }
     }
     if (n == 0) {
         return MEMB_HIP_OK;
@@ -375,10 +387,13 @@ int launchResolve(
     params.jobShift = jobShift;
     params.n = n;
     params.queryBytesTotal = totalBytes;
-    params.slots = static_cast<const WordSlot*>(ctx->wordSlots);
-    params.slotMask = ctx->wordSlotMask;
-    params.keyBytes = ctx->wordKeyBytes;
-    params.rows = rows;
+    params.models = static_cast<uint32_t>(count);
+    for (size_t m = 0; m < count; ++m) {
+        params.slots[m] = static_cast<const WordSlot*>(ctxs[m]->wordSlots);
+        params.slotMask[m] = ctxs[m]->wordSlotMask;
+        params.keyBytes[m] = ctxs[m]->wordKeyBytes;
+        params.rows[m] = rows[m];
+    }
     params.stageQueries = reinterpret_cast<uintptr_t>(bytes) % 16 == 0 ? 1u : 0u;
     const size_t perBlock = size_t(RESOLVE_WAVES) * WAVE;
     hipLaunchKernelGGL(
@@ -390,30 +405,48 @@ int launchResolve(
     return MEMB_HIP_OK;
 }
 
-int resolve_range_device_checked(
-    memb_hip_ctx* ctx, const memb_hip_words* batch, size_t firstWord, size_t nWords, uint32_t* rows, hipStream_t stream)
+int launchResolve(
+    memb_hip_ctx* ctx, const uint8_t* bytes, uint64_t totalBytes, const uint32_t* offsets, uint32_t jobShift, size_t first,
+    size_t n, uint32_t* rows, hipStream_t stream)
 {
-    if (!ctx || !batch || (nWords && !rows)) {
+    return launchResolve(&ctx, &rows, 1, bytes, totalBytes, offsets, jobShift, first, n, stream);
+}
+
+// memb_hip_resolve_range_union_device: words [firstWord, firstWord + nWords) of one batch against `count` contexts.
+int resolve_range_union_device_checked(
+    memb_hip_ctx* const* ctxs, size_t count, const memb_hip_words* batch, size_t firstWord, size_t nWords, uint32_t* const* rows,
+    hipStream_t stream)
+{
+    if (!ctxs || !batch || !rows || count == 0 || !ctxs[0]) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
-    if (batch->device != ctx->device) {
+    if (batch->device != ctxs[0]->device) {
         return fail(MEMB_HIP_ERR_INVALID, "the word batch lives on another device than the context");
     }
     if (!batch->plan.bytes || firstWord > batch->plan.n || nWords > batch->plan.n - firstWord ||
         (nWords && firstWord % batch->plan.job_words != 0)) {
         return fail(MEMB_HIP_ERR_INVALID, "the range is not a run of whole jobs of the batch");
     }
-    DeviceScope deviceScope(ctx->device);
+    DeviceScope deviceScope(ctxs[0]->device);
     HIP_TRY(deviceScope.status());
     const int code = launchResolve(
-        ctx, batch->deviceBytes, uint64_t(batch->plan.jobs) * batch->plan.job_bytes, batch->deviceOffsets, batch->jobShift,
-        firstWord, nWords, rows, stream);
+        ctxs, rows, count, batch->deviceBytes, uint64_t(batch->plan.jobs) * batch->plan.job_bytes, batch->deviceOffsets,
+        batch->jobShift, firstWord, nWords, stream);
     if (code == MEMB_HIP_OK && nWords) {
         memb_hip_words* mutableBatch = const_cast<memb_hip_words*>(batch);   // (bookkeeping of who still reads the buffers)
         HIP_TRY(hipEventRecord(mutableBatch->lastUse, stream));
         mutableBatch->inUse = true;
     }
     return code;
+}
+
+int resolve_range_device_checked(
+    memb_hip_ctx* ctx, const memb_hip_words* batch, size_t firstWord, size_t nWords, uint32_t* rows, hipStream_t stream)
+{
+    if (!ctx || !batch || (nWords && !rows)) {
+        return fail(MEMB_HIP_ERR_INVALID, "null argument");
+    }
+    return resolve_range_union_device_checked(&ctx, 1, batch, firstWord, nWords, &rows, stream);
 }
 
 int resolve_rows_device_checked(memb_hip_ctx* ctx, const memb_hip_words* batch, uint32_t* rows, hipStream_t stream)

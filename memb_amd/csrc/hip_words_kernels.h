@@ -88,6 +88,8 @@ __global__ void build_word_table(WordTableParams p)
     }
 }
 
+constexpr uint32_t RESOLVE_MAX_MODELS = 4;
+
 struct ResolveParams {
     const uint8_t* queryBytes;      // the batch's words; device memory, or pinned host memory read over PCIe
     const uint32_t* queryOffsets;   // word i = queryBytes[queryOffsets[at(i)] .. queryOffsets[at(i) + 1]) with
@@ -97,10 +99,13 @@ struct ResolveParams {
     uint32_t jobShift;
     unsigned long long n;
     unsigned long long queryBytesTotal;   // bytes behind queryBytes: a word that claims more is answered MISSING
-    const WordSlot* slots;
-    uint32_t slotMask;
-    const uint8_t* keyBytes;
-    uint32_t* rows;                 // out: [n]
+    // One word, several models (a ReadersUnion resolves one batch against every reader): the word is fetched and hashed
+    // once and probed in every model's table.
+    uint32_t models;                // 1 .. RESOLVE_MAX_MODELS
+    const WordSlot* slots[RESOLVE_MAX_MODELS];
+    uint32_t slotMask[RESOLVE_MAX_MODELS];
+    const uint8_t* keyBytes[RESOLVE_MAX_MODELS];
+    uint32_t* rows[RESOLVE_MAX_MODELS];   // out: [first + n] each
     uint32_t stageQueries;          // queryBytes is 16-byte aligned: a wavefront's words go through LDS
 };
 
@@ -110,26 +115,32 @@ constexpr uint32_t RESOLVE_STAGE_PIECES = 128;   // 16-byte pieces of LDS per wa
 // The probe, for query bytes in LDS or in global memory (one instantiation per call site, so that the
 // compiler knows the address space of `query`).
 template <typename QueryBytes>
-__device__ __forceinline__ uint32_t probeWord(const ResolveParams& p, QueryBytes query, uint32_t length)
+__device__ __forceinline__ unsigned long long hashWord(QueryBytes query, uint32_t length)
 {
     unsigned long long h = FNV_OFFSET_BASIS;
     for (uint32_t i = 0; i < length; ++i) {
         h = (h ^ query[i]) * FNV_PRIME;
     }
-    h = finishWordHash(h);
+    return finishWordHash(h);
+}
+
+template <typename QueryBytes>
+__device__ __forceinline__ uint32_t probeWord(
+    const WordSlot* slots, uint32_t slotMask, const uint8_t* keyBytes, unsigned long long h, QueryBytes query, uint32_t length)
+{
     const uint32_t tag = static_cast<uint32_t>(h >> 32);
-    uint32_t at = static_cast<uint32_t>(h) & p.slotMask;
+    uint32_t at = static_cast<uint32_t>(h) & slotMask;
     // (the table is at most half full: an empty slot ends every probe sequence; the bound is for a table
     // that is not what build_word_table leaves behind)
-    for (uint32_t probes = 0; probes <= p.slotMask; ++probes, at = (at + 1) & p.slotMask) {
-        const WordSlot slot = p.slots[at];
+    for (uint32_t probes = 0; probes <= slotMask; ++probes, at = (at + 1) & slotMask) {
+        const WordSlot slot = slots[at];
         if (slot.y == WORD_SLOT_EMPTY) {
             break;
         }
         if (slot.x != tag || slot.w != length) {
             continue;
         }
-        const uint8_t* key = p.keyBytes + slot.z;
+        const uint8_t* key = keyBytes + slot.z;
         uint32_t difference = 0;
         for (uint32_t i = 0; i < length; i += 4) {
             // four independent loads per round; the last round re-reads the last byte
@@ -169,7 +180,19 @@ __global__ __launch_bounds__(RESOLVE_WAVES * WAVE) void resolve_words(ResolvePar
     const uint32_t waveBegin = __shfl(begin, 0);
     const uint32_t waveEnd = __shfl(end, WAVE - 1);   // (lanes past the batch end hold the last word)
     const uint32_t alignedBegin = waveBegin & ~15u;
-    uint32_t row;
+    // (every model's answer, then the stores: p.models is small and uniform)
+    auto lookUp = [&](auto query) {
+        const unsigned long long h = hashWord(query, length);
+        for (uint32_t m = 0; m < p.models; ++m) {
+            const uint32_t row = probeWord(p.slots[m], p.slotMask[m], p.keyBytes[m], h, query, length);
+            p.rows[m][p.first + base + lane] = row;
+        }
+    };
+    auto allMissing = [&] {
+        for (uint32_t m = 0; m < p.models; ++m) {
+            p.rows[m][p.first + base + lane] = MISSING;
+        }
+    };
     if (p.stageQueries && waveEnd >= alignedBegin && waveEnd - alignedBegin <= RESOLVE_STAGE_PIECES * 16 &&
         __all(sane && begin >= waveBegin && end <= waveEnd)) {   // wave-uniform
         const uint32_t pieces = (waveEnd - alignedBegin + 15) / 16;
@@ -181,11 +204,14 @@ __global__ __launch_bounds__(RESOLVE_WAVES * WAVE) void resolve_words(ResolvePar
         }
         waveLdsFence();
         const uint8_t* query = reinterpret_cast<const uint8_t*>(&stage[wave][0]) + (begin - alignedBegin);
-        row = valid ? probeWord(p, query, length) : MISSING;
-    } else {
-        row = valid && sane ? probeWord(p, p.queryBytes + begin, length) : MISSING;
-    }
-    if (valid) {
-        p.rows[p.first + base + lane] = row;
+        if (valid) {
+            lookUp(query);
+        }
+    } else if (valid) {
+        if (sane) {
+            lookUp(p.queryBytes + begin);
+        } else {
+            allMissing();
+        }
     }
 }

@@ -2672,6 +2672,15 @@ int memb_hip_resolve_rows_device(memb_hip_ctx* ctx, const memb_hip_words* batch,
     return guarded([&] { return resolve_rows_device_checked(ctx, batch, rows_dev, static_cast<hipStream_t>(stream)); });
 }
 
+int memb_hip_resolve_range_union_device(
+    memb_hip_ctx* const* ctxs, size_t count, const memb_hip_words* batch, size_t first_word, size_t n_words,
+    uint32_t* const* rows_dev, void* stream)
+{
+    return guarded([&] {
+        return resolve_range_union_device_checked(ctxs, count, batch, first_word, n_words, rows_dev, static_cast<hipStream_t>(stream));
+    });
+}
+
 int memb_hip_resolve_packed_device(
     memb_hip_ctx* ctx, const uint8_t* bytes_dev, const uint32_t* offsets_dev, size_t n, uint32_t* rows_dev, void* stream)
 {

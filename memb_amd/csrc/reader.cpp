@@ -324,6 +324,32 @@ void Reader::resolveRows(const std::vector<std::string>& words, uint32_t* rows) 
     resolveRows(pointers.data(), pointers.size(), rows);
 }
 
+void Reader::resolveRangeToDevice(
+    const std::vector<const Reader*>& readers, const WordBatch& batch, size_t firstWord, size_t count,
+    const std::vector<uint32_t*>& rowsDevice, void* stream)
+{
+    if (readers.size() != rowsDevice.size()) {
+        throw std::runtime_error("one row-id array per reader is needed");
+    }
+    for (size_t first = 0; first < readers.size(); first += 4) {
+        const size_t group = std::min<size_t>(4, readers.size() - first);
+        memb_hip_ctx* contexts[4] = {};
+        uint32_t* rows[4] = {};
+        for (size_t r = 0; r < group; ++r) {
+            const Reader* reader = readers[first + r];
+            if (batch.device() != reader->compressedStorage_->device()) {
+                throw std::runtime_error("the word batch lives on another device than the reader");
+            }
+            reader->compressedStorage_->stageWords();
+            contexts[r] = reader->compressedStorage_->deviceContext();
+            rows[r] = rowsDevice[first + r];
+        }
+        if (memb_hip_resolve_range_union_device(contexts, group, batch.handle(), firstWord, count, rows, stream) != MEMB_HIP_OK) {
+            throw std::runtime_error(std::string("HIP word search failed: ") + memb_hip_last_error());
+        }
+    }
+}
+
 Reader::WordBatchLease Reader::leaseWordBatch(size_t count) const
 {
     WordBatchLease lease;

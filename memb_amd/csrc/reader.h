@@ -133,6 +133,11 @@ public:
     // ... of words [firstWord, firstWord + count) of a batch whose jobs covering them are written (committed or not):
     // lookups of finished jobs overlap the filling of later ones. rowsDevice is the whole batch's array.
     void resolveRangeToDevice(const WordBatch& batch, size_t firstWord, size_t count, uint32_t* rowsDevice, void* stream) const;
+    // ... against several readers of one device at once (a ReadersUnion): every word is fetched and hashed once and probed in
+    // each reader's table (memb_hip_resolve_range_union_device, four readers per launch). rowsDevice[r] is reader r's array.
+    static void resolveRangeToDevice(
+        const std::vector<const Reader*>& readers, const WordBatch& batch, size_t firstWord, size_t count,
+        const std::vector<uint32_t*>& rowsDevice, void* stream);
 
 private:
     wire::TableView getIndexChecked() const;

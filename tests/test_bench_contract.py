@@ -134,6 +134,8 @@ def test_single_gpu_line_and_configuration_array(native, tmp_path):
     assert config1['frac_is'].startswith('HBM regime') and config1['repeated_buffer']['frac'] > 0
     assert config1['batches_in_one_launch']['parity'].startswith('bit-exact'), config1['batches_in_one_launch']
     assert config1['batches_in_one_launch']['batches'] == 4 and config1['batches_in_one_launch']['frac'] > 0
+    union = next(entry for entry in line['configs'] if 'configs[4]' in entry['workload'])
+    assert union['from_words']['parity'].startswith('bit-exact') and union['from_words']['ms'] > 0
     search = line['word_search']
     assert len(search['batches']) == 3 and search['index']['word_index_keys'] == 50000
     for entry in search['batches']:

@@ -27,7 +27,7 @@ def test_header_declares_the_expected_entry_points():
         # round 5: word -> row on the device, several batches in one launch
         'memb_hip_ctx_stage_words', 'memb_hip_words_create', 'memb_hip_words_destroy', 'memb_hip_words_pack',
         'memb_hip_words_begin', 'memb_hip_words_commit', 'memb_hip_words_count', 'memb_hip_resolve_rows_device',
-        'memb_hip_resolve_range_device', 'memb_hip_resolve_packed_device',
+        'memb_hip_resolve_range_device', 'memb_hip_resolve_range_union_device', 'memb_hip_resolve_packed_device',
         'memb_hip_decode_batches_device', 'memb_hip_decode_words',
     ])
 

@@ -290,6 +290,26 @@ def test_word_search_through_the_c_abi(native):
         torch.cuda.synchronize()
         assert out.cpu().numpy().view(np.uint32).tolist() == expected, shift
 
+    # one launch for two contexts (a ReadersUnion's readers): every word hashed once, probed in each model's table
+    other_keys = [b'', b'a', b'b', b'bb', b'nope', b'x', b'y', b'z']
+    other_packed = b''.join(key + b'\x00' for key in other_keys)
+    other_offsets = np.cumsum([0] + [len(key) + 1 for key in other_keys[:-1]]).astype(np.uint32)
+    context2 = _uniform_context(library, len(other_keys))
+    assert stage(context2, other_packed, len(other_packed), other_offsets.ctypes.data, len(other_keys)) == 0, library.memb_hip_last_error()
+    union_range = library.memb_hip_resolve_range_union_device
+    union_range.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    rows_a = torch.full((len(many),), 7, dtype=torch.int32, device='cuda')
+    rows_b = torch.full((len(many),), 7, dtype=torch.int32, device='cuda')
+    contexts = (ctypes.c_void_p * 2)(context.value, context2.value)
+    targets = (ctypes.c_void_p * 2)(rows_a.data_ptr(), rows_b.data_ptr())
+    assert union_range(contexts, 2, batch, 0, len(many), targets, None) == 0, library.memb_hip_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(rows_a.cpu().numpy().view(np.uint32), want)
+    want_b = np.array([{b'': 0, b'a': 1, b'b': 2, b'nope': 4}.get(w, MISSING) for w in many], dtype=np.uint32)
+    assert np.array_equal(rows_b.cpu().numpy().view(np.uint32), want_b)
+    assert union_range(contexts, 5, batch, 0, len(many), targets, None) == 1   # at most four contexts per launch
+    library.memb_hip_ctx_destroy(context2)
+
     # words in, host rows out (memb_hip_decode_words): the same rows as memb_hip_decode_rows gives for the looked-up ids
     decode_words = library.memb_hip_decode_words
     decode_words.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]

@@ -20,7 +20,7 @@ struct memb_hip_words {
     const uint32_t* deviceOffsets = nullptr;
     hipEvent_t lastUse = nullptr;     // behind the last lookup that reads the buffers
     bool inUse = false;
-    uint32_t threads = 32;            // MEMB_HIP_PACK_THREADS: threads of memb_hip_words_pack
+    uint32_t threads = 64;            // MEMB_HIP_PACK_THREADS: threads of memb_hip_words_pack (at most; one per 32 768 words, at least sixteen)
     std::unique_ptr<memb::WorkerPool> pool;
 };
 
@@ -68,7 +68,7 @@ int words_create_checked(memb_hip_words** out, int device)
     HIP_TRY(deviceScope.status());
     std::unique_ptr<memb_hip_words> batch(new memb_hip_words());
     batch->device = device;
-    batch->threads = std::max<uint32_t>(1, std::min<uint32_t>(envUint("MEMB_HIP_PACK_THREADS", 32), 128));
+    batch->threads = std::max<uint32_t>(1, std::min<uint32_t>(envUint("MEMB_HIP_PACK_THREADS", 64), 128));
     batch->threads = std::min<uint32_t>(batch->threads, std::max(1u, std::thread::hardware_concurrency()));
     HIP_TRY(hipEventCreateWithFlags(&batch->lastUse, hipEventDisableTiming));
     *out = batch.release();
@@ -228,7 +228,7 @@ int words_pack_checked(memb_hip_words* batch, const char* const* words, const ui
             if (!batch->pool) {
                 batch->pool.reset(new memb::WorkerPool(batch->threads - 1));
             }
-            batch->pool->run(plan.jobs, fill);
+            batch->pool->run(plan.jobs, fill, std::min<size_t>(batch->threads, std::max<size_t>(16, n / 32768)));
         }
         if (needed.load() == 0) {
             return words_commit_checked(batch);

@@ -48,7 +48,10 @@ public:
 
     size_t size() const { return threads_.size(); }
 
-    void start(size_t jobs, std::function<void(size_t)> job)
+    // maxThreads: wake at most this many pool threads for the batch (0 = as many as there are jobs): work that is a
+    // cache miss per item wants many threads for large batches and few for small ones, where rousing a thread costs
+    // more than it then does
+    void start(size_t jobs, std::function<void(size_t)> job, size_t maxThreads = 0)
     {
         {
             std::lock_guard<std::mutex> lock(mutex_);
@@ -59,10 +62,11 @@ public:
             error_ = nullptr;
         }
         // wake no more threads than there are jobs (a small batch must not pay for rousing everyone)
-        if (jobs >= threads_.size()) {
+        const size_t wanted = maxThreads ? std::min(jobs, maxThreads) : jobs;
+        if (wanted >= threads_.size()) {
             wake_.notify_all();
         } else {
-            for (size_t i = 0; i < jobs; ++i) {
+            for (size_t i = 0; i < wanted; ++i) {
                 wake_.notify_one();
             }
         }
@@ -90,9 +94,9 @@ public:
         }
     }
 
-    void run(size_t jobs, std::function<void(size_t)> job)
+    void run(size_t jobs, std::function<void(size_t)> job, size_t maxThreads = 0)
     {
-        start(jobs, std::move(job));
+        start(jobs, std::move(job), maxThreads ? maxThreads - 1 : 0);   // (the calling thread is one of them)
         help();
         wait();
     }

@@ -54,6 +54,7 @@ def main():
         '10 000 random': [keys[i] for i in rng.integers(0, len(keys), size=10000)],
         '1 000 random': [keys[i] for i in rng.integers(0, len(keys), size=1000)],
     }
+    batches['500 000 random'] = [keys[i] for i in rng.integers(0, len(keys), size=500000)]
     for name, words in batches.items():
         expected = reader.resolve_rows(words)
         rows = torch.empty(len(words), dtype=torch.int32, device='cuda')

@@ -596,6 +596,10 @@ def live_traffic(workload, kernel_name, cache_dir, timeout=90):
     profiler = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if profiler is None:
         return None, 'rocprofv3 not found'
+    # this process is itself being profiled (rocprofv3 ... -- python3 bench.py): a profiler inside a profiler is asking for
+    # trouble, and whoever runs that has the counters anyway
+    if any(name.startswith(('ROCPROF', 'ROCPROFILER', 'ROCP_')) for name in os.environ) or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'this run is itself under a profiler'
     readings = {}
     scratch = tempfile.mkdtemp(prefix='memb_bench_pmc_', dir='/tmp')
     try:

@@ -3,8 +3,8 @@
 tag=$1; workload=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-args="bench.py --workload $workload --no-configs --no-cpu-baseline --steps 3 --warmup 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py --workload $workload --no-configs --no-cpu-baseline --steps 10 --warmup 3 > $out/bench.json 2> $out/trace.err
+args="bench.py --workload $workload --no-configs --no-cpu-baseline --no-live-traffic --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py --workload $workload --no-configs --no-cpu-baseline --no-live-traffic --steps 10 --warmup 3 > $out/bench.json 2> $out/trace.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $out/pmc1 -o pmc -- python3 $args > /dev/null 2> $out/pmc1.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL --output-format csv -d $out/pmc2 -o pmc -- python3 $args > /dev/null 2> $out/pmc2.err
 python3 - <<PY

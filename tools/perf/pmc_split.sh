@@ -4,7 +4,7 @@ tag=$1; workload=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for flags in 0 1 2; do
   out=gpurun_out/prof_${tag}_flags$flags; mkdir -p $out
-  MEMB_HIP_DEBUG=$flags rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc1 -o pmc -- python3 bench.py --workload $workload --no-configs --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $out/pmc1.err
+  MEMB_HIP_DEBUG=$flags rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc1 -o pmc -- python3 bench.py --workload $workload --no-configs --no-cpu-baseline --no-live-traffic --steps 3 --warmup 1 > /dev/null 2> $out/pmc1.err
   python3 - <<PY
 import csv, collections, glob
 agg=collections.defaultdict(list)

@@ -8,8 +8,8 @@
 tag=$1; kernel=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-long="bench.py $* --no-configs --no-cpu-baseline --steps 10 --warmup 3"
-short="bench.py $* --no-configs --no-cpu-baseline --no-ceilings --steps 3 --warmup 1"
+long="bench.py $* --no-configs --no-cpu-baseline --no-live-traffic --steps 10 --warmup 3"
+short="bench.py $* --no-configs --no-cpu-baseline --no-ceilings --no-live-traffic --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 $long > $out/bench.json 2> $out/trace.err || exit 1
 pass() {   # name, counters...
     name=$1; shift

@@ -95,9 +95,9 @@ def gather_rows(local_rows, count, group=None, dst=0):
 
 class ShardedReader(BaseReader):
     '''One model replicated on several GPUs of a node, driven from one process.
-    A batch is resolved to row ids once on the host, split into contiguous slices
-    (shard_range), every device decodes its slice and writes it straight into its
-    rows of the one result array: the "gather" is that the slices are disjoint
+    A batch is split into contiguous slices (shard_range), every device looks up and
+    decodes its slice and writes it straight into its rows of the one result array
+    (small batches: resolved to row ids once on the host first): the "gather" is that the slices are disjoint
     ranges of one host buffer. No collective, no peer traffic.
     Parameters
     ----------
@@ -155,7 +155,33 @@ class ShardedReader(BaseReader):
         return out
 
     def batch_embedding(self, words):
-        return self.rows_embedding(self._readers[0].resolve_rows(words))
+        '''Words in, one host matrix out. Batches large enough for every device to search its own slice ON the device
+        (memb_amd.Reader does from 4096 words on: memb_hip_decode_words) are cut into word slices -- each device's thread
+        packs, searches and decodes its slice --; smaller ones are resolved once on the host and decoded by row id.'''
+        words = words if isinstance(words, list) else list(words)
+        world = len(self._readers)
+        if len(words) < 4096 * world:
+            return self.rows_embedding(self._readers[0].resolve_rows(words))
+        out = np.empty((len(words), self.dim), dtype=np.float32)
+        errors = []
+
+        def work(rank):
+            start, stop = shard_range(len(words), rank, world)
+            try:
+                if stop > start:
+                    self._readers[rank].batch_embedding_into(words[start:stop], out[start:stop])
+            except Exception as error:  # re-raised on the calling thread
+                errors.append(error)
+
+        threads = [threading.Thread(target=work, args=(rank,)) for rank in range(1, world)]
+        for thread in threads:
+            thread.start()
+        work(0)
+        for thread in threads:
+            thread.join()
+        if errors:
+            raise errors[0]
+        return out
 
     def tokenizer_embedding(self, tokenizer):
         return self.batch_embedding(tokenizer_word_list(tokenizer))

@@ -800,6 +800,12 @@ def test_sharded_reader_in_one_process(native, make_model):
     assert bits_equal(sharded[batch[:2]], checker.batch_embedding(batch[:2]))   # fewer entries than devices
     assert bits_equal(sharded['missing'], np.zeros(300, dtype=np.float32))
     assert sharded.batch_embedding([]).shape == (0, 300)
+    # large enough for every device to search its own slice on the device (3 x 4096 words and more)
+    rng = np.random.default_rng(2)
+    large = [words[i] for i in rng.integers(0, len(words), size=15000)]
+    large[::41] = ['not-here'] * len(large[::41])
+    assert bits_equal(sharded[large], checker.batch_embedding(large))
+    assert all(reader.host_rows_decoded == 0 for reader in sharded._readers)
 
 
 def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):

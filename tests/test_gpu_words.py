@@ -160,6 +160,50 @@ def test_batch_sizes_around_every_packing_boundary(native, make_model):
         assert np.array_equal(got, expected[:size]), size
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_random_vocabularies_of_look_alikes(native, tmp_path, seed):
+    """Property-style: vocabularies drawn from a tiny alphabet (so that keys share long prefixes, differ in one byte, are
+    prefixes of one another) mixed with multi-byte UTF-8, lengths 0 .. 40; queried with every key, with mutations of keys
+    (a byte changed, dropped, appended) and with fresh draws from the same generator -- device search == checker's binary
+    search == host search on every word, for a trained and a uniform storage."""
+    rng = np.random.default_rng(seed)
+    alphabet = ['a', 'b', 'ab', 'ba', 'é', 'ß', '字', '\U0001f600', '-', 'aa']
+
+    def draw(count):
+        lengths = rng.integers(0, 41, size=count)
+        return [''.join(alphabet[i] for i in rng.integers(0, len(alphabet), size=length)) for length in lengths]
+
+    keys = sorted(set(draw(6000)), key=lambda k: k.encode())
+    vectors = rng.standard_normal((len(keys), 8)).astype(np.float32)
+    queries = list(keys)
+    for key in keys[::3]:
+        if key:
+            position = int(rng.integers(0, len(key)))
+            queries.append(key[:position] + 'b' + key[position + 1:])   # one character changed
+            queries.append(key[:position] + key[position + 1:])        # one dropped
+        queries.append(key + alphabet[int(rng.integers(0, len(alphabet)))])   # one appended
+    queries += draw(5000)
+    order = rng.permutation(len(queries))
+    queries = [queries[i] for i in order]
+    for storage, bits in (('trained', 4), ('uniform', 8)):
+        path = str(tmp_path / '{}_{}.bin'.format(storage, seed))
+        builder = native.Builder(8, storage, bits)
+        insertion = rng.permutation(len(keys))
+        builder.add_words([keys[i] for i in insertion], vectors[insertion])
+        builder.save(path)
+        reader = native.Reader(path)
+        checker = oracle.OracleReader(path)
+        assert reader.keys() == keys
+        expected = checker.resolve_rows(queries)
+        hits = int((expected != MISSING).sum())
+        assert hits >= len(keys) and hits < len(queries) - 1000
+        got = reader.resolve_rows_device(queries).cpu().numpy().view(np.uint32)
+        wrong = np.nonzero(got != expected)[0]
+        assert len(wrong) == 0, [(queries[i], int(got[i]), int(expected[i])) for i in wrong[:5]]
+        assert np.array_equal(reader.resolve_rows(queries), expected)
+        assert bits_equal(reader[queries], checker.batch_embedding(queries))   # (>= 4096 words: the device search inside)
+
+
 def _library(native):
     library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
     library.memb_hip_last_error.restype = ctypes.c_char_p

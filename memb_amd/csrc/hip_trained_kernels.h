@@ -202,6 +202,15 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
     meta.segmentBits = segmentField(role.segment, meta.segmentBits, meta.packed2, meta.packed3);
 }
 
+#ifndef MEMB_HIP_SGPRS
+#define MEMB_HIP_SGPRS 88
+#endif
+#if MEMB_HIP_SGPRS
+#define MEMB_SGPR_BUDGET __attribute__((amdgpu_num_sgpr(MEMB_HIP_SGPRS)))
+#else
+#define MEMB_SGPR_BUDGET
+#endif
+
 #ifndef MEMB_HIP_OUTPUT_BURST
 #define MEMB_HIP_OUTPUT_BURST 5   // 16-byte pieces a lane gathers before it stores them back to back (outputTile)
 #endif
@@ -707,14 +716,14 @@ __device__ __forceinline__ void decodeTilesOfBlock(const TrainedParams& p, const
 }
 
 template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained(TrainedParams p)
+__global__ MEMB_SGPR_BUDGET void decode_trained(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     decodeTilesOfBlock<HAS_SUB, MODE, FAST, false>(p, BatchList(), lds);
 }
 
 template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_trained_batches(TrainedParams p, BatchList list)
+__global__ MEMB_SGPR_BUDGET void decode_trained_batches(TrainedParams p, BatchList list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     decodeTilesOfBlock<HAS_SUB, MODE, FAST, true>(p, list, lds);
@@ -1136,7 +1145,7 @@ __global__ void decode_trained_union(UnionParams u)
 // byte-key forms), decoded through 4-byte PACKED tables.
 // COMPACT (nibble keys only): the models' 4-byte tables (memb_hip_ctx::table32) instead of the 8-byte ones.
 template <bool HAS_SUB, bool FAST, bool AVERAGE, bool COMPACT = false>
-__global__ void decode_union_split(UnionParams u)
+__global__ MEMB_SGPR_BUDGET void decode_union_split(UnionParams u)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t lane = threadIdx.x & (WAVE - 1);

@@ -124,6 +124,8 @@ struct Switches {
                                    // (6 KiB of LDS image per block instead of 8, one ds_read_b32 per symbol): 1 (default) / 0
     uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
+    uint32_t ldsPad = 0;           // option lds_pad, builds with -DMEMB_HIP_MEASURE only: unused LDS bytes added to every block of
+                                   // decode_trained (fewer resident wavefronts per CU from the same code: tools/perf/r5/residency.sh)
     bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -218,7 +220,18 @@ struct TrainedGeometry {
     uint32_t waves;      // wavefronts per block
     uint32_t ldsBytes;   // dynamic LDS per block
     int mode;
+    uint32_t resident;   // wavefronts a CU holds at this block size (LDS and registers)
 };
+
+// Wavefronts per CU the registers of the one-tile kernels (decode_trained, decode_trained_batches, decode_union_split)
+// admit: 57-61 vector registers would allow 8 per SIMD, but the hardware hands out scalar registers too -- 800 per SIMD
+// in steps of 16 plus 16 (MI355X_MICROARCH.md, "Residency and cooperative launch") -- and the compiler, which does not
+// count that, took 106: SIX per SIMD, 24 per CU, in rounds 1-4 (seen in round 5 as a step in the time of small batches at
+// exactly 24 x CUs tiles). hip_trained_kernels.h now holds these kernels to a budget (MEMB_HIP_SGPRS = 88: .sgpr_count 86,
+// no vector register more): SEVEN per SIMD. A budget of 80 (8 per SIMD) costs two vector registers of spills, 3-5 % on the
+// chain of a small batch, and in blocks of eight +5 % on a key-order dump (tools/perf/r5/sgprs.sh, residency.sh);
+// tests/test_isa.py pins the seven.
+constexpr uint32_t ONE_TILE_WAVES_PER_CU = 28;
 
 uint32_t roundUp4(uint32_t v)
 {
@@ -281,7 +294,7 @@ uint32_t trainedLdsBytes(const memb_hip_ctx* ctx, uint32_t waves, uint32_t words
 // unknown): a block size whose LDS would allow more resident wavefronts than the registers do gains nothing by it.
 TrainedGeometry chooseGeometry(
     const memb_hip_ctx* ctx, uint32_t wordsPerWave, size_t ld, size_t colOff, const float* out,
-    uint32_t registerWavesPerCu = 32, uint32_t preferred = 4)
+    uint32_t registerWavesPerCu = ONE_TILE_WAVES_PER_CU, uint32_t preferred = 4)
 {
     TrainedGeometry best{};
     const uint32_t forcedWaves = ctx->switches.waves;   // (1 .. 16; anything but 1, 2, 4, 8: measurements)
@@ -312,9 +325,11 @@ TrainedGeometry chooseGeometry(
             best.ldsBytes = ldsBytes;
         }
     }
+    best.resident = bestResident;
     if (preferredResident && (forcedWaves || 4 * bestResident < 5 * preferredResident)) {
         best.waves = wanted;
         best.ldsBytes = preferredLds;
+        best.resident = preferredResident;
     }
     const bool vec = (ctx->dim % 4 == 0) && (ld % 4 == 0) && (colOff % 4 == 0) &&
         (reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -614,7 +629,7 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
     if (ctx->switches.tilesPerWave) {
         return std::min<uint32_t>(ctx->switches.tilesPerWave, 64);
     }
-    const uint64_t slots = uint64_t(ctx->cuCount) * 32;   // resident wavefronts of the one-tile kernels
+    const uint64_t slots = uint64_t(ctx->cuCount) * 32;   // (the unit the thresholds below were measured in)
     if (unionSplit) {
         return 2 * tiles >= slots ? 2u : 1u;   // (from 16 k words on 256 CUs; below, halving the grid leaves CUs idle)
     }
@@ -632,13 +647,13 @@ struct TrainedPlan {
 };
 
 constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below (times the CUs)
-constexpr uint64_t FINE_TILES_PER_R_PERCENT = 62;   // the finer index up to 0.62 R tiles (20 000 words on 256 CUs)
 
 // (the context's device is current)
 // Which kernel by batch size (n words): a STATIC rule. t = tiles of the batch, R = 16 x CUs. Round 4 measured every
 // kernel of rounds 1-3 on every model kind (2-, 4-, 6-bit, byte-key 4-bit, Student-t 4-bit; key order, shuffled, 100 k,
 // 500 k; tools/perf/r4/batch1.sh, two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
-//   decode_trained (one tile per wavefront at a time, 52-61 VGPRs, 32 wavefronts per CU) -- everything, except
+//   decode_trained (one tile per wavefront at a time, 52-61 VGPRs; 28 wavefronts per CU by its scalar registers, 24 until
+//   round 5: ONE_TILE_WAVES_PER_CU) -- everything, except
 //   2 R < t <= 4 R on row-record models: decode_records_persistent (20 wavefronts per CU, software pipeline):
 //       100 000 rows -4.3..-6 % (4-bit), -8..-9 % (6-bit), -1.5 % (2-bit); at 500 k rows it is 3-11 % BEHIND.
 // The general persistent pipeline lost every dump (+2.3 % 4-bit, +4.9 % 2-bit; 6-bit -1.8 % on one box) and every
@@ -657,16 +672,29 @@ int planTrained(
     uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint64_t R = uint64_t(ctx->cuCount) * PIPELINE_WAVES_PER_CU;
-    // Small batches -- at most FINE_TILES_PER_R_PERCENT % of R tiles: every wavefront has one tile and most CUs are not full --
-    // are one chain of dependent steps per wavefront with nothing to hide it behind; the finer index shortens the longest
-    // link, the decode. Round 5, batch 3 (tools/perf/r5/batch3.sh; eight lanes per word = 100 %): 1 000 / 5 000 / 10 000 /
-    // 16 000 / 20 000 rows: 4-bit -11 / -14 / -13 / -3 / -5 %, 6-bit -22 / -24 / -17 / -8 / -16 %, 2-bit -8 / -13 / -12 / -4 /
-    // -5 %; 30 000 and 40 000 rows +8 / +1 % (4-bit), +3 / -1 % (6-bit), +10 / +7 % (2-bit); 100 000 rows +4..+14 %, with
-    // nothing cached +21..+41 %. (50 000 rows -10 / -15 / -3 %: an island at 1.5 R tiles that the rule leaves alone.)
+    // The finer index, by what fits a CU at once (`resident` = wavefronts per CU at the block size of a small batch, LDS and
+    // registers; x CUs = the tiles of one round):
+    //   (a) batches whose FINE tiles all fit one round (28 600 words on 256 CUs): every wavefront has one tile, the batch is
+    //       one chain of dependent steps per wavefront, and the finer index shortens its longest link, the decode. Round 5
+    //       (tools/perf/r5/batch3.sh, fine_sweep.sh; the usual index = 100 %): 1 000 / 5 000 / 10 000 / 16 000 / 20 000 / 24 000 /
+    //       28 000 rows: 4-bit -11 / -14 / -13 / -6 / -7 / -4 / -4 %, 6-bit -22 / -24 / -17 / -9 / -9 / -6 / -10 %; one row more
+    //       than a round and its second round costs what the index saved: 32 000 / 40 000 / 50 000 rows +6 / +3 / +4 % (4-bit),
+    //       +2 / -1 / -2 % (6-bit);
+    //   (b) batches whose USUAL tiles just miss one round -- more than `resident` x CUs of them, at most a fifth more and at
+    //       most 2 R (57 000 to 65 500 words): the usual index runs a nearly empty second round there (56 000 -> 60 000 rows: 17.3 -> 21.0 us),
+    //       the finer one's tiles are half as long: 60 000 / 65 000 rows -7 / -3 % (4-bit), -9 / -8 % (6-bit). From 2 R tiles
+    //       on decode_records_persistent or the usual index win (70 000 rows +4 / +3 %, 100 000 +4..+14 %, nothing cached
+    //       +21..+41 %).
     // (a forced kernel -- option persistent = 2, force = 1 -- wins over the rule, a forced finer index over both)
-    plan->fine = mayBeFine && ctx->fineIndex && force != 1 &&
-        (ctx->switches.fineLanes == 2 ||
-         (ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && tiles * 100 <= R * FINE_TILES_PER_R_PERCENT));
+    bool fineByRule = false;
+    if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && force != 1) {
+        const uint32_t fineWords = WAVE / ctx->fineLanes;
+        const uint64_t fineTiles = (n + fineWords - 1) / fineWords;
+        const uint64_t fineRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, fineWords, ld, colOff, out).resident;
+        const uint64_t usualRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, wordsPerWave, ld, colOff, out).resident;
+        fineByRule = fineTiles <= fineRound || (tiles > usualRound && tiles <= std::min<uint64_t>(2 * R, usualRound * 6 / 5));
+    }
+    plan->fine = mayBeFine && ctx->fineIndex && force != 1 && (ctx->switches.fineLanes == 2 || fineByRule);
     if (plan->fine) {
         wordsPerWave = WAVE / ctx->fineLanes;
     }
@@ -680,7 +708,7 @@ int planTrained(
     // (randomOrder: the caller says the rows come in no particular order -- MEMB_HIP_ROWS_IN_RANDOM_ORDER -- and eight
     // wavefronts per block only pay for key order)
     const uint32_t preferred = !plan->persistent && tiles > 16 * R && !randomOrder ? 8u : 4u;
-    plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, 32, preferred);
+    plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;
     }
@@ -742,18 +770,19 @@ int launchTrained(
         params.tilesPerWave = oneTileSteps(ctx, tiles, 4u * (params.tableDwords + params.codebookDwords), false);
         const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
         const uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
+        const uint32_t ldsBytes = std::min<uint32_t>(geometry.ldsBytes + ctx->switches.ldsPad, 160 * 1024);   // (ldsPad: measurement builds)
         switch (geometry.mode) {
             case OUT_FLAT:
-                status = launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                status = launchTrainedMode<OUT_FLAT>(ctx, params, blocks, threads, ldsBytes, stream);
                 break;
             case OUT_VEC4:
-                status = launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                status = launchTrainedMode<OUT_VEC4>(ctx, params, blocks, threads, ldsBytes, stream);
                 break;
             case OUT_KEYS:
-                status = launchTrainedMode<OUT_KEYS>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                status = launchTrainedMode<OUT_KEYS>(ctx, params, blocks, threads, ldsBytes, stream);
                 break;
             default:
-                status = launchTrainedMode<OUT_SCALAR>(ctx, params, blocks, threads, geometry.ldsBytes, stream);
+                status = launchTrainedMode<OUT_SCALAR>(ctx, params, blocks, threads, ldsBytes, stream);
                 break;
         }
     }
@@ -2104,6 +2133,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
 #ifdef MEMB_HIP_MEASURE
     } else if (key == "debug" && value <= 0xFFFFFFFFull) {
         ctx->switches.debugFlags = static_cast<uint32_t>(value);
+    } else if (key == "lds_pad" && value <= 128 * 1024) {
+        ctx->switches.ldsPad = static_cast<uint32_t>(value);
 #endif
     } else {
         return fail(MEMB_HIP_ERR_INVALID, "unknown option or value out of range: " + key);

@@ -70,16 +70,26 @@ def test_full_vocabulary_dump(native, full_model):
     assert torch.equal(plain.view(torch.int32), out[everything.long()].view(torch.int32))
 
 
-def expected_kernel_class(tiles, resident):
-    """The kernel a dense batch of `tiles` tiles (of eight words) runs with default options (memb_hip.hip planTrained,
-    chooseGeometry; DESIGN.md section 5.0 "which kernel owns which configuration") for a row-record model of dim 300 whose
-    tables leave the block sizes about the same residency -- the 2-, 4- and 6-bit models, nibble or byte keys:
-    resident = 16 wavefronts per CU x CUs; decode_records_persistent for 2 R < tiles <= 4 R, else decode_trained in blocks
-    of four wavefronts, eight for batches of more than 16 R tiles; up to 0.62 R tiles with the finer index (more lanes per
-    word). Returns (kernel family, wavefronts per block or None where the rule does not pin them, finer index?)."""
+ONE_TILE_WAVES_PER_CU = 28   # memb_hip.hip: what the scalar registers of decode_trained admit (tests/test_isa.py pins it)
+
+
+def expected_kernel_class(words, words_per_tile, fine_words_per_tile, cus):
+    """The kernel a dense batch of `words` words runs with default options (memb_hip.hip planTrained, chooseGeometry;
+    DESIGN.md section 5.0 "which kernel owns which configuration") for a row-record model of dim 300 whose tables leave
+    every block size the residency the registers allow -- the 2-, 4- and 6-bit models, nibble or byte keys. R = 16
+    wavefronts per CU x CUs, one round = 28 x CUs tiles: decode_records_persistent for 2 R < tiles <= 4 R, else
+    decode_trained in blocks of four wavefronts, eight for batches of more than 16 R tiles; with the finer index (more lanes
+    per word) while its own tiles fit one round, and where the usual tiles just miss one (more than a round: by at most a
+    fifth, and at most 2 R).
+    Returns (kernel family, wavefronts per block or None where the rule does not pin them, finer index?)."""
+    tiles = (words + words_per_tile - 1) // words_per_tile
+    fine_tiles = (words + fine_words_per_tile - 1) // fine_words_per_tile
+    resident = 16 * cus
+    one_round = ONE_TILE_WAVES_PER_CU * cus
+    fine = fine_tiles <= one_round or one_round < tiles <= min(2 * resident, one_round * 6 // 5)
     if 2 * resident < tiles <= 4 * resident:
         return 'decode_records_persistent<', None, False
-    return 'decode_trained<', 8 if tiles > 16 * resident else 4, tiles * 100 <= resident * 62
+    return 'decode_trained<', 8 if tiles > 16 * resident else 4, fine
 
 
 def test_default_path_of_every_batch_size_class(native, full_model):
@@ -94,12 +104,14 @@ def test_default_path_of_every_batch_size_class(native, full_model):
     checker = oracle.OracleReader(path, os.cpu_count() or 1)
     assert reader.host_rows_decoded == 0
     words_per_tile = 64 // reader.info()['lanes_per_word']
-    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    fine_words_per_tile = 64 // reader.info(1)['lanes_per_word']
+    assert fine_words_per_tile < words_per_tile
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    resident = 16 * cus
 
     def check(rows, label):
-        tiles = (len(rows) + words_per_tile - 1) // words_per_tile
         info = reader.info(len(rows))
-        family, waves, fine = expected_kernel_class(tiles, resident)
+        family, waves, fine = expected_kernel_class(len(rows), words_per_tile, fine_words_per_tile, cus)
         assert info['kernel'].startswith(family), (label, len(rows), info['kernel'])
         assert waves is None or info['waves_per_block'] == waves, (label, len(rows), info['waves_per_block'])
         assert (info['lanes_per_word'] > 64 // words_per_tile) == fine, (label, len(rows), info['lanes_per_word'])
@@ -120,12 +132,14 @@ def test_default_path_of_every_batch_size_class(native, full_model):
 
     rng = np.random.default_rng(12)
     seen = set()
-    fine_edge = resident * 62 // 100
-    for tiles in (fine_edge, fine_edge + 1):   # the finer index on one side, eight lanes per word on the other
-        batch = tiles * words_per_tile
+    one_round = ONE_TILE_WAVES_PER_CU * cus
+    # the finer index on one side of each of its edges, the usual lanes per word on the other: its own tiles fill one round;
+    # the usual tiles just miss one round ... up to 2 R
+    for batch in (one_round * fine_words_per_tile, one_round * fine_words_per_tile + 1,
+                  one_round * words_per_tile, one_round * words_per_tile + 1):
         rows = rng.integers(0, count, size=batch).astype(np.uint32)
         rows[rng.integers(0, batch, size=batch // 100)] = 0xFFFFFFFF
-        check(rows, 'fine edge {}'.format(tiles))
+        check(rows, 'fine edge {}'.format(batch))
     for multiple in (2, 4, 16):
         for delta in (-1, 0, 1):
             if multiple != 2 and delta == -1:
@@ -156,13 +170,17 @@ def test_block_size_rule_on_the_byte_key_models(native, bits, words, seed):
     checker = oracle.OracleReader(path, os.cpu_count() or 1)
     assert reader.info()['kernel'].rstrip('>').split(',')[2].strip() == 'false'   # byte keys
     words_per_tile = 64 // reader.info()['lanes_per_word']
-    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    fine_words_per_tile = 64 // reader.info(1)['lanes_per_word']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    resident = 16 * cus
+    one_round = ONE_TILE_WAVES_PER_CU * cus
     rng = np.random.default_rng(bits)
-    for tiles in (1, resident * 62 // 100, resident * 62 // 100 + 1, 2 * resident, 2 * resident + 1, 4 * resident, 4 * resident + 1,
+    for tiles in (1, one_round * fine_words_per_tile // words_per_tile, one_round * fine_words_per_tile // words_per_tile + 1,
+                  one_round, one_round + 1, 2 * resident, 2 * resident + 1, 4 * resident, 4 * resident + 1,
                   16 * resident, 16 * resident + 1, (count + words_per_tile - 1) // words_per_tile):
         batch = min(tiles * words_per_tile, 4 * count)
         info = reader.info(batch)
-        family, waves, fine = expected_kernel_class((batch + words_per_tile - 1) // words_per_tile, resident)
+        family, waves, fine = expected_kernel_class(batch, words_per_tile, fine_words_per_tile, cus)
         assert info['kernel'].startswith(family), (tiles, info['kernel'])
         assert waves is None or info['waves_per_block'] == waves, (tiles, info['waves_per_block'])
         assert (info['lanes_per_word'] > 64 // words_per_tile) == fine, (tiles, info['lanes_per_word'])

@@ -1153,7 +1153,8 @@ def test_uniform_tile_kernel(native, make_model):
 @pytest.mark.parametrize('bits,dim', [(4, 300), (2, 300), (6, 300), (8, 300), (4, 128), (6, 100), (4, 52), (4, 1024), (4, 20)])
 def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim):
     """Row-record models carry a second, finer segment index (about sixteen lanes per word; memb_hip.hip: stageIndex,
-    planTrained): batches of up to half a tile per 16 wavefronts per CU run decode_trained with it. Same rows as the
+    planTrained): batches whose tiles under it fit the CUs at once run decode_trained with it, and so does the band of sizes
+    where the usual tiles just miss that. Same rows as the
     checker with the index forced on (2), off (1) and by rule (0), for batch sizes on both sides of a tile and of the
     rule's edge, misses included. Reference: src/huffman_table_decoder.h:102-118 (the serial chain being split)."""
     import torch
@@ -1167,9 +1168,28 @@ def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim
         assert small['lanes_per_word'] > large['lanes_per_word'], (small, large)
         assert small['segment_symbols'] < large['segment_symbols']
     rng = np.random.default_rng(bits * 1000 + dim)
-    resident = 16 * torch.cuda.get_device_properties(0).multi_processor_count
-    edge = resident * 62 // 100 * (64 // large['lanes_per_word'])     # words at the rule's edge (0.62 R tiles: 20 312 on 256 CUs)
-    for count in (1, 3, 4, 5, 64, 1000, edge - 1, edge, edge + 9, 3 * edge):
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def round_of(info):
+        # tiles resident at once: per CU what the registers admit (28: memb_hip.hip ONE_TILE_WAVES_PER_CU) or what LDS --
+        # 160 KiB handed out per block in steps of 1 KiB -- leaves of it (the 8-bit model's tables, dim 1024's slots)
+        waves, lds = info['waves_per_block'], info['lds_bytes_per_block']
+        return cus * waves * min(160 * 1024 // ((lds + 1023) // 1024 * 1024), max(1, 28 // waves))
+
+    reader.set_option('fine_lanes', 1)
+    usual_round = round_of(reader.info(1000))
+    reader.set_option('fine_lanes', 0)
+    fine_words, usual_words = 64 // small['lanes_per_word'], 64 // large['lanes_per_word']
+    edge = round_of(small) * fine_words                  # (a) the finer index while its tiles fit one round: 28 672 words on 256 CUs
+    # (b) ... and where the usual tiles just miss one round: by up to a fifth, and below 2 R (decode_records_persistent's)
+    island = (usual_round * usual_words, min(2 * 16 * cus, usual_round * 6 // 5) * usual_words)
+
+    def expected_lanes(count):
+        usual_tiles = (count + usual_words - 1) // usual_words
+        fine = count <= edge or island[0] // usual_words < usual_tiles <= island[1] // usual_words
+        return small['lanes_per_word'] if fine else large['lanes_per_word']
+
+    for count in (1, 3, 4, 5, 64, 1000, edge - 1, edge, edge + 9, island[0], island[0] + 1, island[1], island[1] + 1):
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)
         rows[rng.integers(0, count, size=max(1, count // 20))] = 0xFFFFFFFF
         expected = checker.rows_embedding(rows)
@@ -1182,7 +1202,7 @@ def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim
             assert bits_equal(out.cpu().numpy(), expected), (count, fine, reader.info(count)['lanes_per_word'])
             by_rule = reader.info(count)['lanes_per_word']
             if fine == 0 and dim >= 100:
-                assert by_rule == (small['lanes_per_word'] if count <= edge else large['lanes_per_word']), (count, by_rule)
+                assert by_rule == expected_lanes(count), (count, by_rule)
         # host buffers take the same path (centroid indices over PCIe for trained storages)
         assert bits_equal(reader.rows_embedding(rows), expected), count
     reader.set_option('fine_lanes', 0)

@@ -128,14 +128,15 @@ for index in range(out_buffers):
 
 def apply(reader, options):
     settings = dict(DEFAULTS)
-    if 'debug' in options or os.environ.get('MEMB_PACKAGE_ROOT'):
+    if 'debug' in options or 'lds_pad' in options or os.environ.get('MEMB_PACKAGE_ROOT'):
         settings['debug'] = 0
+        settings['lds_pad'] = 0   # (round 5's first residency table ran without this line: a variant kept the pad of the one before it)
     settings.update(options)
     for key, value in settings.items():
         try:
             reader.set_option(key, value)
         except RuntimeError:
-            if key != 'debug' or value:   # (a package root that is not a measurement build has no such option)
+            if key not in ('debug', 'lds_pad') or value:   # (a package root that is not a measurement build has no such option)
                 raise
 
 

@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 
 
-def build(extra_flags=(), root=None):
+def build(extra_flags=(), root=None, plain=False):
     import build_native
     root = root or os.path.join(REPO, 'build', 'measure')
     package = os.path.join(root, 'memb_amd')
@@ -34,10 +34,19 @@ def build(extra_flags=(), root=None):
     build_native.INCLUDE = include
     build_native.HIP_LIBRARY = os.path.join(package, os.path.basename(build_native.HIP_LIBRARY))
     build_native.EXTENSION = os.path.join(package, os.path.basename(build_native.EXTENSION))
-    build_native.build_hip_library(force=True, extra_flags=['-DMEMB_HIP_MEASURE', *extra_flags])
+    build_native.build_hip_library(force=True, extra_flags=[*([] if plain else ['-DMEMB_HIP_MEASURE']), *extra_flags])
     build_native.build_extension(force=False)
     return root
 
 
 if __name__ == '__main__':
-    print('measurement package:', build(sys.argv[1:]))
+    # --plain=DIR: a copy WITHOUT the measurement switches (two shipped builds side by side, e.g. -DMEMB_HIP_SGPRS=0)
+    arguments = sys.argv[1:]
+    plain_root = next((a.split('=', 1)[1] for a in arguments if a.startswith('--plain=')), None)
+    arguments = [a for a in arguments if not a.startswith('--plain=')]
+    measure_root = next((a.split('=', 1)[1] for a in arguments if a.startswith('--root=')), None)
+    arguments = [a for a in arguments if not a.startswith('--root=')]
+    if plain_root:
+        print('plain package:', build(arguments, root=os.path.abspath(plain_root), plain=True))
+    else:
+        print('measurement package:', build(arguments, root=os.path.abspath(measure_root) if measure_root else None))

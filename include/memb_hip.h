@@ -183,9 +183,10 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
  *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
  *                     decodes K tiles one after the other behind one copy of the tables into LDS
- *   "fine_lanes"      0 (default) = batches of at most 0.62 tiles per 16 wavefronts per CU (20 000 words on 256 CUs) of a
- *                     row-record model are decoded with its finer segment index (about sixteen lanes per word instead of
- *                     eight: the chain of dependent lookups of a batch too small to hide it is shorter), 1 = never, 2 = always
+ *   "fine_lanes"      0 (default) = a row-record model's finer segment index (about sixteen lanes per word instead of eight:
+ *                     the chain of dependent lookups of a batch too small to hide it is shorter) decodes the batches whose
+ *                     tiles under it are all resident at once (28 600 words on 256 CUs) and those whose usual tiles just
+ *                     miss that (57 000 - 65 500 words), 1 = never, 2 = always
  *   "union_compact"   1 (default) = decode_union_split decodes two nibble-key models through their 4-byte table entries
  *                     (round 5: -2.5 % at 500 000 and 1 000 000 words), 0 = through the 8-byte ones
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split

@@ -797,11 +797,26 @@ int launchTrained(
 // the rule of a single batch with as many words as all of them together.
 int launchTrainedBatches(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_t count, hipStream_t stream)
 {
-    const uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
-    BatchList list{};
-    uint64_t tiles = 0;
     size_t words = 0;
     int mode = OUT_FLAT;
+    for (size_t k = 0; k < count; ++k) {
+        const memb_hip_batch& batch = batches[k];
+        words += batch.n;
+        const bool vec = (ctx->dim % 4 == 0) && (batch.ld % 4 == 0) && (batch.col_off % 4 == 0) &&
+            (reinterpret_cast<uintptr_t>(batch.out) % 16 == 0);
+        const int batchMode = !vec ? OUT_SCALAR : (batch.ld == ctx->dim && batch.col_off == 0) ? OUT_FLAT : OUT_VEC4;
+        // one output mode for the launch: the most general one any batch needs (OUT_SCALAR < OUT_VEC4 < OUT_FLAT)
+        mode = std::min(mode, batchMode);
+    }
+    // (the finer index as for one batch of as many words: a serving loop's handful of small lookups is a small batch)
+    TrainedPlan plan;
+    const int planned = planTrained(ctx, words, ctx->dim, 0, nullptr, false, &plan, 0, true);
+    if (planned != MEMB_HIP_OK) {
+        return planned;
+    }
+    const uint32_t wordsPerWave = WAVE / (plan.fine ? ctx->fineLanes : ctx->lanesPerWord);
+    BatchList list{};
+    uint64_t tiles = 0;
     for (size_t k = 0; k < count; ++k) {
         const memb_hip_batch& batch = batches[k];
         list.firstTile[list.count] = tiles;
@@ -812,25 +827,14 @@ int launchTrainedBatches(memb_hip_ctx* ctx, const memb_hip_batch* batches, size_
         list.colOff[list.count] = batch.col_off;
         ++list.count;
         tiles += (batch.n + wordsPerWave - 1) / wordsPerWave;
-        words += batch.n;
-        const bool vec = (ctx->dim % 4 == 0) && (batch.ld % 4 == 0) && (batch.col_off % 4 == 0) &&
-            (reinterpret_cast<uintptr_t>(batch.out) % 16 == 0);
-        const int batchMode = !vec ? OUT_SCALAR : (batch.ld == ctx->dim && batch.col_off == 0) ? OUT_FLAT : OUT_VEC4;
-        // one output mode for the launch: the most general one any batch needs (OUT_SCALAR < OUT_VEC4 < OUT_FLAT)
-        mode = std::min(mode, batchMode);
     }
     list.firstTile[list.count] = tiles;
-    TrainedPlan plan;
-    const int planned = planTrained(ctx, words, ctx->dim, 0, nullptr, false, &plan, 0, false);
-    if (planned != MEMB_HIP_OK) {
-        return planned;
-    }
     TrainedGeometry geometry = plan.geometry;
     geometry.mode = mode;
     if (!geometry.waves) {
         return fail(MEMB_HIP_ERR_INVALID, "decode tables and bitstream slots do not fit into LDS");
     }
-    TrainedParams params = lookupParams(ctx);
+    TrainedParams params = lookupParams(ctx, plan.fine);
     if (!lookupParamsConsistent(ctx, params, geometry)) {
         return fail(MEMB_HIP_ERR_INVALID, "internal error: inconsistent decode geometry");
     }

@@ -430,7 +430,14 @@ def test_several_batches_in_one_launch(native, make_model, storage, bits):
     reader = native.Reader(path)
     checker = oracle.OracleReader(path)
     rng = np.random.default_rng(31)
-    for sizes in ((1000,), (1, 777, 8), (513, 1, 64, 4099, 7, 8, 250, 1031)):
+    # (trained storages: small lists decode with the finer segment index, as one batch of as many words would -- the last
+    # list is past that rule on 256 CUs; every list also with the index forced off and on)
+    cases = [(sizes, 0) for sizes in ((1000,), (1, 777, 8), (513, 1, 64, 4099, 7, 8, 250, 1031), (20000, 15000, 3))]
+    if storage == 'trained':
+        cases += [((1, 777, 8), 1), ((513, 1, 64, 4099, 7, 8, 250, 1031), 1), ((20000, 15000, 3), 2)]
+    for sizes, fine_lanes in cases:
+        if storage == 'trained':
+            reader.set_option('fine_lanes', fine_lanes)
         entries = []
         host_rows = []
         for k, size in enumerate(sizes):
@@ -448,10 +455,10 @@ def test_several_batches_in_one_launch(native, make_model, storage, bits):
         for k, (rows, out) in enumerate(zip(host_rows, outs)):
             expected = checker.rows_embedding(rows)
             if k % 3 == 2:
-                assert bits_equal(out[:, 320:620].cpu().numpy(), expected), (sizes, k)
+                assert bits_equal(out[:, 320:620].cpu().numpy(), expected), (sizes, k, fine_lanes)
                 assert out[:, :320].eq(3.0).all() and out[:, 620:].eq(3.0).all()
             else:
-                assert bits_equal(out.cpu().numpy(), expected), (sizes, k)
+                assert bits_equal(out.cpu().numpy(), expected), (sizes, k, fine_lanes)
     # an empty batch among the others, and an output whose rows are not 16-byte aligned (dim 300, ld 301)
     ids = torch.from_numpy(host_rows[0].view(np.int32)).cuda()
     odd = torch.zeros((len(host_rows[0]), 301), dtype=torch.float32, device='cuda')
@@ -463,4 +470,53 @@ def test_several_batches_in_one_launch(native, make_model, storage, bits):
     assert bits_equal(odd[:, :300].cpu().numpy(), expected) and bits_equal(dense.cpu().numpy(), expected)
     with pytest.raises(ValueError):
         reader.rows_embedding_device_many([(ids, torch.zeros((len(host_rows[0]), 200), dtype=torch.float32, device='cuda'))])
+    assert reader.host_rows_decoded == 0
+
+
+def test_device_lookups_capture_into_a_hip_graph(native, make_model):
+    """The device APIs only enqueue kernels on the caller's stream once a context has been used (first use stages the model
+    and raises the kernels' LDS limit): a lookup, and several lookups in one launch, can be captured into a HIP graph and
+    replayed -- with new row ids in the same buffers -- bit for bit like eager launches (tools/perf/r5/graphs.py times it:
+    a replay saves nothing over an eager launch, the one launch for K lookups does)."""
+    import torch
+    path, words = make_model(6000, 300, 'trained', 4)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(77)
+    sizes = (1000, 37, 2500)
+
+    def fresh_rows():
+        rows = [rng.integers(0, len(words), size=size).astype(np.uint32) for size in sizes]
+        for r in rows:
+            r[rng.integers(0, len(r), size=max(1, len(r) // 20))] = MISSING
+        return rows
+
+    host_rows = fresh_rows()
+    ids = [torch.from_numpy(r.view(np.int32)).cuda() for r in host_rows]
+    single = [torch.zeros((size, 300), dtype=torch.float32, device='cuda') for size in sizes]
+    many = [torch.zeros((size, 300), dtype=torch.float32, device='cuda') for size in sizes]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                     # warm-up on the capture stream, outside the capture
+        for i in range(len(sizes)):
+            reader.rows_embedding_device(ids[i], out=single[i])
+        reader.rows_embedding_device_many(list(zip(ids, many)))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for i in range(len(sizes)):
+            reader.rows_embedding_device(ids[i], out=single[i])
+        reader.rows_embedding_device_many(list(zip(ids, many)))
+    for attempt in range(3):
+        if attempt:
+            host_rows = fresh_rows()
+            for i, r in enumerate(host_rows):
+                ids[i].copy_(torch.from_numpy(r.view(np.int32)))
+        for t in single + many:
+            t.fill_(9.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, r in enumerate(host_rows):
+            expected = checker.rows_embedding(r)
+            assert bits_equal(single[i].cpu().numpy(), expected), (attempt, i)
+            assert bits_equal(many[i].cpu().numpy(), expected), (attempt, i)
     assert reader.host_rows_decoded == 0

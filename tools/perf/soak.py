@@ -25,7 +25,7 @@ while time.time()-start < seconds:
         reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
         reader.set_option('fine_lanes', int(rng.integers(0,3)))   # round 5: the finer segment index by rule / never / always
     for _ in range(int(rng.integers(1,6))):
-        n=int(rng.choice([1,2,17,64,500,513,3000,20000,60000,140000,300000]))
+        n=int(rng.choice([1,2,17,64,500,513,3000,20000,28672,28673,57345,60000,65537,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
         if rng.random()<0.5: batch[::7]=['?']*len(batch[::7])
         want=checker.batch_embedding(batch)

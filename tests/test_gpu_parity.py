@@ -751,6 +751,12 @@ def test_boundary_argument_errors(native, make_model):
         reader.rows_embedding_device(rows, out=torch.empty((4, 8), dtype=torch.float64, device='cuda'))
     with pytest.raises(RuntimeError):
         reader.batch_embedding_into(['a'], np.zeros((1, 4), dtype=np.float32), 0)   # narrower than dim
+    # the measurement switches (skip the decode, skip the output, unused LDS ...) exist in builds with -DMEMB_HIP_MEASURE only
+    for name in ('debug', 'lds_pad', 'no_such_option'):
+        with pytest.raises(RuntimeError, match='unknown option'):
+            reader.set_option(name, 1)
+    with pytest.raises(RuntimeError, match='out of range'):
+        reader.set_option('fine_lanes', 3)
     library = ctypes.CDLL(native.HIP_LIBRARY_PATH)
     library.memb_hip_last_error.restype = ctypes.c_char_p
     context = ctypes.c_void_p(reader._impl.context_handle())

@@ -61,7 +61,7 @@ def test_headline_kernel_resources(kernels):
 
 def test_shipped_library_has_no_measurement_switches(kernels):
     # no cache-policy bits on any store (the store-policy experiments of round 2 used inline assembly), and the
-    # `debug` option does not exist in a build without -DMEMB_HIP_MEASURE (tests/test_cabi.py asks the library)
+    # `debug` option does not exist in a build without -DMEMB_HIP_MEASURE (tests/test_gpu_parity.py::test_boundary_argument_errors asks the library)
     import isa
     text = isa.device_assembly()
     assert ' sc1 nt' not in text and 'off sc0 sc1' not in text

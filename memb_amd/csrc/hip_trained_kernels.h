@@ -202,8 +202,12 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
     meta.segmentBits = segmentField(role.segment, meta.segmentBits, meta.packed2, meta.packed3);
 }
 
+// Scalar registers the one-tile kernels may use (0 = no limit). The hardware admits wavefronts by scalar registers as well
+// as vector ones -- 800 per SIMD, .sgpr_count (this budget minus 2: VCC and friends are counted in) rounded up to 16, plus
+// 16 -- and without a limit the compiler takes 106 for these kernels: six wavefronts per SIMD where 61 vector registers
+// allow eight. 96 -> seven (memb_hip.hip: ONE_TILE_WAVES_PER_CU; DESIGN.md section 5.0 has the measurements of 80, 88 and none).
 #ifndef MEMB_HIP_SGPRS
-#define MEMB_HIP_SGPRS 88
+#define MEMB_HIP_SGPRS 96
 #endif
 #if MEMB_HIP_SGPRS
 #define MEMB_SGPR_BUDGET __attribute__((amdgpu_num_sgpr(MEMB_HIP_SGPRS)))

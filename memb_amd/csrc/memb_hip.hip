@@ -227,8 +227,8 @@ struct TrainedGeometry {
 // admit: 57-61 vector registers would allow 8 per SIMD, but the hardware hands out scalar registers too -- 800 per SIMD
 // in steps of 16 plus 16 (MI355X_MICROARCH.md, "Residency and cooperative launch") -- and the compiler, which does not
 // count that, took 106: SIX per SIMD, 24 per CU, in rounds 1-4 (seen in round 5 as a step in the time of small batches at
-// exactly 24 x CUs tiles). hip_trained_kernels.h now holds these kernels to a budget (MEMB_HIP_SGPRS = 88: .sgpr_count 86,
-// no vector register more): SEVEN per SIMD. A budget of 80 (8 per SIMD) costs two vector registers of spills, 3-5 % on the
+// exactly 24 x CUs tiles). hip_trained_kernels.h now holds these kernels to a budget (MEMB_HIP_SGPRS = 96: .sgpr_count 94,
+// no vector register more, 12 lane spills in the headline kernel's 2 000 instructions; 88 gives the same seven with 20): SEVEN per SIMD. A budget of 80 (8 per SIMD) costs two vector registers of spills, 3-5 % on the
 // chain of a small batch, and in blocks of eight +5 % on a key-order dump (tools/perf/r5/sgprs.sh, residency.sh);
 // tests/test_isa.py pins the seven.
 constexpr uint32_t ONE_TILE_WAVES_PER_CU = 28;

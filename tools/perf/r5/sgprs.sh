@@ -27,7 +27,7 @@ def read(f):
     return rows
 for bits in (4,6):
     t={(b,p):read('gpurun_out/r5_sgprs/%s_%dbit_%d.txt'%(b,bits,p)) for b in ('new','old') for p in (1,2)}
-    print('%d-bit: case, 80 sgprs pass 1/2, 100 sgprs pass 1/2, mean change'%bits)
+    print('%d-bit: case, the tree (MEMB_HIP_SGPRS as shipped) pass 1/2, no budget (build/sgpr100) pass 1/2, mean change'%bits)
     for c in t[('new',1)]:
         a=[t[('new',p)][c] for p in (1,2)]; b=[t[('old',p)][c] for p in (1,2)]
         print('  %-8s %.4f %.4f | %.4f %.4f | %+.1f %%'%(c,a[0],a[1],b[0],b[1],100*(sum(a)/sum(b)-1)))

@@ -215,6 +215,18 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 #define MEMB_SGPR_BUDGET
 #endif
 
+// decode_records_persistent held to the vector registers of N wavefronts per SIMD (0 = the compiler's own 78-85: five, for
+// the nibble-key dense kernel). Measured with 6 (round 5, batch 23, tools/perf/r5/records_waves.sh): 12 bytes of scratch in
+// that kernel, BASELINE configs[1] -0.9 % uncached and +5.6 % cached, the rest of its class -6..+1 %: not taken.
+#ifndef MEMB_HIP_RECORDS_WAVES
+#define MEMB_HIP_RECORDS_WAVES 0
+#endif
+#if MEMB_HIP_RECORDS_WAVES
+#define MEMB_RECORDS_WAVES __attribute__((amdgpu_waves_per_eu(MEMB_HIP_RECORDS_WAVES)))
+#else
+#define MEMB_RECORDS_WAVES
+#endif
+
 #ifndef MEMB_HIP_OUTPUT_BURST
 #define MEMB_HIP_OUTPUT_BURST 5   // 16-byte pieces a lane gathers before it stores them back to back (outputTile)
 #endif
@@ -758,7 +770,7 @@ __device__ __forceinline__ void issueRecordLoads(
 }
 
 template <bool HAS_SUB, int MODE, bool FAST>
-__global__ void decode_records_persistent(TrainedParams p)
+__global__ MEMB_RECORDS_WAVES void decode_records_persistent(TrainedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr bool PACKED = !FAST;

@@ -215,6 +215,15 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 #define MEMB_SGPR_BUDGET
 #endif
 
+// The output burst of decode_records_persistent for nibble keys: its registers decide between five and six wavefronts per
+// SIMD (82 / 78 vector registers with bursts of 5 / 4 in the dense kernel), and the sixth is worth more than the fifth
+// piece of a burst in this kernel's class (65 000 - 131 000 rows; round 5, batch 24, tools/perf/r5/records_waves.sh:
+// 100 000 rows with nothing cached -5.3 % for the 4-bit model, -7 % for the 2-bit one). Byte keys keep the burst of 5
+// (78 registers: six already; with 4 they would run seven and gain nothing: -4..+3 %).
+#ifndef MEMB_HIP_RECORDS_BURST_NIBBLE
+#define MEMB_HIP_RECORDS_BURST_NIBBLE 4
+#endif
+
 // decode_records_persistent held to the vector registers of N wavefronts per SIMD (0 = the compiler's own 78-85: five, for
 // the nibble-key dense kernel). Measured with 6 (round 5, batch 23, tools/perf/r5/records_waves.sh): 12 bytes of scratch in
 // that kernel, BASELINE configs[1] -0.9 % uncached and +5.6 % cached, the rest of its class -6..+1 %: not taken.
@@ -443,7 +452,7 @@ __device__ __forceinline__ void decodeSegment(
 }
 
 // Symbol tile -> fp32 rows: codebook gather and row-contiguous stores.
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, int BURST = MEMB_HIP_OUTPUT_BURST>
 __device__ __forceinline__ void outputTile(
     const TrainedParams& p, const uint32_t* codebookLds, const uint32_t* keyTile, unsigned long long tileBase,
     uint32_t tileWords, uint32_t lane, const LaneRole& role, bool present)
@@ -491,7 +500,6 @@ __device__ __forceinline__ void outputTile(
         // BURST pieces per lane are gathered first and then stored back to back, so a
         // tile reaches memory as one burst of consecutive KiBs rather than one KiB per
         // LDS round trip.
-        constexpr int BURST = MEMB_HIP_OUTPUT_BURST;
         const uint32_t piecesPerWord = p.dim / 4;
         const uint32_t pieces = tileWords * piecesPerWord;
         float* tileOut = p.out + tileBase * p.ld + p.colOff;
@@ -754,8 +762,8 @@ __global__ MEMB_SGPR_BUDGET void decode_trained_batches(TrainedParams p, BatchLi
 // layout only (TrainedParams::recordPieces): a row's address is arithmetic and its segment offsets arrive with its
 // bitstream, so a tile in flight is its row ids and two stream registers (a tile of at most 128 pieces).
 // Timeline of a round: decode tile t out of LDS | wait for the loads issued one decode ago (tile t + 1's regions,
-// tile t + 2's row ids) | store tile t | issue the loads of tile t + 2 (row ids of t + 3). 82 VGPRs: 20 wavefronts
-// per CU. Measured against one tile per wavefront on 100 000 random rows (round 4, batches 1 and 3, two boxes):
+// tile t + 2's row ids) | store tile t | issue the loads of tile t + 2 (row ids of t + 3). 78 VGPRs: 24 wavefronts
+// per CU (nibble keys: 82 and 20 with an output burst of 5, rounds 3-5; MEMB_HIP_RECORDS_BURST_NIBBLE). Measured against one tile per wavefront on 100 000 random rows (round 4, batches 1 and 3, two boxes):
 // 4-bit -4.3..-6 %, 6-bit -8..-9 %, 2-bit -1.5 %; everywhere else the one-tile kernel wins or ties.
 // (Rounds 1-3 also had a general persistent pipeline for every layout, an LDS-DMA form of this one and a persistent
 // union: none of them won a BASELINE configuration by 3 % in round 4's table -- DESIGN.md section 5 -- and they are gone.)
@@ -860,7 +868,7 @@ __global__ MEMB_RECORDS_WAVES void decode_records_persistent(TrainedParams p)
         __builtin_amdgcn_sched_barrier(0);
 
         if (!(measureFlags(p) & 2)) {
-            outputTile<MODE, FAST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowCurrent < p.nRows);
+            outputTile<MODE, FAST, FAST ? MEMB_HIP_RECORDS_BURST_NIBBLE : MEMB_HIP_OUTPUT_BURST>(p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowCurrent < p.nRows);
         }
         __builtin_amdgcn_sched_barrier(0);
 

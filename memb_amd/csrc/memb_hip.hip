@@ -654,7 +654,7 @@ constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below
 // 500 k; tools/perf/r4/batch1.sh, two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
 //   decode_trained (one tile per wavefront at a time, 52-61 VGPRs; 28 wavefronts per CU by its scalar registers, 24 until
 //   round 5: ONE_TILE_WAVES_PER_CU) -- everything, except
-//   2 R < t <= 4 R on row-record models: decode_records_persistent (20 wavefronts per CU, software pipeline):
+//   2 R < t <= 4 R on row-record models: decode_records_persistent (24 wavefronts per CU, software pipeline):
 //       100 000 rows -4.3..-6 % (4-bit), -8..-9 % (6-bit), -1.5 % (2-bit); at 500 k rows it is 3-11 % BEHIND.
 // The general persistent pipeline lost every dump (+2.3 % 4-bit, +4.9 % 2-bit; 6-bit -1.8 % on one box) and every
 // shuffled batch (+1.7..+9.4 %); with it went the per-context timing that chose between the two ("autotune").

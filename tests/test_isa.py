@@ -56,7 +56,9 @@ def test_headline_kernel_resources(kernels):
     assert facts['store_x4'] >= 1 and facts['store_x4_nt'] == 0, facts           # plain 16-byte output stores
     facts = kernels['void (anonymous namespace)::decode_records_persistent<false, 2, true>((anonymous namespace)::TrainedParams)']
     assert facts['private_segment'] == 0 and facts['scratch_ops'] == 0, facts
-    assert facts['vgpr'] <= 96, facts                                            # 5 wavefronts per SIMD: 20 per CU
+    # six wavefronts per SIMD, 24 per CU (an output burst of 4 pieces for nibble keys: with 5 it took 82 registers and ran five)
+    import isa
+    assert isa.waves_per_simd(facts['vgpr'], facts['sgpr_count']) == 6, facts
 
 
 def test_shipped_library_has_no_measurement_switches(kernels):

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round 5: decode_records_persistent held to 80 vector registers (six wavefronts per SIMD, amdgpu_waves_per_eu) against
-# the compiler's own 82-85 (five). Two builds (build/rec6 = `build_measure.py --plain=build/rec6 -DMEMB_HIP_RECORDS_WAVES=6`; the tree),
-# alternating processes.
+# Round 5: decode_records_persistent at six wavefronts per SIMD against five for nibble keys. Two builds, alternating
+# processes: new = the tree (output burst of 4: 78 vector registers), old = OLD_ROOT (default build/recb5 =
+# `build_measure.py --plain=build/recb5 -DMEMB_HIP_RECORDS_BURST_NIBBLE=5`: 82 registers, rounds 3-5's kernel).
+# (Batch 23 ran it with new = a build with -DMEMB_HIP_RECORDS_WAVES=6: the same six by amdgpu_waves_per_eu, 12 bytes of scratch.)
 set -o pipefail
 out=gpurun_out/r5_records_waves
 mkdir -p $out
@@ -9,7 +10,7 @@ export MEMB_SYNTH_DEVICE=0 AB3_ROUNDS=3
 cases=70k,85k,100k,114k,120k,130k,rot70k,rot85k,rot100k,rot114k,rot120k,rot130k
 for pass in 1 2; do
     for build in new old; do
-        root=""; [ $build = new ] && root=build/rec6
+        root=""; [ $build = old ] && root=${OLD_ROOT:-build/recb5}
         for model in "4 2196017" "6 1999995" "2 2196017"; do
             set -- $model
             MEMB_PACKAGE_ROOT=$root AB3= AB3_BITS=$1 AB3_WORDS=$2 AB3_CASES=$cases timeout -k 10 300 python tools/perf/ab3.py > $out/${build}_$1bit_$pass.txt 2>&1 || { tail -20 $out/${build}_$1bit_$pass.txt; exit 1; }

@@ -230,8 +230,15 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 #ifndef MEMB_HIP_RECORDS_WAVES
 #define MEMB_HIP_RECORDS_WAVES 0
 #endif
-#if MEMB_HIP_RECORDS_WAVES
+#ifndef MEMB_HIP_RECORDS_SGPRS
+#define MEMB_HIP_RECORDS_SGPRS 0   // (a scalar-register budget for the same kernel: experiments)
+#endif
+#if MEMB_HIP_RECORDS_WAVES && MEMB_HIP_RECORDS_SGPRS
+#define MEMB_RECORDS_WAVES __attribute__((amdgpu_waves_per_eu(MEMB_HIP_RECORDS_WAVES), amdgpu_num_sgpr(MEMB_HIP_RECORDS_SGPRS)))
+#elif MEMB_HIP_RECORDS_WAVES
 #define MEMB_RECORDS_WAVES __attribute__((amdgpu_waves_per_eu(MEMB_HIP_RECORDS_WAVES)))
+#elif MEMB_HIP_RECORDS_SGPRS
+#define MEMB_RECORDS_WAVES __attribute__((amdgpu_num_sgpr(MEMB_HIP_RECORDS_SGPRS)))
 #else
 #define MEMB_RECORDS_WAVES
 #endif

@@ -177,16 +177,16 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
 /*
  * Tuning knobs of a live context (results never depend on them). Unknown names and values
  * out of range return MEMB_HIP_ERR_INVALID and change nothing.
- *   "waves_per_block" 0 = choose (four; eight for dumps of nibble-key models), or 1 .. 16
+ *   "waves_per_block" 0 = choose (four; eight for batches of more than 524 000 words on 256 CUs), or 1 .. 16
  *   "persistent"      1 (default) = the kernel by batch size: decode_trained (one tile per wavefront at a time), except
- *                     decode_records_persistent for two to four tiles per 16 wavefronts per CU (65 000 - 131 000 words on 256 CUs);
+ *                     decode_records_persistent from the batch that no longer fits the CUs at once up to four tiles per 16
+ *                     wavefronts per CU (57 000 - 131 000 words on 256 CUs);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
  *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
  *                     decodes K tiles one after the other behind one copy of the tables into LDS
  *   "fine_lanes"      0 (default) = a row-record model's finer segment index (about sixteen lanes per word instead of eight:
  *                     the chain of dependent lookups of a batch too small to hide it is shorter) decodes the batches whose
- *                     tiles under it are all resident at once (28 600 words on 256 CUs) and those whose usual tiles just
- *                     miss that (57 000 - 65 500 words), 1 = never, 2 = always
+ *                     tiles under it are all resident at once (28 600 words on 256 CUs), 1 = never, 2 = always
  *   "union_compact"   1 (default) = decode_union_split decodes two nibble-key models through their 4-byte table entries
  *                     (round 5: -2.5 % at 500 000 and 1 000 000 words), 0 = through the 8-byte ones
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split

@@ -217,7 +217,7 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 
 // The output burst of decode_records_persistent for nibble keys: its registers decide between five and six wavefronts per
 // SIMD (82 / 78 vector registers with bursts of 5 / 4 in the dense kernel), and the sixth is worth more than the fifth
-// piece of a burst in this kernel's class (65 000 - 131 000 rows; round 5, batch 24, tools/perf/r5/records_waves.sh:
+// piece of a burst in this kernel's class (57 000 - 131 000 rows; round 5, batch 24, tools/perf/r5/records_waves.sh:
 // 100 000 rows with nothing cached -5.3 % for the 4-bit model, -7 % for the 2-bit one). Byte keys keep the burst of 5
 // (78 registers: six already; with 4 they would run seven and gain nothing: -4..+3 %).
 #ifndef MEMB_HIP_RECORDS_BURST_NIBBLE
@@ -761,9 +761,9 @@ __global__ MEMB_SGPR_BUDGET void decode_trained_batches(TrainedParams p, BatchLi
 }
 
 // ---------------------------------------------------------------------------
-// decode_records_persistent: a software pipeline for batches of two to four tiles per resident wavefront
+// decode_records_persistent: a software pipeline for batches of more than one and up to four tiles per resident wavefront
 // ---------------------------------------------------------------------------
-// The one kernel besides decode_trained that a single model runs (memb_hip.hip: planTrained): batches of 65 000 to
+// The one kernel besides decode_trained that a single model runs (memb_hip.hip: planTrained): batches of 57 000 to
 // 131 000 words on 256 CUs -- BASELINE.json configs[1] -- where every wavefront has two or three tiles and a
 // wavefront with one tile spends its life in the three dependent hops row id -> row region -> decode. Row-record
 // layout only (TrainedParams::recordPieces): a row's address is arithmetic and its segment offsets arrive with its

@@ -654,7 +654,8 @@ constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below
 // 500 k; tools/perf/r4/batch1.sh, two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
 //   decode_trained (one tile per wavefront at a time, 52-61 VGPRs; 28 wavefronts per CU by its scalar registers, 24 until
 //   round 5: ONE_TILE_WAVES_PER_CU) -- everything, except
-//   2 R < t <= 4 R on row-record models: decode_records_persistent (24 wavefronts per CU, software pipeline):
+//   one round of the one-tile kernel (28 x CUs = 1.75 R) < t <= 4 R on row-record models: decode_records_persistent (24
+//   wavefronts per CU, software pipeline):
 //       100 000 rows -4.3..-6 % (4-bit), -8..-9 % (6-bit), -1.5 % (2-bit); at 500 k rows it is 3-11 % BEHIND.
 // The general persistent pipeline lost every dump (+2.3 % 4-bit, +4.9 % 2-bit; 6-bit -1.8 % on one box) and every
 // shuffled batch (+1.7..+9.4 %); with it went the per-context timing that chose between the two ("autotune").
@@ -672,35 +673,38 @@ int planTrained(
     uint32_t wordsPerWave = WAVE / ctx->lanesPerWord;
     const uint64_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint64_t R = uint64_t(ctx->cuCount) * PIPELINE_WAVES_PER_CU;
-    // The finer index, by what fits a CU at once (`resident` = wavefronts per CU at the block size of a small batch, LDS and
-    // registers; x CUs = the tiles of one round):
-    //   (a) batches whose FINE tiles all fit one round (28 600 words on 256 CUs): every wavefront has one tile, the batch is
-    //       one chain of dependent steps per wavefront, and the finer index shortens its longest link, the decode. Round 5
-    //       (tools/perf/r5/batch3.sh, fine_sweep.sh; the usual index = 100 %): 1 000 / 5 000 / 10 000 / 16 000 / 20 000 / 24 000 /
-    //       28 000 rows: 4-bit -11 / -14 / -13 / -6 / -7 / -4 / -4 %, 6-bit -22 / -24 / -17 / -9 / -9 / -6 / -10 %; one row more
-    //       than a round and its second round costs what the index saved: 32 000 / 40 000 / 50 000 rows +6 / +3 / +4 % (4-bit),
-    //       +2 / -1 / -2 % (6-bit);
-    //   (b) batches whose USUAL tiles just miss one round -- more than `resident` x CUs of them, at most a fifth more and at
-    //       most 2 R (57 000 to 65 500 words): the usual index runs a nearly empty second round there (56 000 -> 60 000 rows: 17.3 -> 21.0 us),
-    //       the finer one's tiles are half as long: 60 000 / 65 000 rows -7 / -3 % (4-bit), -9 / -8 % (6-bit). From 2 R tiles
-    //       on decode_records_persistent or the usual index win (70 000 rows +4 / +3 %, 100 000 +4..+14 %, nothing cached
-    //       +21..+41 %).
+    // One round = the tiles the CUs hold at once (`resident` = wavefronts per CU at the block size of a small batch, by LDS
+    // and registers; x CUs). Two edges of the rule are rounds:
+    //   * the FINER INDEX while the batch's fine tiles all fit one round (28 600 words on 256 CUs): every wavefront has one
+    //     tile, the batch is one chain of dependent steps per wavefront, and the finer index shortens its longest link, the
+    //     decode. Round 5 (tools/perf/r5/batch3.sh, fine_rule.sh, fine_rule_hbm.sh; the usual index = 100 %), 1 000 /
+    //     10 000 / 20 000 / 28 000 rows: 4-bit -12 / -13 / -8 / -4 % with the same batch repeated, -15 / -8 / -5 / -5 % with
+    //     nothing cached between launches; 6-bit -15 / -17 / -9 / -8 % and -21 / -13 / -9 / -8 %. One row more than a round
+    //     and its second round costs what the index saved (30 000 rows +9 / +5 %; nothing cached: +16 / +12 %, 50 000 rows +33 %).
+    //   * decode_records_persistent from ONE ROUND OF THE USUAL INDEX on (57 344 words; until the end of round 5: from 2 R =
+    //     65 536): past one round the one-tile kernel runs a nearly empty second one (56 000 -> 60 000 rows: 17.3 -> 21.0 us),
+    //     the pipeline's wavefronts take a second tile instead. 58 000 / 62 000 / 65 000 rows against the one-tile kernel,
+    //     nothing cached: 4-bit -9 / -10 / -11 %, 6-bit -7 / -10 / -12 %; the same batch repeated: -6 / 0 % at 60 000 rows.
+    //     (For a few hours the rule sent this band to the finer index, on measurements of a repeated batch alone: -6..-12 %
+    //     there, +9..+18 % with nothing cached -- 20-32 % behind the pipeline. Batch 26.)
     // (a forced kernel -- option persistent = 2, force = 1 -- wins over the rule, a forced finer index over both)
     bool fineByRule = false;
     if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && force != 1) {
         const uint32_t fineWords = WAVE / ctx->fineLanes;
         const uint64_t fineTiles = (n + fineWords - 1) / fineWords;
         const uint64_t fineRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, fineWords, ld, colOff, out).resident;
-        const uint64_t usualRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, wordsPerWave, ld, colOff, out).resident;
-        fineByRule = fineTiles <= fineRound || (tiles > usualRound && tiles <= std::min<uint64_t>(2 * R, usualRound * 6 / 5));
+        fineByRule = fineTiles <= fineRound;
     }
     plan->fine = mayBeFine && ctx->fineIndex && force != 1 && (ctx->switches.fineLanes == 2 || fineByRule);
+    // (models whose tables leave a CU fewer than 1.5 R wavefronts -- the 8-bit one -- keep the edge at 2 R: not measured there)
+    const uint64_t usualRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, wordsPerWave, ld, colOff, out).resident;
+    const uint64_t pipelineFrom = 2 * usualRound >= 3 * R ? std::min<uint64_t>(2 * R, usualRound) : 2 * R;
     if (plan->fine) {
         wordsPerWave = WAVE / ctx->fineLanes;
     }
     // the pipeline keeps a tile's row regions in two registers per lane: the slot image must fit two 64-lane rounds
     const bool recordsFit = ctx->recordPieces && wordsPerWave * (ctx->slotDwords / 4) <= RECORD_ROUNDS * WAVE;
-    bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > 2 * R && tiles <= 4 * R);
+    bool wantPersistent = ctx->switches.persistent == 2 || (ctx->switches.persistent == 1 && tiles > pipelineFrom && tiles <= 4 * R);
     if (force >= 0) {
         wantPersistent = force != 0;
     }

@@ -77,19 +77,19 @@ def expected_kernel_class(words, words_per_tile, fine_words_per_tile, cus):
     """The kernel a dense batch of `words` words runs with default options (memb_hip.hip planTrained, chooseGeometry;
     DESIGN.md section 5.0 "which kernel owns which configuration") for a row-record model of dim 300 whose tables leave
     every block size the residency the registers allow -- the 2-, 4- and 6-bit models, nibble or byte keys. R = 16
-    wavefronts per CU x CUs, one round = 28 x CUs tiles: decode_records_persistent for 2 R < tiles <= 4 R, else
+    wavefronts per CU x CUs, one round = 28 x CUs tiles: decode_records_persistent for one round < tiles <= 4 R, else
     decode_trained in blocks of four wavefronts, eight for batches of more than 16 R tiles; with the finer index (more lanes
-    per word) while its own tiles fit one round, and where the usual tiles just miss one (more than a round: by at most a
-    fifth, and at most 2 R).
+    per word) while its own tiles fit one round.
     Returns (kernel family, wavefronts per block or None where the rule does not pin them, finer index?)."""
     tiles = (words + words_per_tile - 1) // words_per_tile
     fine_tiles = (words + fine_words_per_tile - 1) // fine_words_per_tile
     resident = 16 * cus
     one_round = ONE_TILE_WAVES_PER_CU * cus
-    fine = fine_tiles <= one_round or one_round < tiles <= min(2 * resident, one_round * 6 // 5)
-    if 2 * resident < tiles <= 4 * resident:
+    if fine_tiles <= one_round:
+        return 'decode_trained<', 4, True
+    if min(2 * resident, one_round) < tiles <= 4 * resident:
         return 'decode_records_persistent<', None, False
-    return 'decode_trained<', 8 if tiles > 16 * resident else 4, fine
+    return 'decode_trained<', 8 if tiles > 16 * resident else 4, False
 
 
 def test_default_path_of_every_batch_size_class(native, full_model):
@@ -133,8 +133,8 @@ def test_default_path_of_every_batch_size_class(native, full_model):
     rng = np.random.default_rng(12)
     seen = set()
     one_round = ONE_TILE_WAVES_PER_CU * cus
-    # the finer index on one side of each of its edges, the usual lanes per word on the other: its own tiles fill one round;
-    # the usual tiles just miss one round ... up to 2 R
+    # the finer index on one side of its edge (its own tiles fill one round), the usual lanes per word on the other; the
+    # one-tile kernel up to one round of the usual tiles, the pipeline from there
     for batch in (one_round * fine_words_per_tile, one_round * fine_words_per_tile + 1,
                   one_round * words_per_tile, one_round * words_per_tile + 1):
         rows = rng.integers(0, count, size=batch).astype(np.uint32)

@@ -1159,8 +1159,7 @@ def test_uniform_tile_kernel(native, make_model):
 @pytest.mark.parametrize('bits,dim', [(4, 300), (2, 300), (6, 300), (8, 300), (4, 128), (6, 100), (4, 52), (4, 1024), (4, 20)])
 def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim):
     """Row-record models carry a second, finer segment index (about sixteen lanes per word; memb_hip.hip: stageIndex,
-    planTrained): batches whose tiles under it fit the CUs at once run decode_trained with it, and so does the band of sizes
-    where the usual tiles just miss that. Same rows as the
+    planTrained): batches whose tiles under it fit the CUs at once run decode_trained with it. Same rows as the
     checker with the index forced on (2), off (1) and by rule (0), for batch sizes on both sides of a tile and of the
     rule's edge, misses included. Reference: src/huffman_table_decoder.h:102-118 (the serial chain being split)."""
     import torch
@@ -1186,14 +1185,12 @@ def test_small_batches_decode_with_the_finer_index(native, make_model, bits, dim
     usual_round = round_of(reader.info(1000))
     reader.set_option('fine_lanes', 0)
     fine_words, usual_words = 64 // small['lanes_per_word'], 64 // large['lanes_per_word']
-    edge = round_of(small) * fine_words                  # (a) the finer index while its tiles fit one round: 28 672 words on 256 CUs
-    # (b) ... and where the usual tiles just miss one round: by up to a fifth, and below 2 R (decode_records_persistent's)
+    edge = round_of(small) * fine_words                  # the finer index while its tiles fit one round: 28 672 words on 256 CUs
+    # (where the usual tiles just miss one round the finer index was the rule for a few hours; it is the pipeline's now)
     island = (usual_round * usual_words, min(2 * 16 * cus, usual_round * 6 // 5) * usual_words)
 
     def expected_lanes(count):
-        usual_tiles = (count + usual_words - 1) // usual_words
-        fine = count <= edge or island[0] // usual_words < usual_tiles <= island[1] // usual_words
-        return small['lanes_per_word'] if fine else large['lanes_per_word']
+        return small['lanes_per_word'] if count <= edge else large['lanes_per_word']
 
     for count in (1, 3, 4, 5, 64, 1000, edge - 1, edge, edge + 9, island[0], island[0] + 1, island[1], island[1] + 1):
         rows = rng.integers(0, len(words), size=count).astype(np.uint32)

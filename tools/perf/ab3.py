@@ -198,20 +198,23 @@ def run_case(reader, case, target):
         return timeit(lambda: reader.rows_embedding_device(rows, out=target), cold)
     if kind == 'random':
         return timeit(lambda: reader.rows_embedding_device(perm, out=target), cold)
-    if kind.startswith('rot'):
+    if kind.startswith('rot') or kind.startswith('hbm'):
         # 'rot<N>k': FOUR different batches of N thousand random rows round-robin into four output buffers -- more than the
         # 256 MB Infinity Cache holds from one turn to the next at 100 k rows: every launch reads from and writes to HBM
+        # 'hbm<N>k': the same with as many batches as it takes to put 640 MB of output between two uses of a buffer -- the
+        # rotating regime for batches too small for four of them to outgrow the cache
         count = int(kind[3:-1]) * 1000
         if kind not in rotating:
             sets = []
-            for k in range(4):
+            how_many = 4 if kind.startswith('rot') else max(4, -(-640000000 // (count * 1200)))
+            for k in range(how_many):
                 ids = perm[(300000 + k * count) % (n - count):][:count].contiguous()
                 sets.append((ids, torch.empty((count, 300), dtype=torch.float32, device='cuda')))
             rotating[kind] = (sets, [0])
         sets, turn = rotating[kind]
 
         def call():
-            ids, target_k = sets[turn[0] % 4]
+            ids, target_k = sets[turn[0] % len(sets)]
             turn[0] += 1
             reader.rows_embedding_device(ids, out=target_k)
         return timeit(call, cold)

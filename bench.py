@@ -263,6 +263,37 @@ class Timer:
         torch.cuda.synchronize()
         return begin.elapsed_time(end) / count
 
+    def graph_burst(self, call, count, run_in_ms=20.0):
+        """As `burst`, with the `count` launches captured into ONE HIP graph and the replay timed: the host's launch rate (5-8 us
+        per Python call on some boxes) is then out of a figure that is about a 5 us kernel. Returns (ms per launch, 'graph'),
+        or burst's figure and 'eager' where the capture fails."""
+        torch = self.torch
+        try:
+            call()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                call()                      # (on the capture stream once, outside the capture)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(count):
+                    call()
+            begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(max(2, int(run_in_ms / 0.5 / max(count, 1)) + 1)):
+                graph.replay()
+            samples = []
+            for _ in range(5):
+                begin.record()
+                graph.replay()
+                end.record()
+                torch.cuda.synchronize()
+                samples.append(begin.elapsed_time(end) / count)
+            return sorted(samples)[len(samples) // 2], 'graph'
+        except Exception:   # noqa: BLE001 -- a runtime that cannot capture is no reason to lose the line
+            torch.cuda.synchronize()
+            return self.burst(call, count, run_in_ms), 'eager'
+
     def bursts(self, call, count, repeats=5, run_in_ms=20.0):
         """`repeats` bursts (each as `burst`, enqueued without a gap after one run-in): sorted averages per launch.
         Minimum, median and average of a short kernel then all come from ONE method."""
@@ -941,9 +972,14 @@ def all_configs(args, memb_amd, synthetic, headline, timer, library, torch, np, 
         picks = batch_rows(len(reader4), count, np)
         ids = torch.from_numpy(picks.view(np.int32)).cuda()
         target = torch.empty((count, reader4.dim), dtype=torch.float32, device='cuda')
-        ms = timer.burst(lambda: reader4.rows_embedding_device(ids, out=target), 100 if count <= 100000 else 30)
+        # (up to 10 000 rows the launches are replayed from ONE HIP graph: a 5 us kernel against 5-8 us per Python call on some hosts)
+        if count <= 10000:
+            ms, launched = timer.graph_burst(lambda: reader4.rows_embedding_device(ids, out=target), 100)
+        else:
+            ms, launched = timer.burst(lambda: reader4.rows_embedding_device(ids, out=target), 100 if count <= 100000 else 30), 'eager'
         nbytes = algorithmic_bytes(library, reader4, picks)
         small.append({'batch': count, 'kernel': reader4.info(count)['kernel'], 'lanes_per_word': reader4.info(count)['lanes_per_word'], 'us_per_launch': ms * 1e3,
+                      'launched': launched,
                       'embeddings_per_s': count / (ms * 1e-3), 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
         del ids, target
     results[-1]['small_batches_of_the_same_model'] = small

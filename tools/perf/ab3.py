@@ -179,10 +179,24 @@ if any(c.endswith('union') for c in cases):
         ids.append(torch.from_numpy(picks.view(np.int32)).cuda())
     merged = torch.empty((batch, 600), dtype=torch.float32, device='cuda')
     union = (second, ids, merged, batch)
+    # 'hbmunion': other ids and another output buffer every launch, 640 MB of output between two uses of one
+    union_sets = []
+    if 'hbmunion' in cases:
+        for k in range(max(4, -(-640000000 // (batch * 2400)))):
+            more = []
+            for count in (n, len(second)):
+                picks = rng.integers(0, count, size=batch).astype(np.uint32)
+                picks[rng.random(batch) < 0.25] = 0xFFFFFFFF
+                more.append(torch.from_numpy(picks.view(np.int32)).cuda())
+            union_sets.append((more, torch.empty((batch, 600), dtype=torch.float32, device='cuda')))
+    union_turn = [0]
 
 
-def run_union(reader):
+def run_union(reader, rotate=False):
     second, ids, merged, batch = union
+    if rotate:
+        ids, merged = union_sets[union_turn[0] % len(union_sets)]
+        union_turn[0] += 1
     done = _memb.union_rows_to_device(
         [reader._impl, second._impl], [ids[0].data_ptr(), ids[1].data_ptr()], [0, 300], batch, merged.data_ptr(),
         merged.stride(0), torch.cuda.current_stream().cuda_stream, False)
@@ -194,6 +208,8 @@ def run_case(reader, case, target):
     kind = case[4:] if cold else case
     if kind == 'union':
         return timeit(lambda: run_union(reader), cold)
+    if kind == 'hbmunion':
+        return timeit(lambda: run_union(reader, True), cold)
     if kind == 'sorted':
         return timeit(lambda: reader.rows_embedding_device(rows, out=target), cold)
     if kind == 'random':

@@ -182,6 +182,9 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *                     decode_records_persistent from the batch that no longer fits the CUs at once up to four tiles per 16
  *                     wavefronts per CU (57 000 - 131 000 words on 256 CUs);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
+ *   "pipeline_tiles"  0 (default) = decode_records_persistent runs as many wavefronts as the CUs hold and each strides over the
+ *                     tiles; K = every wavefront takes K tiles and exits (shuffled batches of a million rows and more: -2..-4 %
+ *                     with persistent = 2 and K = 3 or 4; key-order dumps tie)
  *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
  *                     decodes K tiles one after the other behind one copy of the tables into LDS
  *   "fine_lanes"      0 (default) = a row-record model's finer segment index (about sixteen lanes per word instead of eight:

@@ -122,6 +122,8 @@ struct Switches {
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
     uint32_t unionCompact = 1;     // MEMB_HIP_UNION_COMPACT: decode_union_split of two nibble-key models through their 4-byte tables
                                    // (6 KiB of LDS image per block instead of 8, one ds_read_b32 per symbol): 1 (default) / 0
+    uint32_t pipelineTiles = 0;    // option pipeline_tiles: tiles per wavefront of decode_records_persistent: 0 = by rule (planTrained:
+                                   // a grid of resident wavefronts for its own class, PIPELINE_DUMP_TILES for key-order dumps), K = a grid of tiles / K wavefronts
     uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
     uint32_t ldsPad = 0;           // option lds_pad, builds with -DMEMB_HIP_MEASURE only: unused LDS bytes added to every block of
@@ -483,7 +485,8 @@ hipError_t registerWavesPerCu(TrainedKernel kernel, uint32_t* waves, int* numReg
 // launch(blocks) enqueues `kernel` (threads per block, ldsBytes of dynamic LDS) with that many blocks.
 template <typename Launch>
 hipError_t launchPersistentGeneric(
-    const memb_hip_ctx* ctx, const void* kernel, Launch launch, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes)
+    const memb_hip_ctx* ctx, const void* kernel, Launch launch, uint32_t tileBlocks, uint32_t threads, uint32_t ldsBytes,
+    uint32_t tilesPerWave = 0)
 {
     int blocksPerCu = 0;
     {
@@ -512,18 +515,23 @@ hipError_t launchPersistentGeneric(
     // of which 44 % run a third round -- is slower: 100 000 uncached rows +10 % (4-bit), +15 % (6-bit, 2-bit). More wavefronts
     // in flight beat an even last round.)
     const uint32_t resident = static_cast<uint32_t>(blocksPerCu) * ctx->cuCount;
-    launch(std::min(tileBlocks, resident));
+    uint32_t blocks = std::min(tileBlocks, resident);
+    if (tilesPerWave) {
+        // NOT a resident grid: every wavefront takes `tilesPerWave` tiles, a grid apart, and exits; the dispatcher refills
+        blocks = std::max<uint32_t>(1, (tileBlocks + tilesPerWave - 1) / tilesPerWave);
+    }
+    launch(blocks);
     return hipGetLastError();
 }
 
 hipError_t launchPersistent(
     const memb_hip_ctx* ctx, TrainedKernel kernel, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads,
-    uint32_t ldsBytes, hipStream_t stream)
+    uint32_t ldsBytes, hipStream_t stream, uint32_t tilesPerWave = 0)
 {
     return launchPersistentGeneric(
         ctx, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
-        }, tileBlocks, threads, ldsBytes);
+        }, tileBlocks, threads, ldsBytes, tilesPerWave);
 }
 
 template <int MODE>
@@ -643,6 +651,7 @@ struct TrainedPlan {
     TrainedGeometry geometry{};
     TrainedKernel kernel = nullptr;      // persistent only
     uint32_t registerWavesPerCu = 32;    // persistent only: what the kernel's registers allow
+    uint32_t pipelineTiles = 0;          // persistent only: 0 = a grid of resident wavefronts, K = a grid of tiles / K wavefronts
     int numRegs = 0;
 };
 
@@ -709,6 +718,7 @@ int planTrained(
         wantPersistent = force != 0;
     }
     plan->persistent = recordsFit && wantPersistent && !plan->fine;
+    plan->pipelineTiles = ctx->switches.pipelineTiles;
     // (randomOrder: the caller says the rows come in no particular order -- MEMB_HIP_ROWS_IN_RANDOM_ORDER -- and eight
     // wavefronts per block only pay for key order)
     const uint32_t preferred = !plan->persistent && tiles > 16 * R && !randomOrder ? 8u : 4u;
@@ -769,7 +779,7 @@ int launchTrained(
     hipError_t status;
     if (persistent) {
         const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
-        status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
+        status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream, plan.pipelineTiles);
     } else {
         params.tilesPerWave = oneTileSteps(ctx, tiles, 4u * (params.tableDwords + params.codebookDwords), false);
         const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
@@ -2130,6 +2140,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
     } else if (key == "union_compact" && value <= 1) {
         ctx->switches.unionCompact = static_cast<uint32_t>(value);
+    } else if (key == "pipeline_tiles" && value <= 64) {
+        ctx->switches.pipelineTiles = static_cast<uint32_t>(value);
     } else if (key == "fine_lanes" && value <= 2) {
         ctx->switches.fineLanes = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {

@@ -288,6 +288,44 @@ __global__ void tile_experiment(Params p, int rowsPerTile, int delay, int order)
     }
 }
 
+// Round 5, batch 28: T tiles per wavefront WITHOUT a persistent grid -- a block of W wavefronts owns W x T consecutive tiles, in
+// step t wavefront w takes tile t x W + w of them (the block's wavefronts stay next to each other, as in decode_trained with
+// tiles_per_wave = T); prefetch = 1: the records of step t + 1 are loaded (two registers per lane) before step t's tile is stored.
+// The question: would a depth-one pipeline inside short-lived blocks -- what decode_union_split has with T = 2 -- beat one tile
+// per wavefront for a single model?
+template <int MODE>   // 1 = sequential records, 2 = random records
+__global__ void tiles_chunked(Params p, int steps, int prefetch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t wavesPerBlock = blockDim.x / WAVE;
+    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
+    const unsigned long long first = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock * steps + wave;
+    uint32_t* slots = dynamicLds + wave * 4 * TILE_RECORD_PIECES;
+    u32x4 a = {0, 0, 0, 0};
+    u32x4 b = {0, 0, 0, 0};
+    if (first < tiles) {
+        loadTile<MODE == 2>(p, first, lane, a, b, p.records, p.ids);
+    }
+    for (int t = 0; t < steps; ++t) {
+        const unsigned long long tile = first + static_cast<unsigned long long>(t) * wavesPerBlock;
+        if (tile >= tiles) {
+            break;
+        }
+        stageTile(slots, lane, a, b);
+        const unsigned long long next = tile + wavesPerBlock;
+        if (prefetch && t + 1 < steps && next < tiles) {
+            loadTile<MODE == 2>(p, next, lane, a, b, p.records, p.ids);   // in flight during the stores
+        }
+        storeTile<true>(p.out, p.words, tile, lane, slots);
+        __builtin_amdgcn_wave_barrier();
+        if (!prefetch && t + 1 < steps && next < tiles) {
+            loadTile<MODE == 2>(p, next, lane, a, b, p.records, p.ids);
+        }
+    }
+}
+
 // Round 5: wavefronts that STORE are not the ones that LOAD. A persistent block of W wavefronts, the
 // first `loaders` of which do nothing but fetch row records into an LDS double buffer while the others do nothing but
 // drain finished tiles with stores (the write-only persistent pattern, which is the fastest tile pattern some boxes
@@ -516,6 +554,32 @@ int memb_ceiling_store_experiment(float* out, unsigned long long words, int expe
     const unsigned long long blocks = (waves * WAVE + threads - 1) / threads;
     hipLaunchKernelGGL(store_experiment, dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<float4*>(out), pieces, experiment, stores, delay);
+    return static_cast<int>(hipGetLastError());
+}
+
+// tiles_chunked: W wavefronts per block, `steps` tiles per wavefront, prefetch 0 / 1; ids = null: consecutive rows
+int memb_ceiling_chunked(
+    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int wavesPerBlock,
+    int steps, int prefetch, void* stream)
+{
+    if (!out || !records || words == 0 || wavesPerBlock < 1 || wavesPerBlock > 16 || steps < 1 || steps > 64) {
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    Params p{};
+    p.out = out;
+    p.words = words;
+    p.records = static_cast<const u32x4*>(records);
+    p.rows = rows;
+    p.ids = ids;
+    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
+    const unsigned long long perBlock = static_cast<unsigned long long>(wavesPerBlock) * steps;
+    const uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
+    const uint32_t ldsBytes = static_cast<uint32_t>(wavesPerBlock) * TILE_RECORD_PIECES * 16;
+    if (ids) {
+        hipLaunchKernelGGL(tiles_chunked<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch);
+    } else {
+        hipLaunchKernelGGL(tiles_chunked<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch);
+    }
     return static_cast<int>(hipGetLastError());
 }
 

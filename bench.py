@@ -327,6 +327,9 @@ CEILING_PATTERNS = (
     (4, 'persistent_tile_fill', '16 resident wavefronts per CU walk the tiles, stores only: the store pattern of a persistent kernel (decode_records_persistent; rounds 1-3: the general pipeline)'),
     (5, 'persistent_tile_fill_sequential_records', 'persistent_tile_fill + sequential records, next tile\'s loads in flight during the stores'),
     (6, 'persistent_tile_fill_random_records', 'persistent_tile_fill + random records, same prefetch'),
+    (10, 'two_tiles_sequential_records', 'pattern 5 with a grid of tiles / 2 wavefronts instead of a resident one: two tiles per wavefront half a batch apart, the second '
+                                         'tile\'s records in flight during the first tile\'s stores, then exit (round 5, batch 28: the fastest tile pattern found so far)'),
+    (11, 'two_tiles_random_records', 'the same behind random records'),
 )
 
 
@@ -1463,6 +1466,14 @@ def main():
         merged = torch.empty((min(500000, n), 2 * dim), dtype=torch.float32, device='cuda') if dim == 300 else None
         ceilings = box_ceilings(torch, timer, out, n, union=(merged, merged.shape[0]) if merged is not None else None) if dim == 300 else None
         del merged
+        if ceilings:
+            # the timed kernel against the FASTEST pattern with the same reads this box has shown (a key-order dump: sequential records)
+            candidates = {key: ceilings[key]['ms'] for key in ('tile_fill_sequential_records', 'persistent_tile_fill_sequential_records',
+                                                               'two_tiles_sequential_records') if key in ceilings}
+            if candidates:
+                best = min(candidates, key=candidates.get)
+                ceilings['kernel_against_the_fastest_pattern'] = {
+                    'pattern': best, 'pattern_ms': candidates[best], 'kernel_avg_ms': kernel_avg_ms, 'kernel_over_pattern': kernel_avg_ms / candidates[best]}
 
     configs = None
     if world_size == 1 and not args.no_configs:

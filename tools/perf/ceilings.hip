@@ -17,6 +17,8 @@
 //   6  4 + random records, same prefetch
 //   7  union shape: a tile is 4 merged rows of 600 floats (9600 B), 8 records at random rows of TWO arrays
 //   8, 9  uniform-storage shapes (320-byte records): one row per wavefront / eight rows per wavefront
+//   10, 11  5 / 6 with a grid of tiles / 2 wavefronts instead of a resident one: two tiles per wavefront, half a batch apart, the
+//      second tile's records in flight during the first tile's stores, then exit (round 5, batch 28: the fastest tile pattern found)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (build_native.py). gfx950 only.
 #include <hip/hip_runtime.h>
@@ -294,14 +296,22 @@ __global__ void tile_experiment(Params p, int rowsPerTile, int delay, int order)
 // The question: would a depth-one pipeline inside short-lived blocks -- what decode_union_split has with T = 2 -- beat one tile
 // per wavefront for a single model?
 template <int MODE>   // 1 = sequential records, 2 = random records
-__global__ void tiles_chunked(Params p, int steps, int prefetch)
+__global__ void tiles_chunked(Params p, int steps, int prefetch, int fronts)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = threadIdx.x / WAVE;
     const uint32_t wavesPerBlock = blockDim.x / WAVE;
     const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
-    const unsigned long long first = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock * steps + wave;
+    // fronts F > 1: the grid writes F regions of the output at once -- groups of eight consecutive blocks (one per XCD) take
+    // turns between the F equal parts of the batch (is it the SECOND write front that the strided pattern gains from?)
+    unsigned long long chunk = blockIdx.x;
+    if (fronts > 1) {
+        const unsigned long long group = blockIdx.x / 8;
+        const unsigned long long perFront = (static_cast<unsigned long long>(gridDim.x) / 8 + fronts - 1) / fronts;   // groups per front
+        chunk = ((group % fronts) * perFront + group / fronts) * 8 + blockIdx.x % 8;
+    }
+    const unsigned long long first = chunk * wavesPerBlock * steps + wave;
     uint32_t* slots = dynamicLds + wave * 4 * TILE_RECORD_PIECES;
     u32x4 a = {0, 0, 0, 0};
     u32x4 b = {0, 0, 0, 0};
@@ -452,7 +462,7 @@ int memb_ceiling_launch(
     const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
     const uint32_t tileBlocks = static_cast<uint32_t>((tiles + 3) / 4);
     const uint32_t resident = static_cast<uint32_t>(computeUnits) * 4;   // 4 blocks of 4 wavefronts per CU = 16 wavefronts
-    if ((pattern >= 2 && pattern != 4 && (!records || !rows)) || ((pattern == 3 || pattern == 6 || pattern == 7) && !ids) ||
+    if ((pattern >= 2 && pattern != 4 && (!records || !rows)) || ((pattern == 3 || pattern == 6 || pattern == 7 || pattern == 11) && !ids) ||
         (pattern == 7 && (!records2 || !ids2)) || !out || words == 0) {
         return static_cast<int>(hipErrorInvalidValue);
     }
@@ -471,6 +481,12 @@ int memb_ceiling_launch(
         case 6: hipLaunchKernelGGL(tiles_persistent<2>, dim3(tileBlocks < resident ? tileBlocks : resident), dim3(256), 0, s, p); break;
         case 8:   // (records: rows x 320 bytes here; ids may be null = consecutive rows)
             hipLaunchKernelGGL(uniform_rows_per_wave<1>, dim3(static_cast<uint32_t>((words + 3) / 4)), dim3(256), 0, s, p);
+            break;
+        case 10:   // two tiles per wavefront, a grid apart, the second one's records in flight during the first one's stores; then exit
+            hipLaunchKernelGGL(tiles_persistent<1>, dim3((tileBlocks + 1) / 2), dim3(256), 0, s, p);
+            break;
+        case 11:
+            hipLaunchKernelGGL(tiles_persistent<2>, dim3((tileBlocks + 1) / 2), dim3(256), 0, s, p);
             break;
         case 9:
             hipLaunchKernelGGL(uniform_rows_per_wave<8>, dim3(static_cast<uint32_t>(((words + 7) / 8 + 3) / 4)), dim3(256), 0, s, p);
@@ -560,9 +576,9 @@ int memb_ceiling_store_experiment(float* out, unsigned long long words, int expe
 // tiles_chunked: W wavefronts per block, `steps` tiles per wavefront, prefetch 0 / 1; ids = null: consecutive rows
 int memb_ceiling_chunked(
     float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int wavesPerBlock,
-    int steps, int prefetch, void* stream)
+    int steps, int prefetch, int fronts, void* stream)
 {
-    if (!out || !records || words == 0 || wavesPerBlock < 1 || wavesPerBlock > 16 || steps < 1 || steps > 64) {
+    if (!out || !records || words == 0 || wavesPerBlock < 1 || wavesPerBlock > 16 || steps < 1 || steps > 64 || fronts < 1 || fronts > 64) {
         return static_cast<int>(hipErrorInvalidValue);
     }
     Params p{};
@@ -573,12 +589,15 @@ int memb_ceiling_chunked(
     p.ids = ids;
     const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
     const unsigned long long perBlock = static_cast<unsigned long long>(wavesPerBlock) * steps;
-    const uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
+    uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
+    if (fronts > 1) {
+        blocks = (blocks + 8 * fronts - 1) / (8 * fronts) * (8 * fronts);   // (whole groups per front; surplus blocks find no tile)
+    }
     const uint32_t ldsBytes = static_cast<uint32_t>(wavesPerBlock) * TILE_RECORD_PIECES * 16;
     if (ids) {
-        hipLaunchKernelGGL(tiles_chunked<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch);
+        hipLaunchKernelGGL(tiles_chunked<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
     } else {
-        hipLaunchKernelGGL(tiles_chunked<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch);
+        hipLaunchKernelGGL(tiles_chunked<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
     }
     return static_cast<int>(hipGetLastError());
 }

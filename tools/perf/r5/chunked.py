@@ -15,7 +15,7 @@ build_native.build_ceilings()
 library = ctypes.CDLL(build_native.CEILINGS_LIBRARY)
 library.memb_ceiling_chunked.restype = ctypes.c_int
 library.memb_ceiling_chunked.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p,
-                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 library.memb_ceiling_launch.restype = ctypes.c_int
 library.memb_ceiling_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -41,10 +41,10 @@ def reference(pattern):
     return median(call)
 
 
-def chunked(waves, steps, prefetch, random):
+def chunked(waves, steps, prefetch, random, fronts=1):
     def call():
         status = library.memb_ceiling_chunked(out.data_ptr(), words, records.data_ptr(), 2196017, ids.data_ptr() if random else None,
-                                              waves, steps, prefetch, stream)
+                                              waves, steps, prefetch, fronts, stream)
         assert status == 0, status
     return median(call)
 
@@ -74,3 +74,11 @@ for steps in (2, 3):
     a, b = strided(5), strided(6)
     print('T = %d, tiles a grid apart (prefetch): consecutive %.4f ms %+.1f %%   random %.4f ms %+.1f %%' % (
         steps, a, 100 * (a / sequential - 1), b, 100 * (b / scattered - 1)), flush=True)
+
+# one tile per wavefront, but the grid writes F regions of the batch at once (groups of eight blocks take turns between F parts)
+for waves in (4, 8):
+    for fronts in (2, 4, 8):
+        a = chunked(waves, 1, 0, False, fronts)
+        b = chunked(waves, 1, 0, True, fronts)
+        print('one tile per wavefront, blocks of %d, %d write fronts: consecutive %.4f ms %+.1f %%   random %.4f ms %+.1f %%' % (
+            waves, fronts, a, 100 * (a / sequential - 1), b, 100 * (b / scattered - 1)), flush=True)

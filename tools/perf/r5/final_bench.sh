@@ -26,5 +26,7 @@ for b in line['word_search']['batches']:
     print('%-36s host %.3f ms device %.3f ms x%.1f' % (b['batch'], b['host_ms'], b['device_ms'], b['speedup']))
 print('host_api batch %.1f ms, 100k %.2f ms; cpu_baseline %.3g emb/s on %d cores' % (line['host_api']['batch_seconds'] * 1e3, line['host_api']['sample_seconds'] * 1e3, line['cpu_baseline']['value'], line['cpu_baseline']['cores']))
 c = r['box_ceilings']
-print('ceilings: linear %.4f tile %.4f +seq %.4f +rand %.4f union %.4f' % (c['linear_fill']['ms'], c['tile_fill']['ms'], c['tile_fill_sequential_records']['ms'], c['tile_fill_random_records']['ms'], c['union_tile_fill_random_records']['ms']))
+print('ceilings: linear %.4f tile %.4f +seq %.4f +rand %.4f union %.4f | two tiles +seq %.4f +rand %.4f | kernel / fastest pattern %.3f (%s)' % (
+    c['linear_fill']['ms'], c['tile_fill']['ms'], c['tile_fill_sequential_records']['ms'], c['tile_fill_random_records']['ms'], c['union_tile_fill_random_records']['ms'],
+    c['two_tiles_sequential_records']['ms'], c['two_tiles_random_records']['ms'], c['kernel_against_the_fastest_pattern']['kernel_over_pattern'], c['kernel_against_the_fastest_pattern']['pattern']))
 PY

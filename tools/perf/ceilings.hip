@@ -336,6 +336,50 @@ __global__ void tiles_chunked(Params p, int steps, int prefetch, int fronts)
     }
 }
 
+// Round 5, batch 29: what separates the records pipeline's memory skeleton from the two-tile pattern? tiles_persistent<1 / 2> again,
+// T tiles per wavefront a grid apart, plus -- one at a time -- what the kernel has and the pattern has not:
+//   copyBytes  a block-wide copy of that many bytes from global memory into LDS and a block barrier in front (tables + codebook: 6 KiB)
+//   padBytes   unused LDS per block (fewer resident wavefronts: 15.5 KiB per block of four in the kernel; registers cap it at 24 per CU)
+//   viaIds     row numbers come from an array even for consecutive rows (a dependent load in front of every tile's records)
+template <int MODE>
+__global__ void tiles_skeleton(Params p, const u32x4* tables, uint32_t copyPieces, uint32_t slotOffsetDwords, int viaIds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x / WAVE;
+    if (copyPieces) {
+        for (uint32_t q = threadIdx.x; q < copyPieces; q += blockDim.x) {
+            *reinterpret_cast<u32x4*>(dynamicLds + 4 * q) = tables[q];
+        }
+        __syncthreads();
+    }
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
+    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
+    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
+    uint32_t* slots = dynamicLds + slotOffsetDwords + wave * 4 * TILE_RECORD_PIECES;
+    u32x4 a = {0, 0, 0, 0};
+    u32x4 b = {0, 0, 0, 0};
+    if (tile < tiles) {
+        if (MODE == 2 || viaIds) {
+            loadTile<true>(p, tile, lane, a, b, p.records, p.ids);
+        } else {
+            loadTile<false>(p, tile, lane, a, b, p.records, p.ids);
+        }
+    }
+    for (; tile < tiles; tile += stride) {
+        stageTile(slots, lane, a, b);
+        if (tile + stride < tiles) {
+            if (MODE == 2 || viaIds) {
+                loadTile<true>(p, tile + stride, lane, a, b, p.records, p.ids);
+            } else {
+                loadTile<false>(p, tile + stride, lane, a, b, p.records, p.ids);
+            }
+        }
+        storeTile<true>(p.out, p.words, tile, lane, slots);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Round 5: wavefronts that STORE are not the ones that LOAD. A persistent block of W wavefronts, the
 // first `loaders` of which do nothing but fetch row records into an LDS double buffer while the others do nothing but
 // drain finished tiles with stores (the write-only persistent pattern, which is the fastest tile pattern some boxes
@@ -598,6 +642,43 @@ int memb_ceiling_chunked(
         hipLaunchKernelGGL(tiles_chunked<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
     } else {
         hipLaunchKernelGGL(tiles_chunked<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+// tiles_skeleton: T tiles per wavefront (grid = tile blocks / T), blocks of four; ids: row numbers (random rows, or consecutive ones
+// with viaIds = 1); tables: copyBytes of device memory to copy into LDS per block (may be null when copyBytes = 0)
+int memb_ceiling_skeleton(
+    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int randomRows, int viaIds,
+    int tilesPerWave, const void* tables, unsigned int copyBytes, unsigned int padBytes, void* stream)
+{
+    if (!out || !records || words == 0 || tilesPerWave < 1 || copyBytes % 16 || padBytes % 16 || copyBytes + padBytes > 120 * 1024 ||
+        ((randomRows || viaIds) && !ids) || (copyBytes && !tables)) {
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    Params p{};
+    p.out = out;
+    p.words = words;
+    p.records = static_cast<const u32x4*>(records);
+    p.rows = rows;
+    p.ids = ids;
+    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t tileBlocks = static_cast<uint32_t>((tiles + 3) / 4);
+    const uint32_t blocks = (tileBlocks + tilesPerWave - 1) / tilesPerWave;
+    const uint32_t slotOffsetDwords = (copyBytes + padBytes) / 4;
+    const uint32_t ldsBytes = copyBytes + padBytes + 4 * TILE_RECORD_PIECES * 16;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tiles_skeleton<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tiles_skeleton<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    if (randomRows) {
+        hipLaunchKernelGGL(tiles_skeleton<2>, dim3(blocks), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), p,
+                           static_cast<const u32x4*>(tables), copyBytes / 16, slotOffsetDwords, viaIds);
+    } else {
+        hipLaunchKernelGGL(tiles_skeleton<1>, dim3(blocks), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), p,
+                           static_cast<const u32x4*>(tables), copyBytes / 16, slotOffsetDwords, viaIds);
     }
     return static_cast<int>(hipGetLastError());
 }

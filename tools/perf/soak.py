@@ -24,6 +24,7 @@ while time.time()-start < seconds:
         reader.set_option('tiles_per_wave', int(rng.choice([0,0,1,2,3,7]))); reader.set_option('persistent', int(rng.integers(0,3)))
         reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
         reader.set_option('fine_lanes', int(rng.integers(0,3)))   # round 5: the finer segment index by rule / never / always
+        reader.set_option('pipeline_tiles', int(rng.choice([0,0,1,2,3,7])))   # the pipeline's grid: resident / K tiles per wavefront
     for _ in range(int(rng.integers(1,6))):
         n=int(rng.choice([1,2,17,64,500,513,3000,20000,28672,28673,57345,60000,65537,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]

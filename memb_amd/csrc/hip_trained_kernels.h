@@ -1186,7 +1186,11 @@ __global__ MEMB_SGPR_BUDGET void decode_union_split(UnionParams u)
 
     const uint32_t half = both.wordsPerWave / 2;   // words of a tile
     // both.tilesPerWave tiles one after the other (tiles wave, wave + W, ... of the block's run), as decode_trained
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * both.tilesPerWave) + wave;
+    // (measurement builds, flag 0x8000: the wavefront's tiles a GRID apart instead -- round 5, batch 31)
+    const bool gridApart = (measureFlags(u.model[0]) & 0x8000) != 0;
+    const unsigned long long tileStride = gridApart ? static_cast<unsigned long long>(gridDim.x) * wavesPerBlock : wavesPerBlock;
+    unsigned long long tile = gridApart ? static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave
+                                        : static_cast<unsigned long long>(blockIdx.x) * (wavesPerBlock * both.tilesPerWave) + wave;
     const bool active = tile * half < both.n;
     // The block's copy of two tables and two codebooks into LDS (8 KiB for two nibble-key models) and the first tile's
     // dependent hops (row ids -> row regions) do not need each other. Union batches are random lookups -- the case in
@@ -1269,7 +1273,7 @@ __global__ MEMB_SGPR_BUDGET void decode_union_split(UnionParams u)
     // A pipeline of depth one over the wavefront's T tiles: while tile k is decoded and stored, the row regions of tile
     // k + 1 are in flight (two registers per lane) and the row ids of tile k + 2 behind them.
     uint32_t row = active ? loadRow(tile, lane) : MISSING;
-    uint32_t rowNext = active && both.tilesPerWave > 1 ? loadRow(tile + wavesPerBlock, lane) : MISSING;
+    uint32_t rowNext = active && both.tilesPerWave > 1 ? loadRow(tile + tileStride, lane) : MISSING;
     u32x4 image0 = {0, 0, 0, 0};
     u32x4 image1 = {0, 0, 0, 0};
     if (copyInFlight && !(measure & 0x4000)) {
@@ -1302,7 +1306,7 @@ __global__ MEMB_SGPR_BUDGET void decode_union_split(UnionParams u)
         }
     }
 #pragma nounroll
-    for (uint32_t step = 0; step < both.tilesPerWave; ++step, tile += wavesPerBlock) {
+    for (uint32_t step = 0; step < both.tilesPerWave; ++step, tile += tileStride) {
         const unsigned long long tileBase = tile * half;
         if (tileBase >= both.n) {
             break;
@@ -1322,7 +1326,7 @@ __global__ MEMB_SGPR_BUDGET void decode_union_split(UnionParams u)
             row = checked(rowNext, lane);
             issueRegions(row, lane, piece0, piece1);
             if (step + 2 < both.tilesPerWave) {
-                rowNext = loadRow(tile + 2 * wavesPerBlock, lane);
+                rowNext = loadRow(tile + 2 * tileStride, lane);
             }
         }
 

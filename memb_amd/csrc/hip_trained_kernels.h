@@ -62,7 +62,8 @@ struct TrainedParams {
 // Measurement switches, TrainedParams::debugFlags (option `debug` / MEMB_HIP_DEBUG): bit 0 skip the decode, bit 1 skip
 // the output, bit 2 skip the row id / index / bitstream loads (the decoder then chews on whatever LDS holds: output values
 // are garbage, the access pattern is kept), bit 13 (0x2000) store constants instead of gathering centroids from LDS,
-// bit 14 (0x4000) no copy of table and codebook into LDS. They exist in builds with -DMEMB_HIP_MEASURE only
+// bit 14 (0x4000) no copy of table and codebook into LDS, bit 15 (0x8000) decode_union_split's tiles per wavefront a grid apart.
+// They exist in builds with -DMEMB_HIP_MEASURE only
 // (tools/perf/build_measure.py): the shipped library folds every one of these branches away, so no environment
 // variable or option can make it write anything but the decoded rows.
 __device__ __forceinline__ uint32_t measureFlags(const TrainedParams& p)

@@ -97,6 +97,17 @@ struct WordPointers {
 // word and little else: every thread prefetches the objects a few words ahead.
 // onChunk(firstWord, words) is called on the calling thread for consecutive runs of finished jobs, in order, while
 // later jobs are still being filled: the lookups of a run overlap the filling of the next.
+// The pool threads read str objects WITHOUT the GIL, relying on the calling thread's hold of it to keep the list and its
+// strings from changing, and on the object layout of the CPython versions this was written against. Where either does
+// not hold -- a free-threaded build, another interpreter, a CPython newer than the layouts known here -- every word goes
+// through PyUnicode_AsUTF8AndSize on the calling thread instead (fillJobWithApi).
+#if defined(Py_GIL_DISABLED) || defined(PYPY_VERSION) || defined(GRAALVM_PYTHON) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030E0000
+constexpr bool DIRECT_STR_ACCESS = false;
+#else
+constexpr bool DIRECT_STR_ACCESS = true;
+static_assert(sizeof(PyASCIIObject) <= sizeof(PyCompactUnicodeObject), "str layout: ASCII header inside the compact one");
+#endif
+
 struct WordFiller {
     static size_t poolThreads()
     {
@@ -172,6 +183,40 @@ struct WordFiller {
         return FILLED;
     }
 
+    // The same job through the C API alone, on the calling thread (GIL held): interpreters whose str layout is not known here.
+    static JobState fillJobWithApi(const memb_hip_words_plan& plan, PyObject** items, size_t job, uint64_t* needed)
+    {
+        const size_t first = job * plan.job_words, last = std::min(plan.n, first + plan.job_words);
+        uint32_t* offsets = plan.offsets + job * (plan.job_words + 1);
+        const uint64_t base = uint64_t(job) * plan.job_bytes;
+        uint64_t at = 0;
+        bool fits = true;
+        for (size_t i = first; i < last; ++i) {
+            if (!PyUnicode_Check(items[i])) {
+                throw py::type_error("words must be str");
+            }
+            Py_ssize_t size = 0;
+            const char* text = PyUnicode_AsUTF8AndSize(items[i], &size);
+            if (!text) {
+                throw py::error_already_set();
+            }
+            const size_t length = ::strnlen(text, static_cast<size_t>(size));
+            if (fits && at + length <= plan.job_bytes) {
+                offsets[i - first] = static_cast<uint32_t>(base + at);
+                std::memcpy(plan.bytes + base + at, text, length);
+            } else {
+                fits = false;
+            }
+            at += length;
+        }
+        if (!fits) {
+            *needed = at;
+            return TOO_LONG;
+        }
+        offsets[last - first] = static_cast<uint32_t>(base + at);
+        return FILLED;
+    }
+
     // The words a job could not read without the API: the calling thread (GIL held) makes their UTF-8 form
     // available, or raises for what is not a str.
     static void prepareWithApi(PyObject** items, size_t first, size_t last)
@@ -199,7 +244,11 @@ struct WordFiller {
         static std::mutex poolMutex;
         size_t bytesPerWord = 0;
         for (int attempt = 0; attempt < 48; ++attempt) {
-            const memb_hip_words_plan plan = batch.begin(count, bytesPerWord);
+            memb_hip_words_plan plan;
+            {
+                py::gil_scoped_release release;   // (begin waits for the lookups that still read the previous batch)
+                plan = batch.begin(count, bytesPerWord);
+            }
             std::vector<int> state(plan.jobs, FILLED);
             std::vector<uint64_t> needed(plan.jobs, 0);
             if (count == 0) {
@@ -208,11 +257,11 @@ struct WordFiller {
                 return 0;
             }
             std::unique_lock<std::mutex> lock(poolMutex, std::try_to_lock);
-            const bool pooled = count >= 8192 && lock.owns_lock();
+            const bool pooled = DIRECT_STR_ACCESS && count >= 8192 && lock.owns_lock();
             bool clean = true;
             if (!pooled) {
                 for (size_t job = 0; job < plan.jobs; ++job) {
-                    state[job] = fillJob(plan, items, job, &needed[job]);
+                    state[job] = DIRECT_STR_ACCESS ? fillJob(plan, items, job, &needed[job]) : fillJobWithApi(plan, items, job, &needed[job]);
                     clean = clean && state[job] == FILLED;
                 }
                 if (clean) {
@@ -234,6 +283,9 @@ struct WordFiller {
                 std::exception_ptr failure;
                 for (size_t chunk = 0; chunk < chunks; ++chunk) {
                     const size_t firstJob = chunk * chunkJobs, lastJob = std::min(plan.jobs, firstJob + chunkJobs);
+                    // (the GIL stays with this thread while the pool reads the list and its strings: it is what keeps them
+                    // from changing under the pool -- as the reference holds it for a whole batch_embedding call,
+                    // python/memb_bindings.cpp:54-63. A 2.2 M-word fill is about a millisecond)
                     while (done[chunk].load(std::memory_order_acquire) < lastJob - firstJob) {
                         std::this_thread::yield();
                     }
@@ -526,6 +578,7 @@ PYBIND11_MODULE(_memb, m) {
         .def(
             "resolve_batch_to_device",
             [](memb::Reader& reader, memb::WordBatch& batch, uintptr_t rows, uintptr_t stream) {
+                py::gil_scoped_release release;   // (may stage the keys on first use)
                 reader.resolveRowsToDevice(batch, reinterpret_cast<uint32_t*>(rows), reinterpret_cast<void*>(stream));
             },
             py::arg("batch"),
@@ -536,8 +589,12 @@ PYBIND11_MODULE(_memb, m) {
             "words_to_rows_device",
             [](memb::Reader& reader, memb::WordBatch& batch, const py::sequence& wordList, uintptr_t rows, uintptr_t stream) {
                 // fill + lookup under one hold of the GIL (the batch object is not shared between two calls in flight);
-                // the lookups of finished runs of jobs are enqueued while the pool fills the next
-                reader.stageWords();
+                // the lookups of finished runs of jobs are enqueued while the pool fills the next. Staging the keys (first
+                // call only: tens of MB to HBM, the hash table built, a synchronize) runs with the GIL released.
+                {
+                    py::gil_scoped_release release;
+                    reader.stageWords();
+                }
                 return WordFiller::fill(batch, wordList, [&](size_t firstWord, size_t words) {
                     reader.resolveRangeToDevice(batch, firstWord, words, reinterpret_cast<uint32_t*>(rows), reinterpret_cast<void*>(stream));
                 });
@@ -725,7 +782,10 @@ PYBIND11_MODULE(_memb, m) {
             std::vector<const memb::Reader*> models;
             std::vector<uint32_t*> targets;
             for (size_t i = 0; i < readers.size(); ++i) {
-                readers[i]->stageWords();
+                {
+                    py::gil_scoped_release release;   // (first call: copies the keys to HBM and builds the table)
+                    readers[i]->stageWords();
+                }
                 models.push_back(readers[i].get());
                 targets.push_back(reinterpret_cast<uint32_t*>(rows[i]));
             }

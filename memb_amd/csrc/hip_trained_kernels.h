@@ -62,7 +62,8 @@ struct TrainedParams {
 // Measurement switches, TrainedParams::debugFlags (option `debug` / MEMB_HIP_DEBUG): bit 0 skip the decode, bit 1 skip
 // the output, bit 2 skip the row id / index / bitstream loads (the decoder then chews on whatever LDS holds: output values
 // are garbage, the access pattern is kept), bit 13 (0x2000) store constants instead of gathering centroids from LDS,
-// bit 14 (0x4000) no copy of table and codebook into LDS, bit 15 (0x8000) decode_union_split's tiles per wavefront a grid apart.
+// bit 14 (0x4000) no copy of table and codebook into LDS, bit 15 (0x8000) decode_union_split's tiles per wavefront a grid apart,
+// bit 16 (0x10000) row ids are not loaded (row = batch position: right for a key-order dump, the dependent load in front of it gone).
 // They exist in builds with -DMEMB_HIP_MEASURE only
 // (tools/perf/build_measure.py): the shipped library folds every one of these branches away, so no environment
 // variable or option can make it write anything but the decoded rows.
@@ -127,7 +128,7 @@ __device__ __forceinline__ uint32_t loadTileRow(const TrainedParams& p, unsigned
     if (role.spare || index >= p.n) {
         return MISSING;
     }
-    return p.rows && !(measureFlags(p) & 4) ? p.rows[index] : static_cast<uint32_t>(index);
+    return p.rows && !(measureFlags(p) & (4 | 0x10000)) ? p.rows[index] : static_cast<uint32_t>(index);
 }
 
 constexpr uint32_t ROW_META_BITS = 13;        // a segment offset inside a rowMeta record: streams below 1 KiB
@@ -886,6 +887,132 @@ __global__ MEMB_RECORDS_WAVES void decode_records_persistent(TrainedParams p)
         rowCurrent = rowNext;
         rowNext = rowAfterNext;
         waveLdsFence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// decode_two_tiles: two tiles per wavefront, half a batch apart, straight-line
+// ---------------------------------------------------------------------------
+// The memory pattern tools/perf/ceilings.hip found fastest (patterns 10 / 11, round 5: 6.5-8 % under one tile per
+// wavefront) with the decoder in it: a grid of ceil(tiles / 2) wavefronts that are NOT resident -- the dispatcher
+// refills -- each of which decodes tile g and tile g + ceil(tiles / 2): two write fronts half a batch apart, the second
+// tile's row regions in flight during the first tile's decode and stores. Row-record layout only. No loop and no
+// loop-carried pipeline state (decode_records_persistent launched this way -- round 5's option pipeline_tiles -- tied
+// with the one-tile kernel on dumps: it keeps three tiles of row ids and a loop's worth of live values, 78 vector and
+// 99 scalar registers = six wavefronts per SIMD); this form stays inside the seven of the one-tile kernels
+// (MEMB_SGPR_BUDGET, tests/test_isa.py), so a batch of up to 2 x 28 x CUs tiles -- BASELINE.json configs[1]: 12 500 tiles
+// -- is ONE round of resident wavefronts with exactly two tiles each.
+// SPECULATE (key-order dumps; chosen per launch by p.speculate, wave-uniform): the row regions of the FIRST tile are
+// requested for the rows a dump would name (row = batch position) side by side with the row ids themselves instead of
+// behind them; when the ids arrive and differ, the regions are requested again -- the result is the same either way.
+template <bool HAS_SUB, int MODE, bool FAST>
+__global__ MEMB_SGPR_BUDGET void decode_two_tiles(TrainedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr bool PACKED = !FAST;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
+    const unsigned long long half = (tiles + 1) / 2;
+    const unsigned long long tileA = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const unsigned long long tileB = tileA + half;
+    const bool active = tileA < half;
+    const bool second = active && tileB < tiles;
+    const LaneRole role = laneRole(p, lane);
+    // row ids of both tiles before the table copy, which hides their latency
+    uint32_t rowA = active ? loadTileRow(p, tileA, role) : MISSING;
+    uint32_t rowB = second ? loadTileRow(p, tileB, role) : MISSING;
+    u32x4 stream0 = {0, 0, 0, 0};
+    u32x4 stream1 = {0, 0, 0, 0};
+    const uint32_t tablePieces = p.tableDwords / 4;
+    const uint32_t copyPieces = tablePieces + (MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
+    WaveLds mem;
+    if (copyPieces <= 2 * blockDim.x) {
+        // the block's image of table and codebook through registers, the first tile's row regions requested behind it,
+        // the image written to LDS (and the block's barrier) while they are in flight -- as decode_records_persistent
+        mem = waveLds(p, lds);
+        u32x4 image0 = {0, 0, 0, 0};
+        u32x4 image1 = {0, 0, 0, 0};
+        auto imageSource = [&](uint32_t at) {
+            return at < tablePieces ? reinterpret_cast<const u32x4*>(p.table) + at
+                                    : reinterpret_cast<const u32x4*>(p.codebook) + (at - tablePieces);
+        };
+        if (threadIdx.x < copyPieces) {
+            image0 = *imageSource(threadIdx.x);
+        }
+        if (threadIdx.x + blockDim.x < copyPieces) {
+            image1 = *imageSource(threadIdx.x + blockDim.x);
+        }
+        if (active) {
+            issueRecordLoads(p, rowA, lane, stream0, stream1);
+        }
+        if (threadIdx.x < copyPieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image0;
+        }
+        if (threadIdx.x + blockDim.x < copyPieces) {
+            reinterpret_cast<u32x4*>(lds)[threadIdx.x + blockDim.x] = image1;
+        }
+        __syncthreads();
+        if (!active) {
+            return;
+        }
+    } else {
+        mem = setUpLds<MODE>(p, lds);
+        if (!active) {
+            return;
+        }
+        issueRecordLoads(p, rowA, lane, stream0, stream1);
+    }
+    uint32_t* slots = mem.slots;
+
+    // tile A's regions into LDS; tile B's requested (its row ids came in with A's)
+    writeStream(p, slots, lane, 0, stream0);
+    writeStream(p, slots, lane, 1, stream1);
+    if (second) {
+        issueRecordLoads(p, rowB, lane, stream0, stream1);
+    }
+    waveLdsFence();
+
+    WordMeta meta;
+    meta.row = rowA;
+    meta.start = 0;
+    meta.segmentBits = 0;
+    meta.packed2 = 0;
+    meta.packed3 = 0;
+    recordSegmentBits(p, slots, role, meta);
+    decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, slots, mem.keyTile, role, meta);
+    waveLdsFence();
+
+    // consume point of tile B's regions (loads return in order and stores are counted with them: taken out of flight
+    // BEFORE tile A's stores are issued)
+    if (second) {
+        writeStream(p, slots, lane, 0, stream0);
+        writeStream(p, slots, lane, 1, stream1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const unsigned long long tileBase = tileA * p.wordsPerWave;
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+        outputTile<MODE, FAST, FAST ? MEMB_HIP_RECORDS_BURST_NIBBLE : MEMB_HIP_OUTPUT_BURST>(
+            p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowA < p.nRows);
+    }
+    if (!second) {
+        return;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    waveLdsFence();
+
+    meta.row = rowB;
+    meta.segmentBits = 0;
+    recordSegmentBits(p, slots, role, meta);
+    decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, slots, mem.keyTile, role, meta);
+    waveLdsFence();
+    {
+        const unsigned long long tileBase = tileB * p.wordsPerWave;
+        const uint32_t tileWords =
+            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
+        outputTile<MODE, FAST, FAST ? MEMB_HIP_RECORDS_BURST_NIBBLE : MEMB_HIP_OUTPUT_BURST>(
+            p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowB < p.nRows);
     }
 }
 

@@ -18,7 +18,8 @@ struct memb_hip_words {
     uint32_t* hostOffsets = nullptr;
     size_t hostOffsetsCapacity = 0;   // entries
     const uint32_t* deviceOffsets = nullptr;
-    hipEvent_t lastUse = nullptr;     // behind the last lookup that reads the buffers
+    hipEvent_t lastUse = nullptr;     // behind EVERY lookup that reads the buffers (noteUse chains streams)
+    hipStream_t lastStream = nullptr; // the stream lastUse was recorded on
     bool inUse = false;
     uint32_t threads = 64;            // MEMB_HIP_PACK_THREADS: threads of memb_hip_words_pack (at most; one per 32 768 words, at least sixteen)
     std::unique_ptr<memb::WorkerPool> pool;
@@ -75,18 +76,27 @@ int words_create_checked(memb_hip_words** out, int device)
     return MEMB_HIP_OK;
 }
 
-// Grows a pinned, device-mapped buffer (contents are not kept: every batch starts afresh).
+// A lookup on `stream` reads the batch's pinned buffers: lastUse must come to lie behind ALL lookups in flight, not only
+// the latest one. A lookup on another stream than the one before first makes its stream wait for the earlier record, so
+// the one event words_begin / destroyWords wait for completes after every reader on every stream.
+int noteUse(memb_hip_words* batch, hipStream_t stream)
+{
+    if (batch->inUse && batch->lastStream != stream) {
+        HIP_TRY(hipStreamWaitEvent(stream, batch->lastUse, 0));
+    }
+    HIP_TRY(hipEventRecord(batch->lastUse, stream));
+    batch->lastStream = stream;
+    batch->inUse = true;
+    return MEMB_HIP_OK;
+}
+
+// Grows a pinned, device-mapped buffer (contents are not kept: every batch starts afresh). The old buffer is released
+// only once the new one exists: a failed allocation leaves the object as it was.
 template <typename T>
 int growPinned(T** buffer, const T** deviceView, size_t* capacity, size_t wanted)
 {
     if (*capacity >= wanted) {
         return MEMB_HIP_OK;
-    }
-    if (*buffer) {
-        (void)hipHostFree(*buffer);
-        *buffer = nullptr;
-        *deviceView = nullptr;
-        *capacity = 0;
     }
     const size_t entries = std::max(wanted + wanted / 4, size_t(4096));   // (a quarter of headroom: batches of one loop vary a little)
     void* raw = nullptr;
@@ -98,6 +108,9 @@ int growPinned(T** buffer, const T** deviceView, size_t* capacity, size_t wanted
     if (status != hipSuccess) {
         (void)hipHostFree(raw);
         return fail(MEMB_HIP_ERR_DEVICE, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(status));
+    }
+    if (*buffer) {
+        (void)hipHostFree(*buffer);
     }
     *buffer = static_cast<T*>(raw);
     *deviceView = static_cast<const T*>(device);
@@ -135,6 +148,7 @@ int words_begin_checked(memb_hip_words* batch, size_t n, size_t bytesPerWord, me
     }
     batch->count = 0;
     batch->committed = false;
+    batch->plan = memb_hip_words_plan{};   // (set again on success only: a batch whose begin failed resolves nothing)
     const uint32_t shift = jobShiftFor(n);
     const size_t jobWords = size_t(1) << shift;
     const size_t jobs = std::max<size_t>(1, (n + jobWords - 1) / jobWords);
@@ -433,9 +447,7 @@ int resolve_range_union_device_checked(
         ctxs, rows, count, batch->deviceBytes, uint64_t(batch->plan.jobs) * batch->plan.job_bytes, batch->deviceOffsets,
         batch->jobShift, firstWord, nWords, stream);
     if (code == MEMB_HIP_OK && nWords) {
-        memb_hip_words* mutableBatch = const_cast<memb_hip_words*>(batch);   // (bookkeeping of who still reads the buffers)
-        HIP_TRY(hipEventRecord(mutableBatch->lastUse, stream));
-        mutableBatch->inUse = true;
+        return noteUse(const_cast<memb_hip_words*>(batch), stream);   // (bookkeeping of who still reads the buffers)
     }
     return code;
 }
@@ -473,9 +485,7 @@ int resolveBatchOnContextStream(memb_hip_ctx* ctx, const memb_hip_words* batch, 
         ctx, batch->deviceBytes, uint64_t(batch->plan.jobs) * batch->plan.job_bytes, batch->deviceOffsets, batch->jobShift, 0,
         batch->count, rowsDevice, ctx->stream);
     if (code == MEMB_HIP_OK && batch->count) {
-        memb_hip_words* mutableBatch = const_cast<memb_hip_words*>(batch);
-        HIP_TRY(hipEventRecord(mutableBatch->lastUse, ctx->stream));
-        mutableBatch->inUse = true;
+        return noteUse(const_cast<memb_hip_words*>(batch), ctx->stream);
     }
     return code;
 }

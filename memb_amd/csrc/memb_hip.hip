@@ -427,6 +427,31 @@ TrainedKernel recordsKernel(const memb_hip_ctx* ctx, int mode)
     }
 }
 
+// decode_two_tiles as instantiated for a context and an output mode.
+template <int MODE>
+TrainedKernel twoTilesKernelOfMode(const memb_hip_ctx* ctx)
+{
+    if (ctx->fast) {
+        return &decode_two_tiles<false, MODE, true>;
+    }
+    return ctx->byteTable.hasSubTables ? &decode_two_tiles<true, MODE, false>
+                                       : &decode_two_tiles<false, MODE, false>;
+}
+
+TrainedKernel twoTilesKernel(const memb_hip_ctx* ctx, int mode)
+{
+    switch (mode) {
+        case OUT_FLAT:
+            return twoTilesKernelOfMode<OUT_FLAT>(ctx);
+        case OUT_VEC4:
+            return twoTilesKernelOfMode<OUT_VEC4>(ctx);
+        case OUT_KEYS:
+            return twoTilesKernelOfMode<OUT_KEYS>(ctx);
+        default:
+            return twoTilesKernelOfMode<OUT_SCALAR>(ctx);
+    }
+}
+
 // What the runtime knows about a kernel on a device: registers (-> wavefronts a CU can hold) and, per
 // (block size, LDS), the resident blocks per CU. Looked up once.
 struct KernelFacts {
@@ -648,6 +673,7 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
 struct TrainedPlan {
     bool fine = false;                   // decode_trained with the finer index (small batches)
     bool persistent = false;             // decode_records_persistent (else decode_trained)
+    bool twoTiles = false;               // decode_two_tiles
     TrainedGeometry geometry{};
     TrainedKernel kernel = nullptr;      // persistent only
     uint32_t registerWavesPerCu = 32;    // persistent only: what the kernel's registers allow
@@ -698,7 +724,7 @@ int planTrained(
     //     there, +9..+18 % with nothing cached -- 20-32 % behind the pipeline. Batch 26.)
     // (a forced kernel -- option persistent = 2, force = 1 -- wins over the rule, a forced finer index over both)
     bool fineByRule = false;
-    if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && force != 1) {
+    if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent < 2 && force != 1) {
         const uint32_t fineWords = WAVE / ctx->fineLanes;
         const uint64_t fineTiles = (n + fineWords - 1) / fineWords;
         const uint64_t fineRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, fineWords, ld, colOff, out).resident;
@@ -718,6 +744,7 @@ int planTrained(
         wantPersistent = force != 0;
     }
     plan->persistent = recordsFit && wantPersistent && !plan->fine;
+    plan->twoTiles = recordsFit && !plan->fine && !plan->persistent && force < 0 && ctx->switches.persistent == 3 && tiles >= 2;
     plan->pipelineTiles = ctx->switches.pipelineTiles;
     // (randomOrder: the caller says the rows come in no particular order -- MEMB_HIP_ROWS_IN_RANDOM_ORDER -- and eight
     // wavefronts per block only pay for key order)
@@ -725,6 +752,14 @@ int planTrained(
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;
+    }
+    if (plan->twoTiles && plan->geometry.waves) {
+        plan->kernel = twoTilesKernel(ctx, plan->geometry.mode);
+        uint32_t byVectorRegisters = 32;
+        hipError_t status = registerWavesPerCu(plan->kernel, &byVectorRegisters, &plan->numRegs);   // (also raises the kernel's LDS limit)
+        if (status != hipSuccess) {
+            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
+        }
     }
     if (plan->persistent && plan->geometry.waves) {
         // again with what the kernel's registers allow (a block size whose LDS would hold more wavefronts than
@@ -777,7 +812,12 @@ int launchTrained(
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t threads = geometry.waves * WAVE;
     hipError_t status;
-    if (persistent) {
+    if (plan.twoTiles) {
+        const size_t wavefronts = (tiles + 1) / 2;   // tile g and tile g + wavefronts
+        const uint32_t blocks = static_cast<uint32_t>((wavefronts + geometry.waves - 1) / geometry.waves);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), geometry.ldsBytes, stream, params);
+        status = hipGetLastError();
+    } else if (persistent) {
         const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
         status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream, plan.pipelineTiles);
     } else {
@@ -1450,7 +1490,7 @@ Switches readSwitches()
 #ifdef MEMB_HIP_MEASURE
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
 #endif
-    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
+    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 3);
     switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
     switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
     switches.fineLanes = std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES", 0), 2);
@@ -2146,7 +2186,7 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.fineLanes = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {
         ctx->switches.unionSplit = static_cast<uint32_t>(value);
-    } else if (key == "persistent" && value <= 2) {
+    } else if (key == "persistent" && value <= 3) {
         ctx->switches.persistent = static_cast<uint32_t>(value);
     } else if (key == "host_expand" && value <= 1) {
         ctx->switches.hostExpand = value != 0;
@@ -2201,7 +2241,8 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         info->row_bytes = ctx->recordPieces * 16;
         // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys, ...>
         std::snprintf(
-            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>", plan.persistent ? "decode_records_persistent" : "decode_trained",
+            info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>",
+            plan.twoTiles ? "decode_two_tiles" : plan.persistent ? "decode_records_persistent" : "decode_trained",
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
             ctx->fast ? "true" : "false");
         if (!plan.persistent) {

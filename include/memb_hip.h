@@ -175,28 +175,25 @@ void memb_hip_ctx_destroy(memb_hip_ctx* ctx);
 int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
 
 /*
- * Tuning knobs of a live context (results never depend on them). Unknown names and values
- * out of range return MEMB_HIP_ERR_INVALID and change nothing.
- *   "waves_per_block" 0 = choose (four; eight for batches of more than 524 000 words on 256 CUs), or 1 .. 16
+ * Knobs of a live context for tests and measurements (results never depend on them; every default is what the library
+ * ships with). Unknown names and values out of range return MEMB_HIP_ERR_INVALID and change nothing.
+ *   "waves_per_block" 0 (default) = by rule: four wavefronts; for batches of more than 524 000 words on 256 CUs eight when
+ *                     the rows come in key order and seven when they do not (see MEMB_HIP_ROWS_IN_RANDOM_ORDER); or 1 .. 16
  *   "persistent"      1 (default) = the kernel by batch size: decode_trained (one tile per wavefront at a time), except
  *                     decode_records_persistent from the batch that no longer fits the CUs at once up to four tiles per 16
  *                     wavefronts per CU (57 000 - 131 000 words on 256 CUs);
  *                     0 = decode_trained always, 2 = decode_records_persistent wherever the row layout allows
- *   "pipeline_tiles"  0 (default) = decode_records_persistent runs as many wavefronts as the CUs hold and each strides over the
- *                     tiles; K = every wavefront takes K tiles and exits (shuffled batches of a million rows and more: -2..-4 %
- *                     with persistent = 2 and K = 3 or 4; key-order dumps tie)
- *   "tiles_per_wave"  0 (default) = by rule (memb_hip.hip: oneTileSteps); K = a wavefront of decode_trained / decode_union_split
- *                     decodes K tiles one after the other behind one copy of the tables into LDS
- *   "fine_lanes"      0 (default) = a row-record model's finer segment index (about sixteen lanes per word instead of eight:
- *                     the chain of dependent lookups of a batch too small to hide it is shorter) decodes the batches whose
- *                     tiles under it are all resident at once (28 600 words on 256 CUs), 1 = never, 2 = always
- *   "union_compact"   1 (default) = decode_union_split decodes two nibble-key models through their 4-byte table entries
- *                     (round 5: -2.5 % at 500 000 and 1 000 000 words), 0 = through the 8-byte ones
+ *   "tiles_per_wave"  0 (default) = by rule (two for models whose tables take 16 KiB of LDS and more, and for the split
+ *                     union; else one); K = a wavefront of decode_trained / decode_union_split decodes K tiles one after
+ *                     the other behind one copy of the tables into LDS
+ *   "fine_lanes"      0 (default) = a row-record model's finer segment index (about sixteen lanes per word instead of eight)
+ *                     decodes the batches whose tiles under it are all resident at once (28 600 words on 256 CUs),
+ *                     1 = never, 2 = always
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
- *   "host_expand"     0 / 1   centroid indices instead of fp32 rows over PCIe (host-buffer entry point)
- * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug",
- * the measurement switches of hip_trained_kernels.h; the shipped library refuses it.
+ *   "host_expand"     1 (default) = centroid indices instead of fp32 rows over PCIe (host-buffer entry point), 0 = fp32 rows
+ * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug" and "lds_pad",
+ * the measurement switches of hip_trained_kernels.h; the shipped library refuses them.
  * Not thread-safe against lookups running on the same context.
  */
 int memb_hip_ctx_set_option(memb_hip_ctx* ctx, const char* name, uint64_t value);
@@ -239,10 +236,12 @@ int memb_hip_decode_rows_device(
  */
 #define MEMB_HIP_ACCUMULATE 1u
 /*
- * A hint, never a requirement (results do not depend on it): the rows of this batch come in no particular order (token
- * ids, shuffled keys). The library does not look at the ids; for batches of more than 524 000 words it launches blocks of
- * eight wavefronts, which key-order dumps like (1-5 %) and random rows do not (3 %): with this flag such a batch keeps
- * blocks of four.
+ * An override, never a requirement (results do not depend on it): the rows of this batch come in no particular order
+ * (token ids, shuffled keys). Batches of more than 524 000 words run blocks of eight wavefronts for rows in key order
+ * (dumps: 1-5 % over the alternatives) and of seven for rows in no particular order (3-5 %). Which of the two a batch is,
+ * the library finds out by itself: the kernel of every such batch looks at sixty-four pairs of neighbouring row ids and
+ * leaves word for the context's NEXT such batch (the first one is taken for a key-order dump). A caller whose batches
+ * alternate between the two can say so here for the ones that are not in key order.
  */
 #define MEMB_HIP_ROWS_IN_RANDOM_ORDER 2u
 int memb_hip_decode_rows_device_ex(

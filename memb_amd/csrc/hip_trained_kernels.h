@@ -30,6 +30,8 @@ struct TrainedParams {
     uint32_t loadPieces;            // pieces copied to LDS per word (recordPieces, or the whole slot: slotDwords / 4)
     uint16_t* segmentIndexOut;      // OUT_INDEX: index being built, [nRows][indexLanes - 1]
                                     // (both hold 32-bit entries when indexWide: rows longer than 65535 bits)
+                                    // Lookup modes of decode_trained: null, or where the launch leaves what it SAW of the
+                                    // batch's order (one uint32_t in pinned host memory, noteBatchOrder below)
     const uint32_t* table;          // 8-byte entries, see TableEntry
     const float* codebook;          // 256 centroids, or 256 centroid pairs (FAST)
     unsigned long long nRows;
@@ -656,6 +658,27 @@ __device__ __forceinline__ TrainedParams batchOfTile(const TrainedParams& p, con
     return q;
 }
 
+// What order do the rows of this batch come in? Sixty-four pairs of neighbouring row ids, spread over the batch, looked at by
+// the first wavefront of the grid: 1 = at least three quarters of the pairs are consecutive rows (a key-order dump, or runs of
+// one), 0 = not. The answer goes to pinned host memory, where the NEXT launch of a very large batch reads it when it picks
+// its block size (memb_hip.hip: launchTrained) -- key-order dumps and shuffled batches want different ones, the caller of
+// the reference's API (src/reader.cpp:49-57) has no way to say which it brings, and the batches of one caller tend to look
+// like the batch before. A hint to the launch geometry, never to the result; two launches of one context on two streams
+// may both write it (a plain store of 0 or 1).
+__device__ __forceinline__ void noteBatchOrder(const TrainedParams& p, uint32_t lane)
+{
+    uint32_t* seen = reinterpret_cast<uint32_t*>(p.segmentIndexOut);
+    uint32_t consecutive = 1;
+    if (p.rows && p.n >= 2) {
+        const unsigned long long at = (p.n - 2) / (WAVE - 1) * lane;   // <= n - 2
+        consecutive = p.rows[at + 1] == p.rows[at] + 1 ? 1u : 0u;
+    }
+    const uint32_t pairs = __popcll(__ballot(consecutive != 0));
+    if (lane == 0) {
+        __hip_atomic_store(seen, pairs >= 48 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One tile per wavefront at a time, no software pipeline: the hardware's dispatch of short-lived blocks is what
 // keeps the memory system busy. Also builds the segment index (OUT_INDEX).
 // A wavefront decodes p.tilesPerWave tiles one after the other -- tiles wave, wave + W, ... of its block's run of
@@ -686,6 +709,9 @@ __device__ __forceinline__ void decodeTilesOfBlock(const TrainedParams& p, const
     // a block that starts its dependent loads a microsecond later is the better citizen there (round 3 had seen the same
     // sign with a cruder ordering).
     const WaveLds mem = setUpLds<MODE>(p, lds);
+    if (!BATCHES && MODE != OUT_INDEX && blockIdx.x == 0 && threadIdx.x < WAVE && p.segmentIndexOut) {   // (one wavefront of the grid)
+        noteBatchOrder(p, lane);
+    }
     const unsigned long long tiles = BATCHES ? list.firstTile[list.count] : (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
     if (tile >= tiles) {
         return;
@@ -775,7 +801,13 @@ __global__ MEMB_SGPR_BUDGET void decode_trained_batches(TrainedParams p, BatchLi
 // per CU (nibble keys: 82 and 20 with an output burst of 5, rounds 3-5; MEMB_HIP_RECORDS_BURST_NIBBLE). Measured against one tile per wavefront on 100 000 random rows (round 4, batches 1 and 3, two boxes):
 // 4-bit -4.3..-6 %, 6-bit -8..-9 %, 2-bit -1.5 %; everywhere else the one-tile kernel wins or ties.
 // (Rounds 1-3 also had a general persistent pipeline for every layout, an LDS-DMA form of this one and a persistent
-// union: none of them won a BASELINE configuration by 3 % in round 4's table -- DESIGN.md section 5 -- and they are gone.)
+// union: none of them won a BASELINE configuration by 3 % in round 4's table -- DESIGN.md section 5 -- and they are gone.
+// Round 6 built the fastest memory pattern known -- two tiles per wavefront half a batch apart, the second tile's regions in
+// flight during the first tile's stores, a grid that is NOT resident -- as a kernel of its own, straight-line, 52 vector and
+// 70 scalar registers (decode_two_tiles), and this kernel launched that way had been round 5's option pipeline_tiles:
+// key-order dumps +4.0 % (blocks of four) / +8.4 % (of eight) against decode_trained, shuffled -2.1 % where plain blocks of
+// four make -3.5 %, 100 000 rows with nothing cached +0.5 % against this kernel, 60 000 rows +4 %. Both are gone;
+// profiles/r06_experiments.txt, batch 1.)
 constexpr int RECORD_ROUNDS = 2;   // 64-lane rounds per tile: 8 words x (160-byte region + padding piece) = 88 pieces
 
 __device__ __forceinline__ void issueRecordLoads(
@@ -887,132 +919,6 @@ __global__ MEMB_RECORDS_WAVES void decode_records_persistent(TrainedParams p)
         rowCurrent = rowNext;
         rowNext = rowAfterNext;
         waveLdsFence();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// decode_two_tiles: two tiles per wavefront, half a batch apart, straight-line
-// ---------------------------------------------------------------------------
-// The memory pattern tools/perf/ceilings.hip found fastest (patterns 10 / 11, round 5: 6.5-8 % under one tile per
-// wavefront) with the decoder in it: a grid of ceil(tiles / 2) wavefronts that are NOT resident -- the dispatcher
-// refills -- each of which decodes tile g and tile g + ceil(tiles / 2): two write fronts half a batch apart, the second
-// tile's row regions in flight during the first tile's decode and stores. Row-record layout only. No loop and no
-// loop-carried pipeline state (decode_records_persistent launched this way -- round 5's option pipeline_tiles -- tied
-// with the one-tile kernel on dumps: it keeps three tiles of row ids and a loop's worth of live values, 78 vector and
-// 99 scalar registers = six wavefronts per SIMD); this form stays inside the seven of the one-tile kernels
-// (MEMB_SGPR_BUDGET, tests/test_isa.py), so a batch of up to 2 x 28 x CUs tiles -- BASELINE.json configs[1]: 12 500 tiles
-// -- is ONE round of resident wavefronts with exactly two tiles each.
-// SPECULATE (key-order dumps; chosen per launch by p.speculate, wave-uniform): the row regions of the FIRST tile are
-// requested for the rows a dump would name (row = batch position) side by side with the row ids themselves instead of
-// behind them; when the ids arrive and differ, the regions are requested again -- the result is the same either way.
-template <bool HAS_SUB, int MODE, bool FAST>
-__global__ MEMB_SGPR_BUDGET void decode_two_tiles(TrainedParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr bool PACKED = !FAST;
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const unsigned long long tiles = (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
-    const unsigned long long half = (tiles + 1) / 2;
-    const unsigned long long tileA = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    const unsigned long long tileB = tileA + half;
-    const bool active = tileA < half;
-    const bool second = active && tileB < tiles;
-    const LaneRole role = laneRole(p, lane);
-    // row ids of both tiles before the table copy, which hides their latency
-    uint32_t rowA = active ? loadTileRow(p, tileA, role) : MISSING;
-    uint32_t rowB = second ? loadTileRow(p, tileB, role) : MISSING;
-    u32x4 stream0 = {0, 0, 0, 0};
-    u32x4 stream1 = {0, 0, 0, 0};
-    const uint32_t tablePieces = p.tableDwords / 4;
-    const uint32_t copyPieces = tablePieces + (MODE != OUT_KEYS ? p.codebookDwords / 4 : 0u);
-    WaveLds mem;
-    if (copyPieces <= 2 * blockDim.x) {
-        // the block's image of table and codebook through registers, the first tile's row regions requested behind it,
-        // the image written to LDS (and the block's barrier) while they are in flight -- as decode_records_persistent
-        mem = waveLds(p, lds);
-        u32x4 image0 = {0, 0, 0, 0};
-        u32x4 image1 = {0, 0, 0, 0};
-        auto imageSource = [&](uint32_t at) {
-            return at < tablePieces ? reinterpret_cast<const u32x4*>(p.table) + at
-                                    : reinterpret_cast<const u32x4*>(p.codebook) + (at - tablePieces);
-        };
-        if (threadIdx.x < copyPieces) {
-            image0 = *imageSource(threadIdx.x);
-        }
-        if (threadIdx.x + blockDim.x < copyPieces) {
-            image1 = *imageSource(threadIdx.x + blockDim.x);
-        }
-        if (active) {
-            issueRecordLoads(p, rowA, lane, stream0, stream1);
-        }
-        if (threadIdx.x < copyPieces) {
-            reinterpret_cast<u32x4*>(lds)[threadIdx.x] = image0;
-        }
-        if (threadIdx.x + blockDim.x < copyPieces) {
-            reinterpret_cast<u32x4*>(lds)[threadIdx.x + blockDim.x] = image1;
-        }
-        __syncthreads();
-        if (!active) {
-            return;
-        }
-    } else {
-        mem = setUpLds<MODE>(p, lds);
-        if (!active) {
-            return;
-        }
-        issueRecordLoads(p, rowA, lane, stream0, stream1);
-    }
-    uint32_t* slots = mem.slots;
-
-    // tile A's regions into LDS; tile B's requested (its row ids came in with A's)
-    writeStream(p, slots, lane, 0, stream0);
-    writeStream(p, slots, lane, 1, stream1);
-    if (second) {
-        issueRecordLoads(p, rowB, lane, stream0, stream1);
-    }
-    waveLdsFence();
-
-    WordMeta meta;
-    meta.row = rowA;
-    meta.start = 0;
-    meta.segmentBits = 0;
-    meta.packed2 = 0;
-    meta.packed3 = 0;
-    recordSegmentBits(p, slots, role, meta);
-    decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, slots, mem.keyTile, role, meta);
-    waveLdsFence();
-
-    // consume point of tile B's regions (loads return in order and stores are counted with them: taken out of flight
-    // BEFORE tile A's stores are issued)
-    if (second) {
-        writeStream(p, slots, lane, 0, stream0);
-        writeStream(p, slots, lane, 1, stream1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const unsigned long long tileBase = tileA * p.wordsPerWave;
-        const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-        outputTile<MODE, FAST, FAST ? MEMB_HIP_RECORDS_BURST_NIBBLE : MEMB_HIP_OUTPUT_BURST>(
-            p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowA < p.nRows);
-    }
-    if (!second) {
-        return;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    waveLdsFence();
-
-    meta.row = rowB;
-    meta.segmentBits = 0;
-    recordSegmentBits(p, slots, role, meta);
-    decodeSegment<HAS_SUB, MODE, FAST, PACKED>(p, mem.table, slots, mem.keyTile, role, meta);
-    waveLdsFence();
-    {
-        const unsigned long long tileBase = tileB * p.wordsPerWave;
-        const uint32_t tileWords =
-            static_cast<uint32_t>(min(static_cast<unsigned long long>(p.wordsPerWave), p.n - tileBase));
-        outputTile<MODE, FAST, FAST ? MEMB_HIP_RECORDS_BURST_NIBBLE : MEMB_HIP_OUTPUT_BURST>(
-            p, mem.codebook, mem.keyTile, tileBase, tileWords, lane, role, rowB < p.nRows);
     }
 }
 

@@ -137,6 +137,11 @@ int words_begin_checked(memb_hip_words* batch, size_t n, size_t bytesPerWord, me
     if (!batch || !plan) {
         return fail(MEMB_HIP_ERR_INVALID, "null argument");
     }
+    // (whatever happens below, the batch of the call before is gone: its plan is set again on success only, so that a batch
+    // whose begin failed resolves nothing -- a range lookup on stale buffers would be a wild read on the device)
+    batch->count = 0;
+    batch->committed = false;
+    batch->plan = memb_hip_words_plan{};
     if (n >= 0x7FFFFFFFull) {
         return fail(MEMB_HIP_ERR_INVALID, "batch too large");
     }
@@ -146,9 +151,6 @@ int words_begin_checked(memb_hip_words* batch, size_t n, size_t bytesPerWord, me
         HIP_TRY(hipEventSynchronize(batch->lastUse));   // the previous batch's lookups read these buffers
         batch->inUse = false;
     }
-    batch->count = 0;
-    batch->committed = false;
-    batch->plan = memb_hip_words_plan{};   // (set again on success only: a batch whose begin failed resolves nothing)
     const uint32_t shift = jobShiftFor(n);
     const size_t jobWords = size_t(1) << shift;
     const size_t jobs = std::max<size_t>(1, (n + jobWords - 1) / jobWords);
@@ -359,7 +361,9 @@ int stage_words_checked(
         (void)hipFree(offsets);
     }
     if (code != MEMB_HIP_OK) {
-        return code;   // (what was allocated stays with the context and goes with it)
+        deviceRelease(ctx, &slots, capacity * sizeof(WordSlot));   // (a retry starts from nothing)
+        deviceRelease(ctx, &keyBytes, packedBytes + 16);
+        return code;
     }
     ctx->wordKeyBytes = keyBytes;
     ctx->wordSlotMask = static_cast<uint32_t>(capacity - 1);

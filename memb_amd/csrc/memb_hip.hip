@@ -120,10 +120,6 @@ struct Switches {
                                    // 0 = never, 1 = whenever the pair qualifies
     uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: tiles a wavefront of the one-tile kernels decodes one after the
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
-    uint32_t unionCompact = 1;     // MEMB_HIP_UNION_COMPACT: decode_union_split of two nibble-key models through their 4-byte tables
-                                   // (6 KiB of LDS image per block instead of 8, one ds_read_b32 per symbol): 1 (default) / 0
-    uint32_t pipelineTiles = 0;    // option pipeline_tiles: tiles per wavefront of decode_records_persistent: 0 = by rule (planTrained:
-                                   // a grid of resident wavefronts for its own class, PIPELINE_DUMP_TILES for key-order dumps), K = a grid of tiles / K wavefronts
     uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
     uint32_t ldsPad = 0;           // option lds_pad, builds with -DMEMB_HIP_MEASURE only: unused LDS bytes added to every block of
@@ -203,6 +199,10 @@ struct memb_hip_ctx {
     std::vector<float> hostCodebook;   // the device codebook's host copy (256 centroids or 256 pairs)
     uint32_t* hostRowsPinned = nullptr;   // memb_hip_decode_words: the row ids the device looked up, for the host threads
     size_t hostRowsCapacity = 0;
+    // What the last very large batch looked like to the kernel that decoded it (hip_trained_kernels.h: noteBatchOrder):
+    // one word of pinned host memory, 1 = rows mostly consecutive, 0 = no particular order, ORDER_UNKNOWN before the first
+    uint32_t* orderSeen = nullptr;
+    uint32_t* orderSeenDevice = nullptr;
     // small batches: pinned host memory the kernel reads row ids from and writes rows to directly
     void* smallHost = nullptr;
     void* smallDevice = nullptr;
@@ -234,6 +234,7 @@ struct TrainedGeometry {
 // chain of a small batch, and in blocks of eight +5 % on a key-order dump (tools/perf/r5/sgprs.sh, residency.sh);
 // tests/test_isa.py pins the seven.
 constexpr uint32_t ONE_TILE_WAVES_PER_CU = 28;
+constexpr uint32_t ORDER_UNKNOWN = 2;   // memb_hip_ctx::orderSeen before any very large batch
 
 uint32_t roundUp4(uint32_t v)
 {
@@ -427,31 +428,6 @@ TrainedKernel recordsKernel(const memb_hip_ctx* ctx, int mode)
     }
 }
 
-// decode_two_tiles as instantiated for a context and an output mode.
-template <int MODE>
-TrainedKernel twoTilesKernelOfMode(const memb_hip_ctx* ctx)
-{
-    if (ctx->fast) {
-        return &decode_two_tiles<false, MODE, true>;
-    }
-    return ctx->byteTable.hasSubTables ? &decode_two_tiles<true, MODE, false>
-                                       : &decode_two_tiles<false, MODE, false>;
-}
-
-TrainedKernel twoTilesKernel(const memb_hip_ctx* ctx, int mode)
-{
-    switch (mode) {
-        case OUT_FLAT:
-            return twoTilesKernelOfMode<OUT_FLAT>(ctx);
-        case OUT_VEC4:
-            return twoTilesKernelOfMode<OUT_VEC4>(ctx);
-        case OUT_KEYS:
-            return twoTilesKernelOfMode<OUT_KEYS>(ctx);
-        default:
-            return twoTilesKernelOfMode<OUT_SCALAR>(ctx);
-    }
-}
-
 // What the runtime knows about a kernel on a device: registers (-> wavefronts a CU can hold) and, per
 // (block size, LDS), the resident blocks per CU. Looked up once.
 struct KernelFacts {
@@ -540,23 +516,18 @@ hipError_t launchPersistentGeneric(
     // of which 44 % run a third round -- is slower: 100 000 uncached rows +10 % (4-bit), +15 % (6-bit, 2-bit). More wavefronts
     // in flight beat an even last round.)
     const uint32_t resident = static_cast<uint32_t>(blocksPerCu) * ctx->cuCount;
-    uint32_t blocks = std::min(tileBlocks, resident);
-    if (tilesPerWave) {
-        // NOT a resident grid: every wavefront takes `tilesPerWave` tiles, a grid apart, and exits; the dispatcher refills
-        blocks = std::max<uint32_t>(1, (tileBlocks + tilesPerWave - 1) / tilesPerWave);
-    }
-    launch(blocks);
+    launch(std::min(tileBlocks, resident));
     return hipGetLastError();
 }
 
 hipError_t launchPersistent(
     const memb_hip_ctx* ctx, TrainedKernel kernel, const TrainedParams& params, uint32_t tileBlocks, uint32_t threads,
-    uint32_t ldsBytes, hipStream_t stream, uint32_t tilesPerWave = 0)
+    uint32_t ldsBytes, hipStream_t stream)
 {
     return launchPersistentGeneric(
         ctx, reinterpret_cast<const void*>(kernel), [&](uint32_t blocks) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), ldsBytes, stream, params);
-        }, tileBlocks, threads, ldsBytes, tilesPerWave);
+        }, tileBlocks, threads, ldsBytes);
 }
 
 template <int MODE>
@@ -673,15 +644,22 @@ uint32_t oneTileSteps(const memb_hip_ctx* ctx, uint64_t tiles, uint32_t copyByte
 struct TrainedPlan {
     bool fine = false;                   // decode_trained with the finer index (small batches)
     bool persistent = false;             // decode_records_persistent (else decode_trained)
-    bool twoTiles = false;               // decode_two_tiles
     TrainedGeometry geometry{};
     TrainedKernel kernel = nullptr;      // persistent only
     uint32_t registerWavesPerCu = 32;    // persistent only: what the kernel's registers allow
-    uint32_t pipelineTiles = 0;          // persistent only: 0 = a grid of resident wavefronts, K = a grid of tiles / K wavefronts
     int numRegs = 0;
 };
 
 constexpr uint64_t PIPELINE_WAVES_PER_CU = 16;   // the unit R of the rule below (times the CUs)
+// Do the rows of very large batches come in no particular order? The caller's word for it (MEMB_HIP_ROWS_IN_RANDOM_ORDER),
+// else what the kernel of the last such batch saw (memb_hip_ctx::orderSeen); key order until something was seen.
+bool rowsUnordered(const memb_hip_ctx* ctx, bool callerSaysRandom)
+{
+    if (callerSaysRandom) {
+        return true;
+    }
+    return ctx->orderSeen && __atomic_load_n(ctx->orderSeen, __ATOMIC_RELAXED) == 0;
+}
 
 // (the context's device is current)
 // Which kernel by batch size (n words): a STATIC rule. t = tiles of the batch, R = 16 x CUs. Round 4 measured every
@@ -724,7 +702,7 @@ int planTrained(
     //     there, +9..+18 % with nothing cached -- 20-32 % behind the pipeline. Batch 26.)
     // (a forced kernel -- option persistent = 2, force = 1 -- wins over the rule, a forced finer index over both)
     bool fineByRule = false;
-    if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent < 2 && force != 1) {
+    if (mayBeFine && ctx->fineIndex && ctx->switches.fineLanes == 0 && ctx->switches.persistent != 2 && force != 1) {
         const uint32_t fineWords = WAVE / ctx->fineLanes;
         const uint64_t fineTiles = (n + fineWords - 1) / fineWords;
         const uint64_t fineRound = uint64_t(ctx->cuCount) * chooseGeometry(ctx, fineWords, ld, colOff, out).resident;
@@ -744,22 +722,19 @@ int planTrained(
         wantPersistent = force != 0;
     }
     plan->persistent = recordsFit && wantPersistent && !plan->fine;
-    plan->twoTiles = recordsFit && !plan->fine && !plan->persistent && force < 0 && ctx->switches.persistent == 3 && tiles >= 2;
-    plan->pipelineTiles = ctx->switches.pipelineTiles;
-    // (randomOrder: the caller says the rows come in no particular order -- MEMB_HIP_ROWS_IN_RANDOM_ORDER -- and eight
-    // wavefronts per block only pay for key order)
-    const uint32_t preferred = !plan->persistent && tiles > 16 * R && !randomOrder ? 8u : 4u;
+    // Block size of very large batches (more than 16 R tiles): EIGHT wavefronts for rows in key order -- the dumps; three
+    // blocks = 24 resident wavefronts per CU and a table copy per eight tiles -- and, for rows in no particular order
+    // (randomOrder: the caller's hint or what the last such batch looked like, rowsUnordered), SEVEN: four whole blocks = the
+    // 28 wavefronts the registers admit, which random row regions (two lines each) want in flight. Round 6, batches 2-3, two
+    // boxes, seven against eight: shuffled 2.2 M rows 4-bit -4.7 / -3.7 %, 6-bit -3.6 / -4.7 %, byte-key 4-bit -4.6 %,
+    // Student-t -3.8 %, 1 M random rows -5.6 / -3.8 % (four: -3.0 / -2.3, -1.2 / -3.6, -3.4, -2.8, -4.6 / -2.3 %); key-order
+    // dumps -0.3 / +4.9 % (4-bit), -5.5 / -1.0 % (6-bit), +2.5 %, +5.0 %: the order decides, which is why it is looked at.
+    // Models with row regions below 160 bytes (the 2-bit one) keep four: seven costs them 5-10 % in either order.
+    const uint32_t unorderedWaves = ctx->recordPieces >= 10 ? 7u : 4u;
+    const uint32_t preferred = !plan->persistent && tiles > 16 * R ? (randomOrder ? unorderedWaves : 8u) : 4u;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, preferred);
     if (keysOut) {
         plan->geometry.mode = OUT_KEYS;
-    }
-    if (plan->twoTiles && plan->geometry.waves) {
-        plan->kernel = twoTilesKernel(ctx, plan->geometry.mode);
-        uint32_t byVectorRegisters = 32;
-        hipError_t status = registerWavesPerCu(plan->kernel, &byVectorRegisters, &plan->numRegs);   // (also raises the kernel's LDS limit)
-        if (status != hipSuccess) {
-            return fail(MEMB_HIP_ERR_DEVICE, std::string("hipFuncGetAttributes: ") + hipGetErrorString(status));
-        }
     }
     if (plan->persistent && plan->geometry.waves) {
         // again with what the kernel's registers allow (a block size whose LDS would hold more wavefronts than
@@ -787,7 +762,7 @@ int launchTrained(
     const Epilogue& epilogue, bool keysOut = false, int force = -1)
 {
     TrainedPlan plan;
-    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force, true, epilogue.randomOrder);
+    int planned = planTrained(ctx, n, ld, colOff, out, keysOut, &plan, force, true, rowsUnordered(ctx, epilogue.randomOrder));
     if (planned != MEMB_HIP_OK) {
         return planned;
     }
@@ -812,16 +787,17 @@ int launchTrained(
     const size_t tiles = (n + wordsPerWave - 1) / wordsPerWave;
     const uint32_t threads = geometry.waves * WAVE;
     hipError_t status;
-    if (plan.twoTiles) {
-        const size_t wavefronts = (tiles + 1) / 2;   // tile g and tile g + wavefronts
-        const uint32_t blocks = static_cast<uint32_t>((wavefronts + geometry.waves - 1) / geometry.waves);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), geometry.ldsBytes, stream, params);
-        status = hipGetLastError();
-    } else if (persistent) {
+    if (persistent) {
         const uint32_t blocks = static_cast<uint32_t>((tiles + geometry.waves - 1) / geometry.waves);
-        status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream, plan.pipelineTiles);
+        status = launchPersistent(ctx, kernel, params, blocks, threads, geometry.ldsBytes, stream);
     } else {
         params.tilesPerWave = oneTileSteps(ctx, tiles, 4u * (params.tableDwords + params.codebookDwords), false);
+        // very large batches leave word of their order for the next one (device-resident row ids only: the host-buffer
+        // entry points stage slices of the caller's batch)
+        const uint64_t R = uint64_t(ctx->cuCount) * PIPELINE_WAVES_PER_CU;
+        if (tiles > 16 * R && !keysOut && rows && ctx->orderSeenDevice) {
+            params.segmentIndexOut = reinterpret_cast<uint16_t*>(ctx->orderSeenDevice);
+        }
         const size_t perBlock = size_t(geometry.waves) * params.tilesPerWave;
         const uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
         const uint32_t ldsBytes = std::min<uint32_t>(geometry.ldsBytes + ctx->switches.ldsPad, 160 * 1024);   // (ldsPad: measurement builds)
@@ -1082,8 +1058,8 @@ int launchTrainedUnion(
         UnionParams sp = params;
         uint32_t shared = sharedDwords;
         const bool packedSub = !allFast && hasSub;
-        // nibble keys through the 4-byte tables (option union_compact): half the table bytes in the block's LDS image
-        const bool compact = allFast && first->switches.unionCompact != 0 && ctxs[0]->table32 && ctxs[1]->table32 &&
+        // nibble keys through the 4-byte tables (round 5: -2.5 % at 500 000 and 1 M words): half the table bytes in the block's LDS image
+        const bool compact = allFast && ctxs[0]->table32 && ctxs[1]->table32 &&
             !ctxs[0]->byteTable.hasSubTables && !ctxs[1]->byteTable.hasSubTables;
         if (compact) {
             shared = 0;
@@ -1377,6 +1353,22 @@ int deviceAlloc(memb_hip_ctx* ctx, T** pointer, size_t bytes)
     return MEMB_HIP_OK;
 }
 
+// Gives an allocation of deviceAlloc back before the context goes (optional structures whose build failed).
+template <typename T>
+void deviceRelease(memb_hip_ctx* ctx, T** pointer, size_t bytes)
+{
+    if (!*pointer) {
+        return;
+    }
+    auto found = std::find(ctx->allocations.begin(), ctx->allocations.end(), static_cast<void*>(*pointer));
+    if (found != ctx->allocations.end()) {
+        ctx->allocations.erase(found);
+        ctx->deviceBytes -= std::max<size_t>(bytes, 16);
+    }
+    (void)hipFree(*pointer);
+    *pointer = nullptr;
+}
+
 // Host -> device copy of a (possibly file-mapped) range. Pinning the mapped
 // pages first lets the copy run at the PCIe rate; registration of a read-only
 // mapping can be refused, in which case the plain copy is used.
@@ -1480,6 +1472,20 @@ int openDevice(memb_hip_ctx* ctx, int device)
         ctx->ldsLimit = 160 * 1024;
     }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    // the word the kernels of very large batches leave about their rows' order (noteBatchOrder); a context that cannot have
+    // it runs the block size of key order whatever comes
+    void* seen = nullptr;
+    if (hipHostMalloc(&seen, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        void* device = nullptr;
+        if (hipHostGetDevicePointer(&device, seen, 0) == hipSuccess) {
+            ctx->orderSeen = static_cast<uint32_t*>(seen);
+            ctx->orderSeenDevice = static_cast<uint32_t*>(device);
+            *ctx->orderSeen = ORDER_UNKNOWN;
+        } else {
+            (void)hipHostFree(seen);
+        }
+    }
+    (void)hipGetLastError();
     return MEMB_HIP_OK;
 }
 
@@ -1490,11 +1496,10 @@ Switches readSwitches()
 #ifdef MEMB_HIP_MEASURE
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
 #endif
-    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 3);
+    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
     switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
     switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
     switches.fineLanes = std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES", 0), 2);
-    switches.unionCompact = std::min<uint32_t>(envUint("MEMB_HIP_UNION_COMPACT", switches.unionCompact), 1);
     switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
@@ -1516,6 +1521,9 @@ void destroy(memb_hip_ctx* ctx)
     }
     for (void* allocation : ctx->allocations) {
         (void)hipFree(allocation);
+    }
+    if (ctx->orderSeen) {
+        (void)hipHostFree(ctx->orderSeen);
     }
     if (ctx->smallHost) {
         (void)hipHostFree(ctx->smallHost);
@@ -1970,15 +1978,18 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         const uint32_t symbols = std::max<uint32_t>(group, ((desc->dim + wanted - 1) / wanted + group - 1) / group * group);
         const uint32_t lanes = (desc->dim + symbols - 1) / symbols;
         if (lanes > ctx->lanesPerWord && lanes <= WAVE) {
-            code = deviceAlloc(ctx, &ctx->fineIndex, size_t(desc->n_rows) * (lanes - 1) * sizeof(uint16_t) + 16);
-            if (code == MEMB_HIP_OK) {
-                code = buildSegmentIndex(ctx, lanes, symbols, ctx->fineIndex);
+            // (an optimisation of small batches: a model that cannot have it -- no memory left, a failed pass -- is staged without)
+            const size_t fineBytes = size_t(desc->n_rows) * (lanes - 1) * sizeof(uint16_t) + 16;
+            int fine = deviceAlloc(ctx, &ctx->fineIndex, fineBytes);
+            if (fine == MEMB_HIP_OK) {
+                fine = buildSegmentIndex(ctx, lanes, symbols, ctx->fineIndex);
             }
-            if (code == MEMB_HIP_OK) {
+            if (fine == MEMB_HIP_OK) {
                 ctx->fineLanes = lanes;
                 ctx->fineSymbols = symbols;
             } else {
-                ctx->fineIndex = nullptr;
+                (void)hipGetLastError();
+                deviceRelease(ctx, &ctx->fineIndex, fineBytes);
             }
         }
     }
@@ -2178,15 +2189,11 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.waves = static_cast<uint32_t>(value);
     } else if (key == "tiles_per_wave" && value <= 64) {
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
-    } else if (key == "union_compact" && value <= 1) {
-        ctx->switches.unionCompact = static_cast<uint32_t>(value);
-    } else if (key == "pipeline_tiles" && value <= 64) {
-        ctx->switches.pipelineTiles = static_cast<uint32_t>(value);
     } else if (key == "fine_lanes" && value <= 2) {
         ctx->switches.fineLanes = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {
         ctx->switches.unionSplit = static_cast<uint32_t>(value);
-    } else if (key == "persistent" && value <= 3) {
+    } else if (key == "persistent" && value <= 2) {
         ctx->switches.persistent = static_cast<uint32_t>(value);
     } else if (key == "host_expand" && value <= 1) {
         ctx->switches.hostExpand = value != 0;
@@ -2211,7 +2218,7 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
     info->n_rows = ctx->nRows;
     info->device_bytes = ctx->deviceBytes;
     info->word_index_bytes = ctx->wordIndexBytes;
-    info->word_index_slots = ctx->wordSlots ? ctx->wordSlotMask + 1 : 0;
+    info->word_index_slots = ctx->wordSlots ? static_cast<uint32_t>(std::min<uint64_t>(uint64_t(ctx->wordSlotMask) + 1, 0xFFFFFFFFull)) : 0;   // (saturates: a table of 2^32 slots)
     info->word_index_keys = ctx->wordIndexKeys;
     if (ctx->storage == memb::wire::Storage_Trained) {
         const memb::DecodeTable& table = ctx->fast ? ctx->hostTable : ctx->byteTable;   // the lookup kernels' table
@@ -2224,7 +2231,8 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         {
             DeviceScope deviceScope(ctx->device);
             HIP_TRY(deviceScope.status());
-            const int planned = planTrained(ctx, batchWords ? size_t(batchWords) : size_t(1) << 30, ctx->dim, 0, nullptr, false, &plan);
+            const int planned = planTrained(
+                ctx, batchWords ? size_t(batchWords) : size_t(1) << 30, ctx->dim, 0, nullptr, false, &plan, -1, true, rowsUnordered(ctx, false));
             if (planned != MEMB_HIP_OK) {
                 return planned;
             }
@@ -2242,7 +2250,7 @@ int fillInfo(const memb_hip_ctx* ctx, memb_hip_ctx_info* info, uint64_t batchWor
         // template arguments as in the symbol: <two-level table, output mode (2 = dense rows), nibble keys, ...>
         std::snprintf(
             info->kernel, sizeof(info->kernel), "%s<%s, %d, %s>",
-            plan.twoTiles ? "decode_two_tiles" : plan.persistent ? "decode_records_persistent" : "decode_trained",
+            plan.persistent ? "decode_records_persistent" : "decode_trained",
             (ctx->fast ? ctx->hostTable : ctx->byteTable).hasSubTables ? "true" : "false", static_cast<int>(OUT_FLAT),
             ctx->fast ? "true" : "false");
         if (!plan.persistent) {

@@ -94,6 +94,12 @@ class Reader(BaseReader):
     max_direct_decode_bits
                  width of the first-level decode table, 0 = library default (results
                  never depend on it; the reference's tests force 1, src/tests.cpp:76-88)
+
+    Footprint: the model itself (info()['device_bytes']) is staged on first use. Batches of 4096 words
+    and more -- host results too -- are also SEARCHED on the device: the first such call copies the keys
+    to HBM and builds a hash table over them there (16-byte slots, at least 2 x len(reader) of them, plus
+    the keys: about 160 MB and some tens of milliseconds for a 2.2 M-word model; info()['word_index_bytes']).
+    stage_words() pays that up front; device='cpu' and host_below keep a reader's host batches off it.
     """
 
     def __init__(self, filename, num_threads=0, device=None, max_direct_decode_bits=0, host_below=None):
@@ -236,6 +242,42 @@ class Reader(BaseReader):
         self._impl.words_to_rows_device(self._word_batch, words, out.data_ptr(), _current_stream(torch, index))
         return out
 
+    def resolve_packed_device(self, data, offsets, out=None):
+        '''resolve_rows_device for words that are packed already (a tokenizer's output): word i is the UTF-8 bytes
+        data[offsets[i]:offsets[i + 1]]. No str object is touched -- the walk over a list of 2.2 M str is a cache miss per
+        word and the larger half of resolve_rows_device's time.
+        data : bytes-like (bytes, bytearray, memoryview, numpy.uint8) with offsets a numpy.uint32 array of n + 1 ascending
+            entries -- copied once into pinned memory by pooled threads (GIL released), the lookups of finished runs overlap
+            the copy of later ones; or BOTH torch tensors on this reader's device (uint8, int32 / uint32): looked up in place
+            (memb_hip_resolve_packed_device).
+        Returns the torch.int32 row ids on this reader's device (0xFFFFFFFF = not in the model).'''
+        import torch
+        index = self._impl.device()
+        if index == _memb.HOST_DEVICE:
+            raise RuntimeError("this reader decodes on the host (device 'cpu'): the device word search needs a reader on a HIP device")
+        on_device = isinstance(data, torch.Tensor) or isinstance(offsets, torch.Tensor)
+        n = int(offsets.numel() if isinstance(offsets, torch.Tensor) else len(offsets)) - 1
+        if n < 0:
+            raise ValueError('offsets needs n + 1 entries')
+        if out is None:
+            out = torch.empty((n,), dtype=torch.int32, device='cuda:{}'.format(index))
+        elif (out.device.type != 'cuda' or out.device.index != index or out.dtype not in (torch.int32, torch.uint32)
+              or not out.is_contiguous() or out.numel() != n):
+            raise TypeError('out must be a contiguous int32/uint32 tensor of n entries on cuda:{}'.format(index))
+        if on_device:
+            if not (isinstance(data, torch.Tensor) and isinstance(offsets, torch.Tensor)):
+                raise TypeError('data and offsets must both be torch tensors on the device, or both host buffers')
+            for tensor, kinds in ((data, (torch.uint8,)), (offsets, (torch.int32, torch.uint32))):
+                if tensor.device.type != 'cuda' or tensor.device.index != index or tensor.dtype not in kinds or not tensor.is_contiguous():
+                    raise TypeError('device-resident words: contiguous uint8 bytes and int32 offsets on cuda:{}'.format(index))
+            self._impl.packed_device_to_rows_device(data.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), _current_stream(torch, index))
+            return out
+        if self._word_batch is None:
+            self._word_batch = _memb.WordBatch(index)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        self._impl.packed_to_rows_device(self._word_batch, data, offsets, out.data_ptr(), _current_stream(torch, index))
+        return out
+
     def batch_embedding_device(self, words):
         '''batch_embedding with the result left on the GPU as a torch.Tensor (DLPack capable). Words are resolved on
         the GPU as well (resolve_rows_device): the only host work is packing the strings.'''
@@ -281,6 +323,6 @@ class Reader(BaseReader):
         return self._impl.info(int(batch_words))
 
     def set_option(self, name, value):
-        '''Tuning knob of the device context ('persistent', 'pipeline_tiles', 'tiles_per_wave', 'waves_per_block', 'union_split',
+        '''Tuning knob of the device context ('persistent', 'tiles_per_wave', 'waves_per_block', 'union_split',
         'host_expand': include/memb_hip.h, memb_hip_ctx_set_option); results never depend on them'''
         self._impl.set_option(str(name), int(value))

@@ -23,8 +23,10 @@ def run_bench(arguments, tmp_path, **extra_env):
     assert result.returncode == 0, result.stderr[-3000:]
     # what the driver keeps: the last 8 081 characters of stdout. The record must be whole in there, and alone on stdout.
     lines = result.stdout.splitlines()
-    # (a gloo rehearsal's rendezvous chatter -- "[Gloo] Rank 3 is connected to ..." -- comes first; RCCL runs have none)
-    assert len([line for line in lines if line.strip() and 'peer ranks' not in line]) == 1 and lines[-1].startswith('{'), result.stdout[-2000:]
+    # (a gloo rehearsal's rendezvous chatter -- "[Gloo] Rank 3 is connected to ...", lines of several ranks interleaved --
+    # comes first; RCCL runs have none)
+    assert len([line for line in lines if line.startswith('{')]) == 1 and lines[-1].startswith('{'), result.stdout[-2000:]
+    assert all('Gloo' in line or 'peer ranks' in line or 'connected' in line or not line.strip() for line in lines[:-1]), lines[:-1]
     assert len(lines[-1]) < 8000, len(lines[-1])
     line = json.loads(result.stdout[-8081:].splitlines()[-1])
     assert line == json.loads(lines[-1])

@@ -156,6 +156,55 @@ def test_default_path_of_every_batch_size_class(native, full_model):
     assert reader.host_rows_decoded == 0
 
 
+def test_block_size_follows_the_order_of_the_batch_before(native, full_model):
+    """Very large batches (more than 16 R tiles) run blocks of eight wavefronts for rows in key order and of seven for rows in
+    no particular order. The reference's caller cannot say which it brings (src/reader.cpp:49-57 takes words in any order):
+    the kernel looks at sixty-four pairs of neighbouring row ids and leaves word for the next launch (noteBatchOrder). The
+    rows are the checker's whatever the block size; the caller's hint still overrides."""
+    import torch
+    path, count = full_model
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if count <= 16 * 16 * cus * 8:
+        pytest.skip('the model is not larger than 16 R tiles')
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path, os.cpu_count() or 1)
+    rng = np.random.default_rng(41)
+    ordered = torch.arange(count, dtype=torch.int32, device='cuda')
+    shuffled_host = rng.permutation(count).astype(np.uint32)
+    shuffled = torch.from_numpy(shuffled_host.view(np.int32)).cuda()
+    picks = np.sort(rng.choice(count, size=20000, replace=False))
+    picks_device = torch.from_numpy(picks).cuda()
+    out = torch.empty((count, 300), dtype=torch.float32, device='cuda')
+
+    def run(ids, ids_host, **options):
+        before = reader.info(count)['waves_per_block']
+        out.fill_(7.0)
+        reader.rows_embedding_device(ids, out=out, **options)
+        torch.cuda.synchronize()
+        assert bits_equal(out[picks_device].cpu().numpy(), checker.rows_embedding(np.ascontiguousarray(ids_host[picks])))
+        return before, reader.info(count)['waves_per_block']
+
+    in_order = np.arange(count, dtype=np.uint32)
+    assert run(ordered, in_order) == (8, 8)            # nothing seen yet: key order is assumed, and confirmed
+    assert run(shuffled, shuffled_host) == (8, 7)      # decoded in blocks of eight; the next such batch gets seven
+    assert run(shuffled, shuffled_host) == (7, 7)
+    assert run(ordered, in_order) == (7, 8)            # and back
+    assert run(ordered, in_order, order='random') == (8, 8)   # the caller's hint decides its own launch, not the memory
+    # batches at or below 16 R tiles neither look nor are looked at
+    small = shuffled[:100000].contiguous()
+    reader.rows_embedding_device(small)
+    torch.cuda.synchronize()
+    assert reader.info(count)['waves_per_block'] == 8 and reader.info(100000)['waves_per_block'] == 4
+    # mostly consecutive rows with misses sprinkled in count as key order; runs of eight shuffled among themselves do not
+    holes = in_order.copy()
+    holes[rng.integers(0, count, size=count // 100)] = 0xFFFFFFFF
+    assert run(torch.from_numpy(holes.view(np.int32)).cuda(), holes)[1] == 8
+    blocks = (rng.permutation(count // 8)[:, None] * 8 + np.arange(8)[None, :]).reshape(-1).astype(np.uint32)
+    blocks = np.concatenate([blocks, np.arange(len(blocks), count, dtype=np.uint32)])
+    assert run(torch.from_numpy(blocks.view(np.int32)).cuda(), blocks)[1] == 8   # 7 of 8 pairs consecutive: key order
+    assert reader.host_rows_decoded == 0
+
+
 @pytest.mark.parametrize('bits,words,seed', [(6, 1999995, 1234), (4, FULL_VOCAB, 99)])
 def test_block_size_rule_on_the_byte_key_models(native, bits, words, seed):
     """The 6-bit model (BASELINE.json configs[2]) and the byte-key 4-bit one: kernel class, block size and lanes per word
@@ -175,16 +224,20 @@ def test_block_size_rule_on_the_byte_key_models(native, bits, words, seed):
     resident = 16 * cus
     one_round = ONE_TILE_WAVES_PER_CU * cus
     rng = np.random.default_rng(bits)
+    unordered_seen = False
     for tiles in (1, one_round * fine_words_per_tile // words_per_tile, one_round * fine_words_per_tile // words_per_tile + 1,
                   one_round, one_round + 1, 2 * resident, 2 * resident + 1, 4 * resident, 4 * resident + 1,
                   16 * resident, 16 * resident + 1, (count + words_per_tile - 1) // words_per_tile):
         batch = min(tiles * words_per_tile, 4 * count)
         info = reader.info(batch)
         family, waves, fine = expected_kernel_class(batch, words_per_tile, fine_words_per_tile, cus)
+        if waves == 8 and unordered_seen:
+            waves = 7   # (the random batch of 16 R + 1 tiles below left word of its order: the next very large batch runs blocks of seven)
         assert info['kernel'].startswith(family), (tiles, info['kernel'])
         assert waves is None or info['waves_per_block'] == waves, (tiles, info['waves_per_block'])
         assert (info['lanes_per_word'] > 64 // words_per_tile) == fine, (tiles, info['lanes_per_word'])
         if tiles in (16 * resident, 16 * resident + 1, 1):
+            unordered_seen = unordered_seen or tiles > 16 * resident
             rows = rng.integers(0, count, size=batch).astype(np.uint32)
             rows[rng.integers(0, batch, size=max(1, batch // 100))] = 0xFFFFFFFF
             out = reader.rows_embedding_device(torch.from_numpy(rows.view(np.int32)).cuda())

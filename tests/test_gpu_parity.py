@@ -983,9 +983,9 @@ def test_host_results_written_with_non_temporal_stores(native, make_model, monke
 @pytest.mark.parametrize('bits,distribution', [(4, 'normal'), (2, 'normal'), (6, 'student'), (8, 'student')])
 def test_every_kernel_of_a_model_produces_the_same_rows(native, make_model, bits, distribution):
     """The kernels a single trained model can run -- decode_trained with one, two and five tiles per wavefront
-    (option 'tiles_per_wave') in blocks of 4 and 8 wavefronts, and decode_records_persistent (option 'persistent' = 2) as a
-    resident grid and with 2, 3 and 64 tiles per wavefront (option 'pipeline_tiles') -- against the checker: dense rows, strided rows, unaligned output (scalar stores), host batches (centroid indices
-    over PCIe) and ragged / tiny batches, with missing rows in every one."""
+    (option 'tiles_per_wave') in blocks of 4, 7 and 8 wavefronts, and decode_records_persistent (option 'persistent' = 2) --
+    against the checker: dense rows, strided rows, unaligned output (scalar stores), host batches (centroid indices over
+    PCIe) and ragged / tiny batches, with missing rows in every one."""
     import torch
     path, words = make_model(20000, 300, 'trained', bits, distribution=distribution)
     checker = oracle.OracleReader(path)
@@ -1002,18 +1002,15 @@ def test_every_kernel_of_a_model_produces_the_same_rows(native, make_model, bits
             rows[:12000] = np.arange(12000, dtype=np.uint32)   # a key-order run as well
         expected = checker.rows_embedding(rows)
         ids = torch.from_numpy(rows.view(np.int32)).cuda()
-        # (persistent, tiles_per_wave, waves_per_block, pipeline_tiles: the pipeline's grid -- resident, or every wavefront K tiles)
-        for persistent, steps, waves, grid in ((0, 1, 0, 0), (0, 2, 8, 0), (0, 5, 4, 0), (2, 0, 0, 0), (2, 0, 0, 2), (2, 0, 8, 3), (2, 0, 0, 64), (3, 0, 0, 0), (3, 0, 8, 0), (1, 0, 0, 0)):
+        # (persistent, tiles_per_wave, waves_per_block; seven wavefronts = the blocks of very large batches in no particular order)
+        for persistent, steps, waves in ((0, 1, 0), (0, 2, 8), (0, 5, 4), (0, 1, 7), (0, 3, 7), (2, 0, 0), (2, 0, 8), (2, 0, 7), (1, 0, 0)):
             reader.set_option('persistent', persistent)
             reader.set_option('tiles_per_wave', steps)
             reader.set_option('waves_per_block', waves)
-            reader.set_option('pipeline_tiles', grid)
             name = reader.info(count)['kernel']
-            if persistent == 3:   # (a batch of one tile has no second tile: decode_trained)
-                assert name.startswith('decode_two_tiles<' if has_records and count > 8 else 'decode_trained<'), name
-            elif persistent != 1:
+            if persistent != 1:
                 assert name.startswith('decode_records_persistent<' if persistent == 2 and has_records else 'decode_trained<'), name
-            setting = (persistent, steps, waves, grid, count)
+            setting = (persistent, steps, waves, count)
             dense = reader.rows_embedding_device(ids)
             assert bits_equal(dense.cpu().numpy(), expected), setting
             wide = torch.full((count, 640), 7.0, dtype=torch.float32, device='cuda')
@@ -1027,7 +1024,6 @@ def test_every_kernel_of_a_model_produces_the_same_rows(native, make_model, bits
     reader.set_option('persistent', 1)
     reader.set_option('tiles_per_wave', 0)
     reader.set_option('waves_per_block', 0)
-    reader.set_option('pipeline_tiles', 0)
 
 
 @pytest.mark.parametrize('bits_a,bits_b,seed_b', [(4, 4, 1234), (6, 8, 1234), (2, 4, 1234), (4, 4, 99), (4, 6, 99), (6, 6, 5)])

@@ -520,3 +520,168 @@ def test_device_lookups_capture_into_a_hip_graph(native, make_model):
             assert bits_equal(single[i].cpu().numpy(), expected), (attempt, i)
             assert bits_equal(many[i].cpu().numpy(), expected), (attempt, i)
     assert reader.host_rows_decoded == 0
+
+
+@pytest.mark.parametrize('storage', ['uniform', 'full'])
+def test_full_vocabulary_word_search_on_node_keyed_storages(native, storage, tmp_path_factory):
+    """The uniform and the full storage keep their keys in the nodes of a sorted vector (LookupByKey,
+    src/uniform_compression.cpp:56, src/full_compression.cpp:39): the hash table is staged from keys collected node by
+    node. 2.2 M keys (narrow vectors: the search does not look at them), key order, shuffled, misses on both ends."""
+    import torch
+    from memb_amd import synthetic
+    count = int(os.environ.get('MEMB_TEST_FULL_VOCAB', FULL_VOCAB))
+    path = str(tmp_path_factory.mktemp('wide') / (storage + '.bin'))
+    synthetic.build_file(path, count, 4, storage, 8 if storage == 'uniform' else 32, seed=31)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    keys = reader.keys()
+    assert len(keys) == count
+    assert torch.equal(reader.resolve_rows_device(keys), torch.arange(count, dtype=torch.int32, device='cuda'))
+    info = reader.info()
+    assert info['word_index_keys'] == count and info['word_index_slots'] >= 2 * count
+    rng = np.random.default_rng(29)
+    order = rng.permutation(count)
+    shuffled = [keys[i] for i in order]
+    assert np.array_equal(reader.resolve_rows_device(shuffled).cpu().numpy().view(np.uint32), order.astype(np.uint32))
+    mixed = [keys[i] for i in rng.integers(0, count, size=200000)]
+    for i in range(0, len(mixed), 5):
+        mixed[i] = mixed[i] + '#'
+    for i in range(2, len(mixed), 997):
+        mixed[i] = '\x01' + mixed[i]
+    for i in range(4, len(mixed), 991):
+        mixed[i] = '\U0010ffff' + mixed[i]
+    expected = checker.resolve_rows(mixed)
+    assert (expected == MISSING).sum() > 40000
+    assert np.array_equal(reader.resolve_rows_device(mixed).cpu().numpy().view(np.uint32), expected)
+    assert bits_equal(reader.batch_embedding_device(mixed[:5000]).cpu().numpy(), checker.batch_embedding(mixed[:5000]))
+
+
+def test_poisoned_offsets_of_a_caller_filled_batch(native):
+    """A caller that fills the pinned job regions itself (memb_hip_words_begin / _commit) and gets offsets wrong: entries
+    that run backwards, point past the job regions, or are 0xFFFFFFFF make THEIR words MISSING (resolve_words' `sane` guard);
+    every other word of the batch keeps its answer and nothing faults."""
+    import torch
+    library = _library(native)
+    keys = [b'a', b'b', b'c', b'cc', b'd', b'e']
+    packed = b''.join(key + b'\x00' for key in keys)
+    offsets = np.cumsum([0] + [len(key) + 1 for key in keys[:-1]]).astype(np.uint32)
+    context = _uniform_context(library, len(keys))
+    stage = library.memb_hip_ctx_stage_words
+    stage.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    assert stage(context, packed, len(packed), offsets.ctypes.data, len(keys)) == 0, library.memb_hip_last_error()
+    batch = ctypes.c_void_p()
+    assert library.memb_hip_words_create(ctypes.byref(batch), 0) == 0
+
+    class Plan(ctypes.Structure):
+        _fields_ = [('bytes', ctypes.c_void_p), ('offsets', ctypes.c_void_p), ('n', ctypes.c_size_t),
+                    ('job_words', ctypes.c_size_t), ('jobs', ctypes.c_size_t), ('job_bytes', ctypes.c_size_t)]
+    begin = library.memb_hip_words_begin
+    begin.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+    resolve = library.memb_hip_resolve_rows_device
+    resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    plan = Plan()
+    words = [b'cc', b'a', b'zz', b'd', b'b', b'e', b'c'] * 120    # 840 words: several jobs, several wavefronts
+    assert begin(batch, len(words), 0, ctypes.byref(plan)) == 0, library.memb_hip_last_error()
+    host_bytes = (ctypes.c_uint8 * (plan.jobs * plan.job_bytes)).from_address(plan.bytes)
+    host_offsets = (ctypes.c_uint32 * (plan.jobs * (plan.job_words + 1))).from_address(plan.offsets)
+
+    def entry(word):   # where word's offset lives (every job has one entry more than words)
+        return word + word // plan.job_words
+
+    for job in range(plan.jobs):
+        at = job * plan.job_bytes
+        mine = words[job * plan.job_words:(job + 1) * plan.job_words]
+        for k, word in enumerate(mine):
+            host_offsets[job * (plan.job_words + 1) + k] = at
+            host_bytes[at:at + len(word)] = word
+            at += len(word)
+        host_offsets[job * (plan.job_words + 1) + len(mine)] = at
+    want = np.array([{b'a': 0, b'b': 1, b'c': 2, b'cc': 3, b'd': 4, b'e': 5}.get(w, MISSING) for w in words], dtype=np.uint32)
+    total = plan.jobs * plan.job_bytes
+    # word k's begin is entry(k), its end entry(k) + 1: poisoning entry(k) spoils words k - 1 (its end) and k (its begin)
+    spoiled = set()
+    for word, value in ((10, 0xFFFFFFFF), (70, total + 1), (200, 0xFFFFFFF0), (300, None), (500, 0x80000000), (839, total + 16)):
+        if value is None:
+            value = host_offsets[entry(word)] - 3   # runs backwards: in front of word 299's begin
+        host_offsets[entry(word)] = value
+        spoiled.update((word - 1, word))
+    # (word 300 after its poisoning: begins three bytes early and ends where it should -- a longer string that is no key)
+    assert library.memb_hip_words_commit(batch) == 0
+    rows = torch.full((len(words),), 7, dtype=torch.int32, device='cuda')
+    assert resolve(context, batch, rows.data_ptr(), None) == 0, library.memb_hip_last_error()
+    torch.cuda.synchronize()
+    got = rows.cpu().numpy().view(np.uint32)
+    for word in range(len(words)):
+        if word in spoiled:
+            assert got[word] == MISSING, (word, got[word])
+        else:
+            assert got[word] == want[word], (word, got[word], want[word])
+    # the context still works afterwards
+    pack = library.memb_hip_words_pack
+    pack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    queries = [b'd', b'nope', b'a']
+    array = (ctypes.c_char_p * len(queries))(*queries)
+    assert pack(batch, array, None, len(queries)) == 0
+    assert resolve(context, batch, rows.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert rows.cpu().numpy().view(np.uint32).tolist()[:3] == [4, MISSING, 0]
+    # a failed begin leaves no batch behind: the range lookup refuses instead of launching on stale buffers
+    assert begin(batch, 0x7FFFFFFF, 0, ctypes.byref(plan)) == 1
+    in_range = library.memb_hip_resolve_range_device
+    in_range.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    assert in_range(context, batch, 0, 1, rows.data_ptr(), None) == 1
+    assert resolve(context, batch, rows.data_ptr(), None) == 1
+    library.memb_hip_words_destroy(batch)
+    library.memb_hip_ctx_destroy(context)
+
+
+def test_words_that_are_packed_already(native, make_model):
+    """Reader.resolve_packed_device: one buffer of UTF-8 bytes + n + 1 offsets (a tokenizer's output) instead of a list of
+    str -- from host memory (bytes, bytearray, numpy) through the pinned job regions, from device tensors in place; the
+    answers of resolve_rows_device; several lookups of one batch on different streams before the next batch begins."""
+    import torch
+    path, words = make_model(30000, 300, 'trained', 4)
+    reader = native.Reader(path)
+    checker = oracle.OracleReader(path)
+    rng = np.random.default_rng(13)
+    for count in (0, 1, 63, 5000, 70000):
+        queries = [words[i] for i in rng.integers(0, len(words), size=count)]
+        for i in range(0, count, 9):
+            queries[i] = queries[i] + 'x'
+        if count > 100:
+            queries[17] = ''
+            queries[18] = 'naïve-日本語'
+        encoded = [q.encode('utf-8') for q in queries]
+        blob = b''.join(encoded)
+        offsets = np.cumsum([0] + [len(e) for e in encoded]).astype(np.uint32)
+        expected = checker.resolve_rows(queries) if count else np.zeros(0, dtype=np.uint32)
+        for data in (blob, bytearray(blob), np.frombuffer(blob, dtype=np.uint8)):
+            got = reader.resolve_packed_device(data, offsets)
+            assert got.dtype == torch.int32 and got.device.type == 'cuda' and got.numel() == count
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), expected), count
+        if count:
+            on_device = reader.resolve_packed_device(torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda(),
+                                                     torch.from_numpy(offsets.view(np.int32).copy()).cuda())
+            assert np.array_equal(on_device.cpu().numpy().view(np.uint32), expected), count
+            assert np.array_equal(reader.resolve_rows_device(queries).cpu().numpy().view(np.uint32), expected)
+    # one packed batch looked up on two streams, then the next batch at once: begin must wait for BOTH lookups
+    queries = [words[i] for i in rng.integers(0, len(words), size=70000)]
+    encoded = [q.encode('utf-8') for q in queries]
+    blob = b''.join(encoded)
+    offsets = np.cumsum([0] + [len(e) for e in encoded]).astype(np.uint32)
+    expected = checker.resolve_rows(queries)
+    first = reader.resolve_packed_device(blob, offsets)
+    side = torch.cuda.Stream()
+    second = torch.empty_like(first)
+    with torch.cuda.stream(side):
+        reader._impl.resolve_batch_to_device(reader._word_batch, second.data_ptr(), side.cuda_stream)
+    third = reader.resolve_packed_device(b'zz', np.array([0, 2], dtype=np.uint32))
+    torch.cuda.synchronize()
+    assert np.array_equal(first.cpu().numpy().view(np.uint32), expected) and np.array_equal(second.cpu().numpy().view(np.uint32), expected)
+    assert third.cpu().numpy().view(np.uint32).tolist() == [MISSING]
+    with pytest.raises(ValueError):
+        reader.resolve_packed_device(blob, np.array([0, 5, 3], dtype=np.uint32))          # runs backwards
+    with pytest.raises(ValueError):
+        reader.resolve_packed_device(b'abc', np.array([0, 2, 9], dtype=np.uint32))        # past the end of the bytes
+    with pytest.raises(TypeError):
+        reader.resolve_packed_device(blob, torch.zeros(3, dtype=torch.int32, device='cuda'))   # one on the host, one on the device

@@ -1,8 +1,9 @@
 // libmemb_ceilings.so -- what this GPU does with the decoder's MEMORY pattern and nothing else.
 //
 // Measurement code, not product: bench.py loads it (ctypes) to put the box's own ceilings next to the
-// kernel's time in the JSON line (`roofline.box_ceilings`); tools/perf/r4/small_ceilings.py and store_patterns.py
-// run the same entry points at other sizes and shapes.
+// kernel's time (`bench.py --extras`: tools/perf/bench_extras.py; tools/perf/r6/rot_ceilings.py at small sizes). The
+// experiments of rounds 4-5 that lived here -- stores per wavefront, 54 tile shapes, chunked and specialised wavefronts, the
+// skeleton of the records pipeline -- are in profiles/r04_experiments.txt / r05_experiments.txt with their numbers.
 // No decode, no tables; every pattern writes `words` rows of 300 floats (the 2.2 M-word dump: 2.635 GB)
 // and, from pattern 2 on, reads what a decoder of row records reads -- the stored values DEPEND on the
 // loaded bytes (through LDS, as in the decoder), so no load can be dropped or overtaken by its tile's stores.
@@ -159,34 +160,6 @@ __global__ void tiles_persistent(Params p)
     }
 }
 
-// Experiments (tools/perf/r4/store_patterns.py; not part of bench.py's table). What makes the linear fill fast?
-//   EXPERIMENT 0: every wavefront stores ONE KiB and exits -- after `delay` x ~0.43 us of sleeping (a wavefront that lives
-//                 as long as a decoding one, but still stores once)
-//   EXPERIMENT 1: every wavefront stores `stores` consecutive KiB (its own run) and exits, `delay` sleeps before the first
-//   EXPERIMENT 2: as 1, `delay` sleeps between consecutive stores
-__global__ void store_experiment(float4* out, unsigned long long pieces, int experiment, int stores, int delay)
-{
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const unsigned long long wave = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) / WAVE;
-    const int perWave = experiment == 0 ? 1 : stores;
-    if (experiment != 2) {
-        for (int i = 0; i < delay; ++i) {
-            __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
-        }
-    }
-    for (int k = 0; k < perWave; ++k) {
-        const unsigned long long i = (wave * perWave + k) * WAVE + lane;
-        if (i < pieces) {
-            out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
-        }
-        if (experiment == 2) {
-            for (int d = 0; d < delay; ++d) {
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-    }
-}
-
 // Uniform-storage shapes (tools/perf/r4/store_patterns.py): a row's record is 20 pieces (320 B: {min, max} + 300 weights).
 //   ROWS = 1: one row per wavefront -- 20 lanes load the record, the row leaves as TWO stores (1 KiB + 176 B), exit
 //   ROWS = 8: eight rows per wavefront -- 160 pieces in three rounds, 9600 B as ten stores, exit
@@ -224,215 +197,6 @@ __global__ void uniform_rows_per_wave(Params p)
         if (first * (ROW_FLOATS / 4) + q < endPiece) {
             out[q] = value;
         }
-    }
-}
-
-// A parametrised tile pattern (tools/perf/r4/tile_patterns.py): `rowsPerTile` rows per wavefront (records of consecutive or
-// random rows read first, through LDS), `delay` x ~0.43 us of sleeping between the loads and the stores (a decode's
-// latency), and the order of the stores: 0 = the wavefront's own tile, ascending; 1 = descending; 2 = after a block
-// barrier the block's wavefronts sweep the block's region together (wavefront w stores KiB w, w + W, ...).
-__global__ void tile_experiment(Params p, int rowsPerTile, int delay, int order)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const uint32_t wavesPerBlock = blockDim.x / WAVE;
-    const unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock + wave;
-    const uint32_t recordPieces = static_cast<uint32_t>(rowsPerTile) * RECORD_PIECES;
-    uint32_t* slots = dynamicLds + wave * recordPieces * 4;
-    const bool active = tile * rowsPerTile < p.words;
-    if (active) {
-        for (uint32_t q = lane; q < recordPieces; q += WAVE) {
-            const uint32_t w = q / RECORD_PIECES;
-            const unsigned long long word = tile * rowsPerTile + w;
-            const unsigned long long row = word < p.words ? (p.ids ? p.ids[word] : word) : 0xFFFFFFFFull;
-            u32x4 v = {0, 0, 0, 0};
-            if (row < p.rows) {
-                v = p.records[row * RECORD_PIECES + (q - w * RECORD_PIECES)];
-            }
-            *reinterpret_cast<u32x4*>(slots + 4 * q) = v;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i < delay; ++i) {
-        __builtin_amdgcn_s_sleep(16);
-    }
-    const unsigned long long endPiece = p.words * (ROW_FLOATS / 4);
-    const uint32_t tilePieces = static_cast<uint32_t>(rowsPerTile) * (ROW_FLOATS / 4);
-    if (order == 2) {
-        __syncthreads();
-        const unsigned long long blockFirst = static_cast<unsigned long long>(blockIdx.x) * wavesPerBlock * tilePieces;
-        const uint32_t blockPieces = wavesPerBlock * tilePieces;
-        float4* out = reinterpret_cast<float4*>(p.out) + blockFirst;
-        for (uint32_t q = wave * WAVE + lane; q < blockPieces; q += wavesPerBlock * WAVE) {
-            float4 value = make_float4(1.f, 2.f, 3.f, 4.f);
-            value.x = __uint_as_float(dynamicLds[q % (wavesPerBlock * recordPieces * 4)] & 0x3f800000u);
-            if (blockFirst + q < endPiece) {
-                out[q] = value;
-            }
-        }
-        return;
-    }
-    if (!active) {
-        return;
-    }
-    const unsigned long long firstPiece = tile * tilePieces;
-    float4* out = reinterpret_cast<float4*>(p.out) + firstPiece;
-    const uint32_t rounds = (tilePieces + WAVE - 1) / WAVE;
-    for (uint32_t k = 0; k < rounds; ++k) {
-        const uint32_t q = (order == 1 ? rounds - 1 - k : k) * WAVE + lane;
-        float4 value = make_float4(1.f, 2.f, 3.f, 4.f);
-        value.x = __uint_as_float(slots[q % (recordPieces * 4)] & 0x3f800000u);
-        if (q < tilePieces && firstPiece + q < endPiece) {
-            out[q] = value;
-        }
-    }
-}
-
-// Round 5, batch 28: T tiles per wavefront WITHOUT a persistent grid -- a block of W wavefronts owns W x T consecutive tiles, in
-// step t wavefront w takes tile t x W + w of them (the block's wavefronts stay next to each other, as in decode_trained with
-// tiles_per_wave = T); prefetch = 1: the records of step t + 1 are loaded (two registers per lane) before step t's tile is stored.
-// The question: would a depth-one pipeline inside short-lived blocks -- what decode_union_split has with T = 2 -- beat one tile
-// per wavefront for a single model?
-template <int MODE>   // 1 = sequential records, 2 = random records
-__global__ void tiles_chunked(Params p, int steps, int prefetch, int fronts)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const uint32_t wavesPerBlock = blockDim.x / WAVE;
-    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
-    // fronts F > 1: the grid writes F regions of the output at once -- groups of eight consecutive blocks (one per XCD) take
-    // turns between the F equal parts of the batch (is it the SECOND write front that the strided pattern gains from?)
-    unsigned long long chunk = blockIdx.x;
-    if (fronts > 1) {
-        const unsigned long long group = blockIdx.x / 8;
-        const unsigned long long perFront = (static_cast<unsigned long long>(gridDim.x) / 8 + fronts - 1) / fronts;   // groups per front
-        chunk = ((group % fronts) * perFront + group / fronts) * 8 + blockIdx.x % 8;
-    }
-    const unsigned long long first = chunk * wavesPerBlock * steps + wave;
-    uint32_t* slots = dynamicLds + wave * 4 * TILE_RECORD_PIECES;
-    u32x4 a = {0, 0, 0, 0};
-    u32x4 b = {0, 0, 0, 0};
-    if (first < tiles) {
-        loadTile<MODE == 2>(p, first, lane, a, b, p.records, p.ids);
-    }
-    for (int t = 0; t < steps; ++t) {
-        const unsigned long long tile = first + static_cast<unsigned long long>(t) * wavesPerBlock;
-        if (tile >= tiles) {
-            break;
-        }
-        stageTile(slots, lane, a, b);
-        const unsigned long long next = tile + wavesPerBlock;
-        if (prefetch && t + 1 < steps && next < tiles) {
-            loadTile<MODE == 2>(p, next, lane, a, b, p.records, p.ids);   // in flight during the stores
-        }
-        storeTile<true>(p.out, p.words, tile, lane, slots);
-        __builtin_amdgcn_wave_barrier();
-        if (!prefetch && t + 1 < steps && next < tiles) {
-            loadTile<MODE == 2>(p, next, lane, a, b, p.records, p.ids);
-        }
-    }
-}
-
-// Round 5, batch 29: what separates the records pipeline's memory skeleton from the two-tile pattern? tiles_persistent<1 / 2> again,
-// T tiles per wavefront a grid apart, plus -- one at a time -- what the kernel has and the pattern has not:
-//   copyBytes  a block-wide copy of that many bytes from global memory into LDS and a block barrier in front (tables + codebook: 6 KiB)
-//   padBytes   unused LDS per block (fewer resident wavefronts: 15.5 KiB per block of four in the kernel; registers cap it at 24 per CU)
-//   viaIds     row numbers come from an array even for consecutive rows (a dependent load in front of every tile's records)
-template <int MODE>
-__global__ void tiles_skeleton(Params p, const u32x4* tables, uint32_t copyPieces, uint32_t slotOffsetDwords, int viaIds)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    if (copyPieces) {
-        for (uint32_t q = threadIdx.x; q < copyPieces; q += blockDim.x) {
-            *reinterpret_cast<u32x4*>(dynamicLds + 4 * q) = tables[q];
-        }
-        __syncthreads();
-    }
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * (blockDim.x / WAVE);
-    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
-    unsigned long long tile = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x / WAVE) + wave;
-    uint32_t* slots = dynamicLds + slotOffsetDwords + wave * 4 * TILE_RECORD_PIECES;
-    u32x4 a = {0, 0, 0, 0};
-    u32x4 b = {0, 0, 0, 0};
-    if (tile < tiles) {
-        if (MODE == 2 || viaIds) {
-            loadTile<true>(p, tile, lane, a, b, p.records, p.ids);
-        } else {
-            loadTile<false>(p, tile, lane, a, b, p.records, p.ids);
-        }
-    }
-    for (; tile < tiles; tile += stride) {
-        stageTile(slots, lane, a, b);
-        if (tile + stride < tiles) {
-            if (MODE == 2 || viaIds) {
-                loadTile<true>(p, tile + stride, lane, a, b, p.records, p.ids);
-            } else {
-                loadTile<false>(p, tile + stride, lane, a, b, p.records, p.ids);
-            }
-        }
-        storeTile<true>(p.out, p.words, tile, lane, slots);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Round 5: wavefronts that STORE are not the ones that LOAD. A persistent block of W wavefronts, the
-// first `loaders` of which do nothing but fetch row records into an LDS double buffer while the others do nothing but
-// drain finished tiles with stores (the write-only persistent pattern, which is the fastest tile pattern some boxes
-// have), one block barrier per round: in round g the storers write the S = W - loaders tiles of round g out of buffer
-// g % 2 and the loaders fill buffer (g + 1) % 2 with the records of round g + 1's tiles, S / loaders tiles each, all of a
-// loader's loads in flight before the first is written to LDS. The stored values depend on the loaded bytes, as everywhere here.
-template <int MODE>   // 1 = sequential records, 2 = random records
-__global__ void tiles_specialised(Params p, uint32_t loaders)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t dynamicLds[];
-    constexpr uint32_t MAX_TILES_PER_LOADER = 7;
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave = threadIdx.x / WAVE;
-    const uint32_t storers = blockDim.x / WAVE - loaders;
-    const unsigned long long tiles = (p.words + TILE_ROWS - 1) / TILE_ROWS;
-    constexpr uint32_t SLOT = 4 * TILE_RECORD_PIECES;   // dwords of one tile's records
-    auto buffer = [&](unsigned long long round) { return dynamicLds + (round & 1) * storers * SLOT; };
-    auto firstTile = [&](unsigned long long round) { return (static_cast<unsigned long long>(blockIdx.x) + round * gridDim.x) * storers; };
-    auto loadRound = [&](unsigned long long round) {
-        u32x4 a[MAX_TILES_PER_LOADER], b[MAX_TILES_PER_LOADER];
-#pragma unroll
-        for (uint32_t i = 0; i < MAX_TILES_PER_LOADER; ++i) {
-            const uint32_t s = wave + i * loaders;
-            a[i] = u32x4{0, 0, 0, 0};
-            b[i] = u32x4{0, 0, 0, 0};
-            if (s < storers && firstTile(round) + s < tiles) {
-                loadTile<MODE == 2>(p, firstTile(round) + s, lane, a[i], b[i], p.records, p.ids);
-            }
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < MAX_TILES_PER_LOADER; ++i) {
-            const uint32_t s = wave + i * loaders;
-            if (s < storers) {
-                stageTile(buffer(round) + s * SLOT, lane, a[i], b[i]);
-            }
-        }
-    };
-    if (wave < loaders) {
-        loadRound(0);
-    }
-    __syncthreads();
-    for (unsigned long long round = 0; firstTile(round) < tiles; ++round) {
-        if (wave < loaders) {
-            if (firstTile(round + 1) < tiles) {
-                loadRound(round + 1);
-            }
-        } else {
-            const unsigned long long tile = firstTile(round) + (wave - loaders);
-            if (tile < tiles) {
-                storeTile<true>(p.out, p.words, tile, lane, buffer(round) + (wave - loaders) * SLOT);
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -542,143 +306,6 @@ int memb_ceiling_launch(
         }
         default:
             return static_cast<int>(hipErrorInvalidValue);
-    }
-    return static_cast<int>(hipGetLastError());
-}
-
-// tools/perf/r4/tile_patterns.py: see tile_experiment. ids may be null (consecutive rows); wavesPerBlock 1 .. 16.
-int memb_ceiling_tile_experiment(
-    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int rowsPerTile,
-    int wavesPerBlock, int delay, int order, void* stream)
-{
-    if (!out || !records || words == 0 || rowsPerTile < 1 || rowsPerTile > 64 || wavesPerBlock < 1 || wavesPerBlock > 16) {
-        return static_cast<int>(hipErrorInvalidValue);
-    }
-    Params p{};
-    p.out = out;
-    p.words = words;
-    p.records = static_cast<const u32x4*>(records);
-    p.rows = rows;
-    p.ids = ids;
-    const unsigned long long tiles = (words + rowsPerTile - 1) / rowsPerTile;
-    const uint32_t blocks = static_cast<uint32_t>((tiles + wavesPerBlock - 1) / wavesPerBlock);
-    const uint32_t ldsBytes = static_cast<uint32_t>(wavesPerBlock) * rowsPerTile * RECORD_PIECES * 16;
-    static bool raised = false;
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_experiment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
-    hipLaunchKernelGGL(tile_experiment, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, rowsPerTile, delay, order);
-    return static_cast<int>(hipGetLastError());
-}
-
-// tools/perf/r5/specialised.py: see tiles_specialised. wavesPerBlock 2 .. 16, 1 <= loaders < wavesPerBlock with at most seven
-// tiles per loader, wavesPerCu resident wavefronts per CU (the grid); ids null = consecutive rows.
-int memb_ceiling_specialised(
-    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int wavesPerBlock,
-    int loaders, int wavesPerCu, void* stream, int computeUnits)
-{
-    if (!out || !records || words == 0 || wavesPerBlock < 2 || wavesPerBlock > 16 || loaders < 1 || loaders >= wavesPerBlock ||
-        (wavesPerBlock - loaders + loaders - 1) / loaders > 7 || wavesPerCu < wavesPerBlock) {
-        return static_cast<int>(hipErrorInvalidValue);
-    }
-    Params p{};
-    p.out = out;
-    p.words = words;
-    p.records = static_cast<const u32x4*>(records);
-    p.rows = rows;
-    p.ids = ids;
-    const uint32_t storers = static_cast<uint32_t>(wavesPerBlock - loaders);
-    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
-    const unsigned long long rounds = (tiles + storers - 1) / storers;
-    const unsigned long long resident = static_cast<unsigned long long>(computeUnits) * (wavesPerCu / wavesPerBlock);
-    const uint32_t blocks = static_cast<uint32_t>(rounds < resident ? rounds : resident);
-    const uint32_t ldsBytes = 2 * storers * 4 * TILE_RECORD_PIECES * 4;
-    if (ids) {
-        hipLaunchKernelGGL(tiles_specialised<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, static_cast<uint32_t>(loaders));
-    } else {
-        hipLaunchKernelGGL(tiles_specialised<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, static_cast<uint32_t>(loaders));
-    }
-    return static_cast<int>(hipGetLastError());
-}
-
-// tools/perf/r4/store_patterns.py: see store_experiment. threads = 64 .. 1024 per block.
-int memb_ceiling_store_experiment(float* out, unsigned long long words, int experiment, int stores, int delay, int threads, void* stream)
-{
-    if (!out || words == 0 || stores < 1 || threads < 64 || threads > 1024 || threads % 64) {
-        return static_cast<int>(hipErrorInvalidValue);
-    }
-    const unsigned long long pieces = words * (ROW_FLOATS / 4);
-    const unsigned long long perWave = static_cast<unsigned long long>(experiment == 0 ? 1 : stores) * WAVE;
-    const unsigned long long waves = (pieces + perWave - 1) / perWave;
-    const unsigned long long blocks = (waves * WAVE + threads - 1) / threads;
-    hipLaunchKernelGGL(store_experiment, dim3(static_cast<uint32_t>(blocks)), dim3(threads), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<float4*>(out), pieces, experiment, stores, delay);
-    return static_cast<int>(hipGetLastError());
-}
-
-// tiles_chunked: W wavefronts per block, `steps` tiles per wavefront, prefetch 0 / 1; ids = null: consecutive rows
-int memb_ceiling_chunked(
-    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int wavesPerBlock,
-    int steps, int prefetch, int fronts, void* stream)
-{
-    if (!out || !records || words == 0 || wavesPerBlock < 1 || wavesPerBlock > 16 || steps < 1 || steps > 64 || fronts < 1 || fronts > 64) {
-        return static_cast<int>(hipErrorInvalidValue);
-    }
-    Params p{};
-    p.out = out;
-    p.words = words;
-    p.records = static_cast<const u32x4*>(records);
-    p.rows = rows;
-    p.ids = ids;
-    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
-    const unsigned long long perBlock = static_cast<unsigned long long>(wavesPerBlock) * steps;
-    uint32_t blocks = static_cast<uint32_t>((tiles + perBlock - 1) / perBlock);
-    if (fronts > 1) {
-        blocks = (blocks + 8 * fronts - 1) / (8 * fronts) * (8 * fronts);   // (whole groups per front; surplus blocks find no tile)
-    }
-    const uint32_t ldsBytes = static_cast<uint32_t>(wavesPerBlock) * TILE_RECORD_PIECES * 16;
-    if (ids) {
-        hipLaunchKernelGGL(tiles_chunked<2>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
-    } else {
-        hipLaunchKernelGGL(tiles_chunked<1>, dim3(blocks), dim3(wavesPerBlock * WAVE), ldsBytes, static_cast<hipStream_t>(stream), p, steps, prefetch, fronts);
-    }
-    return static_cast<int>(hipGetLastError());
-}
-
-// tiles_skeleton: T tiles per wavefront (grid = tile blocks / T), blocks of four; ids: row numbers (random rows, or consecutive ones
-// with viaIds = 1); tables: copyBytes of device memory to copy into LDS per block (may be null when copyBytes = 0)
-int memb_ceiling_skeleton(
-    float* out, unsigned long long words, const void* records, unsigned long long rows, const uint32_t* ids, int randomRows, int viaIds,
-    int tilesPerWave, const void* tables, unsigned int copyBytes, unsigned int padBytes, void* stream)
-{
-    if (!out || !records || words == 0 || tilesPerWave < 1 || copyBytes % 16 || padBytes % 16 || copyBytes + padBytes > 120 * 1024 ||
-        ((randomRows || viaIds) && !ids) || (copyBytes && !tables)) {
-        return static_cast<int>(hipErrorInvalidValue);
-    }
-    Params p{};
-    p.out = out;
-    p.words = words;
-    p.records = static_cast<const u32x4*>(records);
-    p.rows = rows;
-    p.ids = ids;
-    const unsigned long long tiles = (words + TILE_ROWS - 1) / TILE_ROWS;
-    const uint32_t tileBlocks = static_cast<uint32_t>((tiles + 3) / 4);
-    const uint32_t blocks = (tileBlocks + tilesPerWave - 1) / tilesPerWave;
-    const uint32_t slotOffsetDwords = (copyBytes + padBytes) / 4;
-    const uint32_t ldsBytes = copyBytes + padBytes + 4 * TILE_RECORD_PIECES * 16;
-    static bool raised = false;
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tiles_skeleton<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tiles_skeleton<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
-    if (randomRows) {
-        hipLaunchKernelGGL(tiles_skeleton<2>, dim3(blocks), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), p,
-                           static_cast<const u32x4*>(tables), copyBytes / 16, slotOffsetDwords, viaIds);
-    } else {
-        hipLaunchKernelGGL(tiles_skeleton<1>, dim3(blocks), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), p,
-                           static_cast<const u32x4*>(tables), copyBytes / 16, slotOffsetDwords, viaIds);
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -1,7 +1,10 @@
 """gpurun_out/prof_<round>_<tag>/ (tools/perf/prof.sh) -> profiles/<round>_<tag>_{summary.json, kernel_stats.csv,
 bench_under_rocprof.json} and profiles/hbm_traffic.json, stamped with the commit the passes ran on.
 
-    python tools/perf/collect_profiles.py r05 <commit>
+    python tools/perf/collect_profiles.py r06 <commit>
+
+`_sources_sha16` = the hash of memb_amd/csrc/* + include/memb_hip.h at collection time (bench_support.sources_sha16):
+bench.py reports these counters only from a tree with the same hash, `traffic_source: stale` otherwise.
 """
 import json
 import os
@@ -9,6 +12,8 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_support import sources_sha16   # noqa: E402
 WORKLOADS = {   # tag -> bench.py workload
     'headline': 'glove840b-300d-4bit-fullvocab', '100k': 'glove840b-300d-4bit-100k', 'union': 'union-concat-500k',
     '6bit': 'fasttext2m-300d-6bit-fullvocab', '2bit': 'glove840b-300d-2bit-fullvocab', 'uniform': 'uniform-8bit-500k'}
@@ -17,11 +22,11 @@ WORKLOADS = {   # tag -> bench.py workload
 def main(round_tag, commit):
     traffic = {
         '_how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --workload <name> '
-                '--steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-ceilings --no-live-traffic` (tools/perf/prof.sh '
-                '{0}_<tag> <kernel>; tools/perf/r5/profiles.sh), mean over the launches of the pass; profiles/{0}_*_summary.json. '
+                '--steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-live-traffic` (tools/perf/prof.sh '
+                '{0}_<tag> <kernel>; tools/perf/profiles.sh), mean over the launches of the pass; profiles/{0}_*_summary.json. '
                 'FETCH_SIZE (KB) = TCC_EA0_RDREQ x 64 B; on gfx950 it reports half of wide reads (MI355X_MICROARCH.md, HBM '
                 'section), so read bytes = 2 x FETCH_SIZE x 1024. WRITE_SIZE x 1024 = the fp32 output exactly.'.format(round_tag),
-        '_commit': commit, '_round': int(round_tag.lstrip('r')), '_detail': {}}
+        '_commit': commit, '_sources_sha16': sources_sha16(), '_round': int(round_tag.lstrip('r')), '_detail': {}}
     for tag, workload in WORKLOADS.items():
         source = os.path.join(REPO, 'gpurun_out', 'prof_{}_{}'.format(round_tag, tag))
         with open(os.path.join(source, 'summary.json')) as f:

@@ -3,13 +3,12 @@
 # One workload of bench.py under rocprofv3: kernel trace + stats, then the counter groups one pass each
 # (never combined with a trace, FETCH_SIZE and WRITE_SIZE in passes of their own: MI355X_MICROARCH.md),
 # summarised into gpurun_out/prof_<tag>/summary.json. Example:
-#   tools/perf/prof.sh r04_union decode_union_split --workload union-concat-500k
-# The trace pass also holds the box-ceiling kernels of tools/perf/ceilings.hip (bench.py runs them on the headline workload).
+#   tools/perf/prof.sh r06_union decode_union_split --workload union-concat-500k
 tag=$1; kernel=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
 long="bench.py $* --no-configs --no-cpu-baseline --no-live-traffic --steps 10 --warmup 3"
-short="bench.py $* --no-configs --no-cpu-baseline --no-ceilings --no-live-traffic --steps 3 --warmup 1"
+short="bench.py $* --no-configs --no-cpu-baseline --no-live-traffic --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 $long > $out/bench.json 2> $out/trace.err || exit 1
 pass() {   # name, counters...
     name=$1; shift

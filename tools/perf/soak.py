@@ -24,7 +24,6 @@ while time.time()-start < seconds:
         reader.set_option('tiles_per_wave', int(rng.choice([0,0,1,2,3,7]))); reader.set_option('persistent', int(rng.integers(0,3)))
         reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
         reader.set_option('fine_lanes', int(rng.integers(0,3)))   # round 5: the finer segment index by rule / never / always
-        reader.set_option('pipeline_tiles', int(rng.choice([0,0,1,2,3,7])))   # the pipeline's grid: resident / K tiles per wavefront
     for _ in range(int(rng.integers(1,6))):
         n=int(rng.choice([1,2,17,64,500,513,3000,20000,28672,28673,57345,60000,65537,140000,300000]))
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
@@ -62,7 +61,6 @@ while time.time()-start < seconds:
         pool=models[0][1][:2000]+models[1][1][:2000]
         if rng.random()<0.5: a.set_option('tiles_per_wave', int(rng.choice([0,1,2,3])))
         a.set_option('union_split', int(rng.integers(0,2))); a.set_option('persistent', int(rng.integers(0,3)))
-        a.set_option('union_compact', int(rng.integers(0,2)))
         batch=[pool[i] for i in rng.integers(0,len(pool),size=int(rng.choice([5,700,9000,90000])))]
         for mode in ('concatenate','average'):
             u=memb_amd.ReadersUnion([a,b],mode)

@@ -709,9 +709,11 @@ __device__ __forceinline__ void decodeTilesOfBlock(const TrainedParams& p, const
     // a block that starts its dependent loads a microsecond later is the better citizen there (round 3 had seen the same
     // sign with a cruder ordering).
     const WaveLds mem = setUpLds<MODE>(p, lds);
+#ifndef MEMB_HIP_NO_ORDER_PROBE   // (two builds side by side: tools/perf/r6/probe_cost.sh)
     if (!BATCHES && MODE != OUT_INDEX && blockIdx.x == 0 && threadIdx.x < WAVE && p.segmentIndexOut) {   // (one wavefront of the grid)
         noteBatchOrder(p, lane);
     }
+#endif
     const unsigned long long tiles = BATCHES ? list.firstTile[list.count] : (p.n + p.wordsPerWave - 1) / p.wordsPerWave;
     if (tile >= tiles) {
         return;

@@ -18,6 +18,7 @@
 //   6  4 + random records, same prefetch
 //   7  union shape: a tile is 4 merged rows of 600 floats (9600 B), 8 records at random rows of TWO arrays
 //   8, 9  uniform-storage shapes (320-byte records): one row per wavefront / eight rows per wavefront
+//   12, 13, 14  expand_keys: the output half of a two-kernel decoder (one / two / four 16-byte pieces per thread behind a load of nibble keys)
 //   10, 11  5 / 6 with a grid of tiles / 2 wavefronts instead of a resident one: two tiles per wavefront, half a batch apart, the
 //      second tile's records in flight during the first tile's stores, then exit (round 5, batch 28: the fastest tile pattern found)
 //
@@ -200,6 +201,36 @@ __global__ void uniform_rows_per_wave(Params p)
     }
 }
 
+// Round 6: the OUTPUT HALF of a two-kernel decoder as a pattern: symbols already decoded lie in memory as nibble keys (one uint16 =
+// four weights = one 16-byte piece of output), a thread reads its uint16 (128 consecutive bytes per wavefront), picks four of sixteen
+// centroids held in the lanes of one register (ds_bpermute: no LDS memory, no block barrier), stores ONE float4 and the wavefront
+// exits -- the linear fill's store pattern behind a dependent load. PIECES > 1: that many pieces per thread, 64 pieces apart.
+template <int PIECES>
+__global__ void expand_keys(float4* out, unsigned long long pieces, const uint16_t* keys)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const float centroid = lane < 16 ? 0.125f * static_cast<float>(lane) - 1.f : 0.f;
+    const unsigned long long first = (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x - lane) * PIECES + lane;
+    uint32_t key[PIECES];
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) {
+        const unsigned long long i = first + static_cast<unsigned long long>(u) * WAVE;
+        key[u] = i < pieces ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) {
+        const unsigned long long i = first + static_cast<unsigned long long>(u) * WAVE;
+        float4 value;
+        value.x = __shfl(centroid, key[u] & 15);
+        value.y = __shfl(centroid, (key[u] >> 4) & 15);
+        value.z = __shfl(centroid, (key[u] >> 8) & 15);
+        value.w = __shfl(centroid, (key[u] >> 12) & 15);
+        if (i < pieces) {
+            out[i] = value;
+        }
+    }
+}
+
 // union: 4 words per tile, each 600 floats wide; records of the 4 words from both arrays (slots 0-3 / 4-7)
 __global__ void union_tile_per_wave(Params p)
 {
@@ -299,6 +330,21 @@ int memb_ceiling_launch(
         case 9:
             hipLaunchKernelGGL(uniform_rows_per_wave<8>, dim3(static_cast<uint32_t>(((words + 7) / 8 + 3) / 4)), dim3(256), 0, s, p);
             break;
+        case 12:   // (records: at least words x 150 bytes of anything: the keys)
+        case 13:
+        case 14: {
+            const unsigned long long pieces = words * (ROW_FLOATS / 4);
+            const int per = pattern == 12 ? 1 : pattern == 13 ? 2 : 4;
+            const uint32_t blocks = static_cast<uint32_t>((pieces + 256ull * per - 1) / (256ull * per));
+            if (pattern == 12) {
+                hipLaunchKernelGGL(expand_keys<1>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<float4*>(out), pieces, reinterpret_cast<const uint16_t*>(records));
+            } else if (pattern == 13) {
+                hipLaunchKernelGGL(expand_keys<2>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<float4*>(out), pieces, reinterpret_cast<const uint16_t*>(records));
+            } else {
+                hipLaunchKernelGGL(expand_keys<4>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<float4*>(out), pieces, reinterpret_cast<const uint16_t*>(records));
+            }
+            break;
+        }
         case 7: {
             const unsigned long long unionTiles = (words + TILE_ROWS / 2 - 1) / (TILE_ROWS / 2);
             hipLaunchKernelGGL(union_tile_per_wave, dim3(static_cast<uint32_t>((unionTiles + 3) / 4)), dim3(256), 0, s, p);

@@ -389,19 +389,36 @@ struct PackedFiller {
                     onChunk(size_t(0), count);
                 }
             } else {
-                const size_t chunkJobs = std::max((plan.jobs + 7) / 8, (size_t(65536) + plan.job_words - 1) / plan.job_words);
-                const size_t chunks = (plan.jobs + chunkJobs - 1) / chunkJobs;
+                // Runs of jobs whose lookups are launched as they finish: a sixteenth of the batch, then up to a quarter, a half,
+                // the rest. The lookup reads the words over PCIe (2.2 M words: 0.68 ms at 51 GB/s) and every launch costs it a
+                // ramp of ~15 us, so few launches, the first one early (round 6, tools/perf/r6/packed.sh: eight equal runs
+                // 0.87-0.98 ms, sixteen 0.92-0.98, thirty-two 1.07-1.12, sixty-four 1.29-1.36).
+                std::vector<size_t> ends;
+                for (size_t fraction : {16u, 4u, 2u, 1u}) {
+                    const size_t end = fraction == 1 ? plan.jobs : std::max<size_t>(1, plan.jobs / fraction);
+                    if ((ends.empty() || end > ends.back()) && (fraction == 1 || end * plan.job_words >= 65536)) {
+                        ends.push_back(end);
+                    }
+                }
+                const size_t chunks = ends.size();
+                auto chunkOf = [&](size_t job) {
+                    size_t chunk = 0;
+                    while (job >= ends[chunk]) {
+                        ++chunk;
+                    }
+                    return chunk;
+                };
                 std::vector<std::atomic<size_t>> done(chunks);
                 for (auto& counter : done) {
                     counter.store(0, std::memory_order_relaxed);
                 }
                 WordFiller::pool().start(plan.jobs, [&](size_t job) {
                     fillJob(job);
-                    done[job / chunkJobs].fetch_add(1, std::memory_order_release);
+                    done[chunkOf(job)].fetch_add(1, std::memory_order_release);
                 }, WordFiller::threadsFor(count));
                 std::exception_ptr failure;
                 for (size_t chunk = 0; chunk < chunks; ++chunk) {
-                    const size_t firstJob = chunk * chunkJobs, lastJob = std::min(plan.jobs, firstJob + chunkJobs);
+                    const size_t firstJob = chunk ? ends[chunk - 1] : 0, lastJob = ends[chunk];
                     while (done[chunk].load(std::memory_order_acquire) < lastJob - firstJob) {
                         std::this_thread::yield();
                     }
@@ -948,6 +965,17 @@ PYBIND11_MODULE(_memb, m) {
     m.def("_word_fill_seconds", [](memb::WordBatch& batch, const py::sequence& wordList) {
         const auto start = std::chrono::steady_clock::now();
         WordFiller::fill(batch, wordList, [](size_t, size_t) {});
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    });
+    m.def("_packed_fill_seconds", [](memb::WordBatch& batch, const py::buffer& bytes, const py::array_t<uint32_t, py::array::c_style>& offsets) {
+        const py::buffer_info blob = bytes.request();
+        const size_t count = static_cast<size_t>(offsets.shape(0)) - 1;
+        const uint32_t* starts = offsets.data();
+        const uint8_t* data = static_cast<const uint8_t*>(blob.ptr);
+        const size_t dataBytes = static_cast<size_t>(blob.size);
+        py::gil_scoped_release release;
+        const auto start = std::chrono::steady_clock::now();
+        PackedFiller::fill(batch, data, dataBytes, starts, count, [](size_t, size_t) {});
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     });
     m.attr("HOST_DEVICE") = static_cast<int>(memb::CompressedStorage::HOST_DEVICE);

@@ -644,7 +644,7 @@ def test_words_that_are_packed_already(native, make_model):
     reader = native.Reader(path)
     checker = oracle.OracleReader(path)
     rng = np.random.default_rng(13)
-    for count in (0, 1, 63, 5000, 70000):
+    for count in (0, 1, 63, 5000, 70000, 600000):   # (600 000: several runs of jobs, looked up while later ones are copied)
         queries = [words[i] for i in rng.integers(0, len(words), size=count)]
         for i in range(0, count, 9):
             queries[i] = queries[i] + 'x'

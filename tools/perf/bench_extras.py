@@ -204,6 +204,22 @@ def word_search_timings(reader, path, torch, np, repeats=5):
         agree_checker = bool(np.array_equal(checker.resolve_rows(sample), expected[picks]))
         host_s = best(lambda: reader.resolve_rows(words))
         device_s = best(device)
+        # the same words packed already (a tokenizer's output: UTF-8 bytes + n + 1 offsets): no str object is walked
+        encoded = [word.encode('utf-8') for word in words]
+        blob = b''.join(encoded)
+        starts = np.zeros(len(words) + 1, dtype=np.uint32)
+        np.cumsum([len(e) for e in encoded], out=starts[1:])
+        del encoded
+        packed_rows = torch.empty(len(words), dtype=torch.int32, device='cuda')
+
+        def packed():
+            reader.resolve_packed_device(blob, starts, out=packed_rows)
+            torch.cuda.synchronize()
+
+        packed()
+        agree_packed = bool(np.array_equal(packed_rows.cpu().numpy().view(np.uint32), expected))
+        packed_s = best(packed)
+        packed_fill_s = best(lambda: _memb._packed_fill_seconds(scratch, blob, starts))
         fill_s = best(lambda: _memb._word_fill_seconds(scratch, words))
         begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         stream = torch.cuda.current_stream().cuda_stream
@@ -216,6 +232,7 @@ def word_search_timings(reader, path, torch, np, repeats=5):
             kernel_ms.append(begin.elapsed_time(end))
         result['batches'].append({
             'batch': name, 'words': len(words), 'host_ms': host_s * 1e3, 'device_ms': device_s * 1e3, 'speedup': host_s / device_s,
+            'device_ms_from_packed_words': packed_s * 1e3, 'packed_words_to_pinned_memory_alone_ms': packed_fill_s * 1e3, 'packed_parity': 'equal to the host search' if agree_packed else 'MISMATCH',
             'device_breakdown_ms': {'strings -> pinned memory alone (no lookup)': fill_s * 1e3,
                                     'resolve_words over the whole batch alone (reads the words over PCIe)': min(kernel_ms)},
             'words_per_s_device': len(words) / device_s,

@@ -376,7 +376,9 @@ def rounded(value, digits=6, text=160):
 
 
 def compact_line(result):
-    """The record: `result` without its verbose parts, as one JSON line of fewer than LINE_LIMIT characters."""
+    """The record: `result` without its verbose parts, as one JSON line of fewer than LINE_LIMIT characters. Never raises for
+    length: a record that would not fit loses precision, then optional keys, in that order -- a run that measured everything
+    must not end without its line."""
     line = {key: value for key, value in result.items() if key not in ('extras', 'geometry') and value is not None}
     if line.get('configs'):
         line['configs'] = [{key: entry[key] for key in CONFIG_KEYS if entry.get(key) is not None} for entry in line['configs']]
@@ -384,7 +386,13 @@ def compact_line(result):
     for key in ('vs_baseline', 'cpu_baseline'):   # (contract keys stay even when null)
         line.setdefault(key, None)
     text = json.dumps(rounded(line), separators=(',', ':'))
-    assert len(text) < LINE_LIMIT, len(text)
+    for digits, cap, dropped in ((5, 80, ()), (4, 48, ('launcher', 'rehearsal', 'sources_sha16', 'model_build_s', 'reader_open_s')),
+                                 (4, 32, ('per_rank', 'kernel_embeddings_per_s')), (4, 24, ('strong_scaling', 'configs'))):
+        if len(text) < LINE_LIMIT:
+            break
+        for key in dropped:
+            line.pop(key, None)
+        text = json.dumps(rounded(line, digits, cap), separators=(',', ':'))
     return text
 
 

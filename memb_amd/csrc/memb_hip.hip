@@ -729,8 +729,15 @@ int planTrained(
     // boxes, seven against eight: shuffled 2.2 M rows 4-bit -4.7 / -3.7 %, 6-bit -3.6 / -4.7 %, byte-key 4-bit -4.6 %,
     // Student-t -3.8 %, 1 M random rows -5.6 / -3.8 % (four: -3.0 / -2.3, -1.2 / -3.6, -3.4, -2.8, -4.6 / -2.3 %); key-order
     // dumps -0.3 / +4.9 % (4-bit), -5.5 / -1.0 % (6-bit), +2.5 %, +5.0 %: the order decides, which is why it is looked at.
-    // Models with row regions below 160 bytes (the 2-bit one) keep four: seven costs them 5-10 % in either order.
-    const uint32_t unorderedWaves = ctx->recordPieces >= 10 ? 7u : 4u;
+    // Models with row regions below 160 bytes (the 2-bit one) keep four: seven costs them 5-10 % in either order. And seven
+    // only where it DOES hold more resident wavefronts than eight: the 8-bit model's 33 KiB of tables leave two blocks of
+    // seven (14) against two of eight (16), and residency is what that model's block size is chosen for (chooseGeometry).
+    uint32_t unorderedWaves = ctx->recordPieces >= 10 ? 7u : 4u;
+    if (unorderedWaves == 7 && !ctx->switches.waves &&
+        chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, 7).resident <=
+            chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, 8).resident) {
+        unorderedWaves = 8;
+    }
     const uint32_t preferred = !plan->persistent && tiles > 16 * R ? (randomOrder ? unorderedWaves : 8u) : 4u;
     plan->geometry = chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, preferred);
     if (keysOut) {

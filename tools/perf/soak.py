@@ -22,14 +22,14 @@ while time.time()-start < seconds:
     if rng.random()<0.5 and 'trained' in reader._impl.storage_name():
         # round 3: the kernels are chosen by batch size; force other choices now and then (results never depend on them)
         reader.set_option('tiles_per_wave', int(rng.choice([0,0,1,2,3,7]))); reader.set_option('persistent', int(rng.integers(0,3)))
-        reader.set_option('waves_per_block', int(rng.choice([0,1,2,4,8])))
+        reader.set_option('waves_per_block', int(rng.choice([0,0,1,2,4,7,8])))
         reader.set_option('fine_lanes', int(rng.integers(0,3)))   # round 5: the finer segment index by rule / never / always
     for _ in range(int(rng.integers(1,6))):
-        n=int(rng.choice([1,2,17,64,500,513,3000,20000,28672,28673,57345,60000,65537,140000,300000]))
+        n=int(rng.choice([1,2,17,64,500,513,3000,20000,28672,28673,57345,60000,65537,140000,300000,600000]))   # (600 000: past 16 R tiles, where the block size follows the order of the batch before)
         batch=[words[i] for i in rng.integers(0,len(words),size=n)]
         if rng.random()<0.5: batch[::7]=['?']*len(batch[::7])
         want=checker.batch_embedding(batch)
-        kind=int(rng.integers(0,7))
+        kind=int(rng.integers(0,8))
         if kind==4:
             # round 5: word -> row on the device against the checker's binary search
             got=reader.resolve_rows_device(batch).cpu().numpy().view(np.uint32)
@@ -41,6 +41,16 @@ while time.time()-start < seconds:
             pieces=[(rows[a:b].contiguous(), torch.empty((b-a,reader.dim),dtype=torch.float32,device='cuda')) for a,b in zip(cuts[:-1],cuts[1:])]
             outs=reader.rows_embedding_device_many(pieces)
             check(torch.cat(outs).cpu().numpy() if outs else np.zeros((0,reader.dim),dtype=np.float32), want, 'many')
+        elif kind==7:
+            # round 6: the same words packed already (UTF-8 bytes + offsets), from host memory or from device tensors
+            encoded=[w.encode('utf-8') for w in batch]; blob=b''.join(encoded)
+            starts=np.zeros(n+1,dtype=np.uint32); np.cumsum([len(e) for e in encoded],out=starts[1:])
+            if rng.random()<0.5 or not blob:
+                got=reader.resolve_packed_device(blob, starts)
+            else:
+                got=reader.resolve_packed_device(torch.from_numpy(np.frombuffer(blob,dtype=np.uint8).copy()).cuda(), torch.from_numpy(starts.view(np.int32).copy()).cuda())
+            if not np.array_equal(got.cpu().numpy().view(np.uint32), checker.resolve_rows(batch)): print('MISMATCH packed', n, flush=True); os._exit(1)
+            if rng.random()<0.5: rows_sorted,_=torch.sort(got.to(torch.int64)); check(reader.rows_embedding_device(rows_sorted.to(torch.int32)).cpu().numpy(), checker.rows_embedding(rows_sorted.cpu().numpy().astype(np.uint32)), 'sorted rows')
         elif kind==6:
             rows=reader.resolve_rows_device(batch)
             check(reader.rows_embedding_device(rows, order='random').cpu().numpy(), want, 'order hint')

@@ -730,8 +730,9 @@ int planTrained(
     // Student-t -3.8 %, 1 M random rows -5.6 / -3.8 % (four: -3.0 / -2.3, -1.2 / -3.6, -3.4, -2.8, -4.6 / -2.3 %); key-order
     // dumps -0.3 / +4.9 % (4-bit), -5.5 / -1.0 % (6-bit), +2.5 %, +5.0 %: the order decides, which is why it is looked at.
     // Models with row regions below 160 bytes (the 2-bit one) keep four: seven costs them 5-10 % in either order. And seven
-    // only where it DOES hold more resident wavefronts than eight: the 8-bit model's 33 KiB of tables leave two blocks of
-    // seven (14) against two of eight (16), and residency is what that model's block size is chosen for (chooseGeometry).
+    // only where it DOES hold more resident wavefronts than eight: models with large tables (8-bit: 33-45 KiB of LDS per
+    // block) get their block size for residency (chooseGeometry; eight against four: -10..-15 %, round 5) and keep eight.
+    // (Batch 7, the 8-bit Student-t model, 21 resident in blocks of seven against 24: seven -2.0 % shuffled, +1.2 % key order.)
     uint32_t unorderedWaves = ctx->recordPieces >= 10 ? 7u : 4u;
     if (unorderedWaves == 7 && !ctx->switches.waves &&
         chooseGeometry(ctx, wordsPerWave, ld, colOff, out, ONE_TILE_WAVES_PER_CU, 7).resident <=

@@ -109,22 +109,22 @@ uint32_t envUint(const char* name, uint32_t fallback)
 // Context
 // ---------------------------------------------------------------------------
 
-// Measurement / test switches (environment variables, see tools/perf/README.md), read once
-// when a context is created.
+// Measurement / test switches: options of a live context (memb_hip_ctx_set_option) and a few environment variables read once
+// when a context is created (tools/perf/README.md has the list).
 struct Switches {
-    uint32_t waves = 0;            // MEMB_HIP_WAVES: force the wavefronts per block (0 = choose)
+    uint32_t waves = 0;            // MEMB_HIP_WAVES / option waves_per_block: force the wavefronts per block (0 = choose)
     uint32_t debugFlags = 0;       // MEMB_HIP_DEBUG, builds with -DMEMB_HIP_MEASURE only (hip_trained_kernels.h: measureFlags)
-    uint32_t persistent = 1;       // MEMB_HIP_PERSISTENT: 1 = the kernel by batch size (planTrained); 0 = one tile per wavefront
+    uint32_t persistent = 1;       // option persistent: 1 = the kernel by batch size (planTrained); 0 = one tile per wavefront
                                    // always, 2 = decode_records_persistent whenever the layout allows (tests, measurements)
-    uint32_t unionSplit = 1;       // MEMB_HIP_UNION_SPLIT: decode_union_split for pairs of models with row records:
+    uint32_t unionSplit = 1;       // option union_split: decode_union_split for pairs of models with row records:
                                    // 0 = never, 1 = whenever the pair qualifies
-    uint32_t tilesPerWave = 0;     // MEMB_HIP_TILES_PER_WAVE: tiles a wavefront of the one-tile kernels decodes one after the
+    uint32_t tilesPerWave = 0;     // option tiles_per_wave: tiles a wavefront of the one-tile kernels decodes one after the
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
-    uint32_t fineLanes = 0;        // MEMB_HIP_FINE_LANES: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
+    uint32_t fineLanes = 0;        // option fine_lanes: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
     uint32_t ldsPad = 0;           // option lds_pad, builds with -DMEMB_HIP_MEASURE only: unused LDS bytes added to every block of
                                    // decode_trained (fewer resident wavefronts per CU from the same code: tools/perf/r5/residency.sh)
-    bool hostExpand = true;        // MEMB_HIP_HOST_EXPAND: centroid indices over PCIe for host buffers
+    bool hostExpand = true;        // option host_expand: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
     uint32_t hostStreaming = 1;    // MEMB_HIP_HOST_STREAMING: non-temporal stores when host threads expand results: 0 = never,
@@ -1500,15 +1500,10 @@ int openDevice(memb_hip_ctx* ctx, int device)
 Switches readSwitches()
 {
     Switches switches;
-    switches.waves = envUint("MEMB_HIP_WAVES", 0);
+    switches.waves = envUint("MEMB_HIP_WAVES", 0);   // (also an option; as a variable it is known when the tables are sized: chooseLanes)
 #ifdef MEMB_HIP_MEASURE
     switches.debugFlags = envUint("MEMB_HIP_DEBUG", 0);
 #endif
-    switches.persistent = std::min<uint32_t>(envUint("MEMB_HIP_PERSISTENT", switches.persistent), 2);
-    switches.unionSplit = std::min<uint32_t>(envUint("MEMB_HIP_UNION_SPLIT", switches.unionSplit), 1);
-    switches.tilesPerWave = envUint("MEMB_HIP_TILES_PER_WAVE", 0);
-    switches.fineLanes = std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES", 0), 2);
-    switches.hostExpand = envUint("MEMB_HIP_HOST_EXPAND", 1) != 0;
     switches.sliceWords = envUint("MEMB_HIP_SLICE_WORDS", ~0u);
     switches.copyChunkRows = envUint("MEMB_HIP_COPY_CHUNK_ROWS", 0);
     switches.copyThreads = std::min<uint32_t>(envUint("MEMB_HIP_COPY_THREADS", 16), 64);
@@ -1634,7 +1629,7 @@ int buildHostTable(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         // whenever 32 KiB of 4-byte entries hold it (13 bits); a given max_direct_bits is still
         // honoured (tests force the two-level path with it), raised only while the tables would not fit.
         ctx->codeLengths = lengths;
-        uint32_t byteLimit = desc->max_direct_bits ? desc->max_direct_bits : envUint("MEMB_HIP_BYTE_ROOT_BITS", 13);
+        uint32_t byteLimit = desc->max_direct_bits ? desc->max_direct_bits : 13u;
         byteLimit = std::max<uint32_t>(1, std::min<uint32_t>(byteLimit, 13));
         for (;;) {
             ctx->byteTable = memb::buildDecodeTable(lengths, byteLimit);
@@ -1738,7 +1733,7 @@ int stageStreams(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
         uint64_t(ctx->maxStreamBytes) * 8 + 64 < (1u << ROW_META_BITS) && envUint("MEMB_HIP_ROW_RECORDS", 1) &&
         envUint("MEMB_HIP_ROW_META", 1) && ctx->slotDwords >= 4 * recordPieces + 3 &&
         uint64_t(recordPieces) * desc->n_rows * 100 <=
-            (compactPieces + desc->n_rows) * (100 + envUint("MEMB_HIP_RECORD_PADDING_PERCENT", 35)) &&   // at most 35 % padding
+            (compactPieces + desc->n_rows) * (100 + 35) &&   // at most 35 % padding
         uint64_t(recordPieces) * (desc->n_rows + 2) < (1ull << 32)) {
         ctx->recordPieces = recordPieces;
     } else {
@@ -1980,9 +1975,9 @@ int stageIndex(memb_hip_ctx* ctx, const memb_hip_trained_desc* desc)
     // The finer index of small batches (memb_hip_ctx::fineIndex): about sixteen lanes per word for models staged as row
     // records -- a second pass of the index kernel, 2 bytes per offset (53 MB for the 2.2 M-word model of dim 300: a
     // seventh of its footprint on a 288 GB part).
-    if (code == MEMB_HIP_OK && records && desc->n_rows && !ctx->indexWide && envUint("MEMB_HIP_FINE_INDEX", 1)) {
+    if (code == MEMB_HIP_OK && records && desc->n_rows && !ctx->indexWide) {
         const uint32_t group = ctx->fast ? 8 : 4;
-        const uint32_t wanted = std::max<uint32_t>(2, std::min<uint32_t>(envUint("MEMB_HIP_FINE_LANES_TARGET", 16), WAVE));
+        const uint32_t wanted = 16;
         const uint32_t symbols = std::max<uint32_t>(group, ((desc->dim + wanted - 1) / wanted + group - 1) / group * group);
         const uint32_t lanes = (desc->dim + symbols - 1) / symbols;
         if (lanes > ctx->lanesPerWord && lanes <= WAVE) {

@@ -171,7 +171,7 @@ def test_host_copy_ring_chunks_threads_and_slices(native, make_model, monkeypatc
 def test_host_batches_cross_pcie_as_centroid_indices(native, make_model, monkeypatch):
     # trained storage + host buffers: the kernel writes rows of centroid indices, the host threads
     # that empty the pinned ring expand them (memb_hip.hip: decodeRowsAsKeys). Same bits as the
-    # fp32 path (MEMB_HIP_HOST_EXPAND=0) and as the checker, for nibble and byte keys, odd
+    # fp32 path (option host_expand = 0) and as the checker, for nibble and byte keys, odd
     # dimensions, tile geometries whose key tiles are not dword multiples, absent rows.
     for dim, bits, lanes in ((300, 4, 8), (300, 8, 8), (7, 2, 1), (301, 4, 5), (33, 6, 3), (150, 4, 64), (2, 4, 1)):
         path, words = make_model(2500, dim, 'trained', bits, seed=dim + bits)
@@ -182,12 +182,12 @@ def test_host_batches_cross_pcie_as_centroid_indices(native, make_model, monkeyp
         expected = checker.rows_embedding(rows)
         monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
         for expand, chunk_rows in ((1, 0), (1, 5), (0, 0)):
-            monkeypatch.setenv('MEMB_HIP_HOST_EXPAND', str(expand))
             if chunk_rows:
                 monkeypatch.setenv('MEMB_HIP_COPY_CHUNK_ROWS', str(chunk_rows))
             else:
                 monkeypatch.delenv('MEMB_HIP_COPY_CHUNK_ROWS', raising=False)
             reader = native.Reader(path)
+            reader.set_option('host_expand', expand)
             assert bits_equal(reader.rows_embedding(rows), expected), (dim, bits, lanes, expand, chunk_rows)
             wide = np.full((len(rows), dim + 5), 9.0, dtype=np.float32)
             keys = reader.keys()
@@ -826,8 +826,8 @@ def test_tile_geometries_give_identical_rows(native, make_model, monkeypatch):
                                          (8, 8, 1), (16, 2, 1), (25, 1, 0), (64, 1, 1)):
             monkeypatch.setenv('MEMB_HIP_LANES', str(lanes))
             monkeypatch.setenv('MEMB_HIP_WAVES', str(waves))
-            monkeypatch.setenv('MEMB_HIP_PERSISTENT', '2' if persistent else '0')   # 2 = persistent whatever the batch size
             reader = native.Reader(path)
+            reader.set_option('persistent', 2 if persistent else 0)   # 2 = decode_records_persistent whatever the batch size
             assert bits_equal(reader.rows_embedding(rows), expected), (bits, lanes, waves, persistent)
             wide = np.zeros((len(rows), 304), dtype=np.float32)
             reader.batch_embedding_into([reader.keys()[r] if r < 20000 else '?' for r in rows[:500]], wide[:500], 4)
@@ -858,8 +858,8 @@ def test_row_layouts_give_identical_rows(native, make_model, monkeypatch):
             for key, value in env.items():
                 monkeypatch.setenv(key, value)
             for persistent in ('2', '1', '0'):   # always persistent / by batch size / one tile per wavefront
-                monkeypatch.setenv('MEMB_HIP_PERSISTENT', persistent)
                 reader = native.Reader(path)
+                reader.set_option('persistent', int(persistent))
                 assert bits_equal(reader.rows_embedding(rows), expected), (bits, name, persistent)
                 device_rows = torch.from_numpy(dump.view(np.int32)).cuda()
                 assert bits_equal(reader.rows_embedding_device(device_rows).cpu().numpy(), expected_dump), (bits, name, persistent)
@@ -904,9 +904,9 @@ def test_randomized_models_and_batches(native, tmp_path, monkeypatch):
         builder.save(path)
 
         monkeypatch.setenv('MEMB_HIP_LANES', str(int(rng.choice([1, 2, 3, 4, 8, 8, 16, 32]))))
-        monkeypatch.setenv('MEMB_HIP_PERSISTENT', str(int(rng.integers(0, 3))))
         monkeypatch.setenv('MEMB_HIP_ROOT_BITS', str(int(rng.choice([1, 2, 4, 8, 11, 12]))))
         reader = native.Reader(path)
+        reader.set_option('persistent', int(rng.integers(0, 3)))
         checker = oracle.OracleReader(str(path))
 
         n = int(rng.choice([1, 2, 5, 64, 65, 300, 1500]))

@@ -36,8 +36,7 @@ run_in_ms = float(os.environ.get('AB3_RUN_IN_MS', '20'))
 cases = os.environ.get('AB3_CASES', 'sorted,random,100k').split(',')
 placement = int(os.environ.get('AB3_PLACEMENT', '0'))
 out_buffers = int(os.environ.get('AB3_OUT_BUFFERS', '0'))
-DEFAULTS = {'fine_lanes': int(os.environ.get('MEMB_HIP_FINE_LANES', '0')), 'union_split': int(os.environ.get('MEMB_HIP_UNION_SPLIT', '1')), 'tiles_per_wave': int(os.environ.get('MEMB_HIP_TILES_PER_WAVE', '0')), 'waves_per_block': 0,
-            'persistent': int(os.environ.get('MEMB_HIP_PERSISTENT', '1'))}
+DEFAULTS = {'fine_lanes': 0, 'union_split': 1, 'tiles_per_wave': 0, 'waves_per_block': 0, 'persistent': 1}
 
 print('package: %s   model: %d words, %d-bit seed %s %s   rounds %d x %d launches after %.0f ms run-in' % (
     os.path.dirname(memb_amd.__file__), n, bits, os.environ.get('AB3_SEED', '1234'), os.environ.get('AB3_DIST', 'normal'), rounds, reps, run_in_ms), flush=True)

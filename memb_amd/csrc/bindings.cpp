@@ -131,6 +131,14 @@ struct WordFiller {
         return workers;
     }
 
+    // The pool serves one batch at a time (start .. wait): whoever fills through it -- this filler or PackedFiller, which
+    // runs without the GIL -- holds this mutex meanwhile, and fills on its own thread when it cannot get it.
+    static std::mutex& poolMutex()
+    {
+        static std::mutex mutex;
+        return mutex;
+    }
+
     enum JobState : int { FILLED = 0, NEEDS_API = 1, TOO_LONG = 2 };
 
     // One job of the plan; returns its state (and, for TOO_LONG, the bytes it needs in *needed).
@@ -241,7 +249,6 @@ struct WordFiller {
         }
         const size_t count = static_cast<size_t>(PySequence_Fast_GET_SIZE(fast.ptr()));
         PyObject** items = PySequence_Fast_ITEMS(fast.ptr());
-        static std::mutex poolMutex;
         size_t bytesPerWord = 0;
         for (int attempt = 0; attempt < 48; ++attempt) {
             memb_hip_words_plan plan;
@@ -256,7 +263,7 @@ struct WordFiller {
                 batch.commit();
                 return 0;
             }
-            std::unique_lock<std::mutex> lock(poolMutex, std::try_to_lock);
+            std::unique_lock<std::mutex> lock(WordFiller::poolMutex(), std::try_to_lock);
             const bool pooled = DIRECT_STR_ACCESS && count >= 8192 && lock.owns_lock();
             bool clean = true;
             if (!pooled) {
@@ -347,7 +354,6 @@ struct PackedFiller {
             throw std::invalid_argument("offsets[n] lies beyond the end of the bytes");
         }
         size_t bytesPerWord = std::max<size_t>(1, (size_t(offsets[count]) - offsets[0] + count - 1) / count + 1);
-        static std::mutex poolMutex;
         for (int attempt = 0; attempt < 3; ++attempt) {
             const memb_hip_words_plan plan = batch.begin(count, bytesPerWord);
             // the longest job decides the region size (jobs are runs of job_words consecutive words)
@@ -380,7 +386,7 @@ struct PackedFiller {
                 }
                 std::memcpy(plan.bytes + size_t(job) * plan.job_bytes, blob + origin, offsets[last] - origin);
             };
-            std::unique_lock<std::mutex> lock(poolMutex, std::try_to_lock);
+            std::unique_lock<std::mutex> lock(WordFiller::poolMutex(), std::try_to_lock);
             if (count < 8192 || !lock.owns_lock()) {
                 for (size_t job = 0; job < plan.jobs; ++job) {
                     fillJob(job);

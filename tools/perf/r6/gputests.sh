@@ -4,7 +4,7 @@ set -o pipefail
 out=gpurun_out/r6_gputests
 mkdir -p $out
 export MEMB_SYNTH_DEVICE=0
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest.txt 2>&1 || { tail -40 $out/pytest.txt; exit 1; }
+timeout -k 10 900 python -m pytest tests -x -q -m gpu --capture=sys > $out/pytest.txt 2>&1 || { tail -40 $out/pytest.txt; exit 1; }
 tail -3 $out/pytest.txt
 timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 wc -c $out/bench.json

@@ -191,6 +191,9 @@ int memb_hip_ctx_get_info(const memb_hip_ctx* ctx, memb_hip_ctx_info* info);
  *                     1 = never, 2 = always
  *   "union_split"     1 (default) = a union of two models staged as row records runs decode_union_split
  *                     (the wavefront's word slots divided between the models), 0 = never (option of the FIRST model's context)
+ *   "union_fused"     1 (default) = memb_hip_decode_rows_union_device launches ONE kernel for its two to four models where they
+ *                     can share one; 0 = it returns MEMB_HIP_UNSUPPORTED and the caller launches per model, as for models that
+ *                     cannot (option of the FIRST model's context; tests compare the two paths)
  *   "host_expand"     1 (default) = centroid indices instead of fp32 rows over PCIe (host-buffer entry point), 0 = fp32 rows
  * Builds with -DMEMB_HIP_MEASURE (tools/perf/build_measure.py; never shipped) also accept "debug" and "lds_pad",
  * the measurement switches of hip_trained_kernels.h; the shipped library refuses them.

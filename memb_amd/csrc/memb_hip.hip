@@ -118,6 +118,7 @@ struct Switches {
                                    // always, 2 = decode_records_persistent whenever the layout allows (tests, measurements)
     uint32_t unionSplit = 1;       // option union_split: decode_union_split for pairs of models with row records:
                                    // 0 = never, 1 = whenever the pair qualifies
+    uint32_t unionFused = 1;       // option union_fused (of the FIRST model's context): 0 = no union kernel, the caller launches per model (tests)
     uint32_t tilesPerWave = 0;     // option tiles_per_wave: tiles a wavefront of the one-tile kernels decodes one after the
                                    // other: 0 = by rule (oneTileSteps), K = K (measurements)
     uint32_t fineLanes = 0;        // option fine_lanes: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
@@ -933,8 +934,8 @@ int launchTrainedUnion(
     size_t ld, hipStream_t stream, bool average)
 {
     // (MEMB_HIP_UNSUPPORTED is not an error, but memb_hip_last_error() says which condition it was)
-    if (count < 2 || count > UNION_MAX_MODELS || envUint("MEMB_HIP_UNION_FUSED", 1) == 0) {
-        return fail(MEMB_HIP_UNSUPPORTED, "union kernel: two to four models (or switched off by MEMB_HIP_UNION_FUSED=0)");
+    if (count < 2 || count > UNION_MAX_MODELS || (ctxs[0] && ctxs[0]->switches.unionFused == 0)) {
+        return fail(MEMB_HIP_UNSUPPORTED, "union kernel: two to four models (or switched off by the first context's option union_fused = 0)");
     }
     const memb_hip_ctx* first = ctxs[0];
     bool hasSub = false;
@@ -2194,6 +2195,8 @@ int option_set_checked(memb_hip_ctx* ctx, const char* name, uint64_t value)
         ctx->switches.tilesPerWave = static_cast<uint32_t>(value);
     } else if (key == "fine_lanes" && value <= 2) {
         ctx->switches.fineLanes = static_cast<uint32_t>(value);
+    } else if (key == "union_fused" && value <= 1) {
+        ctx->switches.unionFused = static_cast<uint32_t>(value);
     } else if (key == "union_split" && value <= 1) {
         ctx->switches.unionSplit = static_cast<uint32_t>(value);
     } else if (key == "persistent" && value <= 2) {

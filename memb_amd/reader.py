@@ -323,6 +323,6 @@ class Reader(BaseReader):
         return self._impl.info(int(batch_words))
 
     def set_option(self, name, value):
-        '''Tuning knob of the device context ('persistent', 'tiles_per_wave', 'waves_per_block', 'union_split',
+        '''Tuning knob of the device context ('persistent', 'tiles_per_wave', 'waves_per_block', 'union_split', 'union_fused',
         'host_expand': include/memb_hip.h, memb_hip_ctx_set_option); results never depend on them'''
         self._impl.set_option(str(name), int(value))

@@ -395,7 +395,7 @@ def test_omitted_default_scalars_on_device(native, tmp_path):
 
 def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
     # memb_hip_decode_rows_union_device: two trained models of one geometry decoded by one kernel that
-    # writes the merged rows whole. Same bits as one launch per reader (MEMB_HIP_UNION_FUSED=0) and as
+    # writes the merged rows whole. Same bits as one launch per reader (option union_fused = 0) and as
     # numpy's concatenation of the checker's rows; nibble and byte keys, two-level tables, batches
     # that end inside a tile, words missing from one or both models, a model paired with itself.
     import torch
@@ -417,9 +417,9 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
             batch = [pool[i] for i in rng.integers(0, len(pool), size=count)]
             batch[::11] = ['in neither'] * len(batch[::11])
             expected = np.concatenate([checker.batch_embedding(batch) for checker in checkers], axis=1)
-            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+            readers[0].set_option('union_fused', 1)
             fused = union.batch_embedding_device(batch).cpu().numpy()
-            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '0')
+            readers[0].set_option('union_fused', 0)
             separate = union.batch_embedding_device(batch).cpu().numpy()
             assert fused.shape == (count, 2 * dim)
             assert bits_equal(fused, expected), (first, second, count)
@@ -427,11 +427,11 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
             # the 'average' mode through the same kernel: numpy.mean of the checker's rows, bit for bit
             mean = native.ReadersUnion(readers, 'average')
             expected_mean = np.mean([checker.batch_embedding(batch) for checker in checkers], axis=0)
-            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+            readers[0].set_option('union_fused', 1)
             assert bits_equal(mean.batch_embedding_device(batch).cpu().numpy(), expected_mean), (first, second, count)
-            monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '0')
+            readers[0].set_option('union_fused', 0)
             assert bits_equal(mean.batch_embedding_device(batch).cpu().numpy(), expected_mean), (first, second, count)
-        monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
+        readers[0].set_option('union_fused', 1)
         twice = native.ReadersUnion([readers[0], readers[0]], 'concatenate').batch_embedding_device(words_a[:100])
         assert bits_equal(twice[:, :dim].cpu().numpy(), twice[:, dim:].cpu().numpy())
     # three and four readers through the same kernel (and five: no kernel, one launch per reader)
@@ -441,7 +441,6 @@ def test_union_concatenation_in_one_launch(native, make_model, monkeypatch):
     many_checkers = [oracle.OracleReader(path) for path, _ in models]
     pool = sorted(set().union(*[set(words[:1500]) for _, words in models]))
     batch = [pool[i] for i in np.random.default_rng(9).integers(0, len(pool), size=2500)] + ['nowhere']
-    monkeypatch.setenv('MEMB_HIP_UNION_FUSED', '1')
     for count in (3, 4, 5):
         rows = [checker.batch_embedding(batch) for checker in many_checkers[:count]]
         concatenated = native.ReadersUnion(many_readers[:count], 'concatenate').batch_embedding_device(batch)

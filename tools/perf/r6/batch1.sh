@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6, batch 1: decode_two_tiles (option persistent = 3) -- parity first, then against the rule's kernels:
+# Round 6, batch 1 (ran on commit 7d9a76a; the kernel and its option value are gone since: this file is the record of how it was measured):
+# decode_two_tiles (option persistent = 3) -- parity first, then against the rule's kernels:
 # key-order dump, shuffled dump, 100 000 rows (cached / nothing cached), blocks of 4 and 8.
 set -o pipefail
 out=gpurun_out/r6_batch1

@@ -169,6 +169,29 @@ def test_the_process_group_never_carries_data(native):
                 assert not used, (name, used)
 
 
+def test_recorded_counters_are_reported_only_for_the_tree_they_were_taken_on(monkeypatch):
+    """profiles/hbm_traffic.json carries the hash of the kernel sources its rocprofv3 passes ran on (collect_profiles.py);
+    bench.py quotes it for `configs[*].traffic_over_algorithmic` only from a tree with the same hash -- `stale` otherwise."""
+    sys.path.insert(0, REPO)
+    import bench
+    import bench_support
+    with open(os.path.join(REPO, 'profiles', 'hbm_traffic.json')) as f:
+        recorded = json.load(f)
+    assert len(recorded['_sources_sha16']) == 16 and recorded['_commit']
+    for workload in ('glove840b-300d-4bit-fullvocab', 'glove840b-300d-4bit-100k', 'fasttext2m-300d-6bit-fullvocab',
+                     'glove840b-300d-2bit-fullvocab', 'union-concat-500k', 'uniform-8bit-500k'):
+        assert recorded[workload] > 0, workload
+    monkeypatch.setattr(bench_support, 'sources_sha16', lambda: recorded['_sources_sha16'])
+    values, source = bench_support.recorded_traffic()
+    assert source == 'profiles/hbm_traffic.json' and values['glove840b-300d-4bit-100k'] == recorded['glove840b-300d-4bit-100k']
+    monkeypatch.setattr(bench_support, 'sources_sha16', lambda: '0' * 16)
+    assert bench_support.recorded_traffic() == ({}, 'stale')
+    # the hash covers the kernel sources and the header, nothing else
+    monkeypatch.undo()
+    first = bench_support.sources_sha16()
+    assert first == bench.sources_sha16() and len(first) == 16
+
+
 def test_gpus_are_counted_from_the_kfd_topology(tmp_path):
     sys.path.insert(0, REPO)
     import bench

@@ -43,7 +43,7 @@ __device__ __forceinline__ const uint8_t* uniformRegion(const UniformParams& p, 
 // RN(q + r * RN(1 / levels)) by another; correctly rounded inside a safe exponent range, the full division outside it;
 // bit-identical on 115 million operands on the CPU and in tests/test_gpu_parity.py::
 // test_uniform_division_for_every_level_count on the device -- and it bought nothing: 0.162-0.168 ms against
-// 0.158-0.165 for the 500 000-word dump, +3 % on 100 000 rows (tools/perf/r4/batch8.sh; twice the registers for the two
+// 0.158-0.165 for the 500 000-word dump, +3 % on 100 000 rows (round 4, batch 8, profiles/r04_experiments.txt; twice the registers for the two
 // paths). The vector ALU is not what these kernels wait for. Removed; the test stays.)
 __device__ __forceinline__ float dequant(float minValue, float range, uint32_t v, float levels)
 {

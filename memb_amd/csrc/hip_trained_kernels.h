@@ -209,7 +209,7 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 // Scalar registers the one-tile kernels may use (0 = no limit). The hardware admits wavefronts by scalar registers as well
 // as vector ones -- 800 per SIMD, .sgpr_count (this budget minus 2: VCC and friends are counted in) rounded up to 16, plus
 // 16 -- and without a limit the compiler takes 106 for these kernels: six wavefronts per SIMD where 61 vector registers
-// allow eight. 96 -> seven (memb_hip.hip: ONE_TILE_WAVES_PER_CU; DESIGN.md section 5.0 has the measurements of 80, 88 and none).
+// allow eight. 96 -> seven (memb_hip.hip: ONE_TILE_WAVES_PER_CU; HISTORY.md, "(r5) 5.0", has the measurements of 80, 88 and none).
 #ifndef MEMB_HIP_SGPRS
 #define MEMB_HIP_SGPRS 96
 #endif
@@ -221,7 +221,7 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 
 // The output burst of decode_records_persistent for nibble keys: its registers decide between five and six wavefronts per
 // SIMD (82 / 78 vector registers with bursts of 5 / 4 in the dense kernel), and the sixth is worth more than the fifth
-// piece of a burst in this kernel's class (57 000 - 131 000 rows; round 5, batch 24, tools/perf/r5/records_waves.sh:
+// piece of a burst in this kernel's class (57 000 - 131 000 rows; round 5, batch 24, profiles/r05_experiments.txt:
 // 100 000 rows with nothing cached -5.3 % for the 4-bit model, -7 % for the 2-bit one). Byte keys keep the burst of 5
 // (78 registers: six already; with 4 they would run seven and gain nothing: -4..+3 %).
 #ifndef MEMB_HIP_RECORDS_BURST_NIBBLE
@@ -229,7 +229,7 @@ __device__ __forceinline__ void unpackMeta(const TrainedParams& p, const LaneRol
 #endif
 
 // decode_records_persistent held to the vector registers of N wavefronts per SIMD (0 = the compiler's own 78-85: five, for
-// the nibble-key dense kernel). Measured with 6 (round 5, batch 23, tools/perf/r5/records_waves.sh): 12 bytes of scratch in
+// the nibble-key dense kernel). Measured with 6 (round 5, batch 23, profiles/r05_experiments.txt): 12 bytes of scratch in
 // that kernel, BASELINE configs[1] -0.9 % uncached and +5.6 % cached, the rest of its class -6..+1 %: not taken.
 #ifndef MEMB_HIP_RECORDS_WAVES
 #define MEMB_HIP_RECORDS_WAVES 0

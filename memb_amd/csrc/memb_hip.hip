@@ -124,7 +124,7 @@ struct Switches {
     uint32_t fineLanes = 0;        // option fine_lanes: the finer index of small batches: 0 = by rule (planTrained), 1 = never,
                                    // 2 = every batch of a model that has one (tests, measurements)
     uint32_t ldsPad = 0;           // option lds_pad, builds with -DMEMB_HIP_MEASURE only: unused LDS bytes added to every block of
-                                   // decode_trained (fewer resident wavefronts per CU from the same code: tools/perf/r5/residency.sh)
+                                   // decode_trained (fewer resident wavefronts per CU from the same code: round 5's residency table, profiles/r05_experiments.txt)
     bool hostExpand = true;        // option host_expand: centroid indices over PCIe for host buffers
     uint32_t sliceWords = ~0u;     // MEMB_HIP_SLICE_WORDS: staging slice (tests)
     uint32_t copyChunkRows = 0;    // MEMB_HIP_COPY_CHUNK_ROWS: rows per ring chunk (tests; 0 = by size)
@@ -232,7 +232,7 @@ struct TrainedGeometry {
 // count that, took 106: SIX per SIMD, 24 per CU, in rounds 1-4 (seen in round 5 as a step in the time of small batches at
 // exactly 24 x CUs tiles). hip_trained_kernels.h now holds these kernels to a budget (MEMB_HIP_SGPRS = 96: .sgpr_count 94,
 // no vector register more, 12 lane spills in the headline kernel's 2 000 instructions; 88 gives the same seven with 20): SEVEN per SIMD. A budget of 80 (8 per SIMD) costs two vector registers of spills, 3-5 % on the
-// chain of a small batch, and in blocks of eight +5 % on a key-order dump (tools/perf/r5/sgprs.sh, residency.sh);
+// chain of a small batch, and in blocks of eight +5 % on a key-order dump (round 5, batches 16-18, profiles/r05_experiments.txt);
 // tests/test_isa.py pins the seven.
 constexpr uint32_t ONE_TILE_WAVES_PER_CU = 28;
 constexpr uint32_t ORDER_UNKNOWN = 2;   // memb_hip_ctx::orderSeen before any very large batch
@@ -665,7 +665,7 @@ bool rowsUnordered(const memb_hip_ctx* ctx, bool callerSaysRandom)
 // (the context's device is current)
 // Which kernel by batch size (n words): a STATIC rule. t = tiles of the batch, R = 16 x CUs. Round 4 measured every
 // kernel of rounds 1-3 on every model kind (2-, 4-, 6-bit, byte-key 4-bit, Student-t 4-bit; key order, shuffled, 100 k,
-// 500 k; tools/perf/r4/batch1.sh, two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
+// 500 k; round 4, batch 1, profiles/r04_experiments.txt: two boxes, A/A floor 0.5 %) and kept what wins a BASELINE configuration by 3 %:
 //   decode_trained (one tile per wavefront at a time, 52-61 VGPRs; 28 wavefronts per CU by its scalar registers, 24 until
 //   round 5: ONE_TILE_WAVES_PER_CU) -- everything, except
 //   one round of the one-tile kernel (28 x CUs = 1.75 R) < t <= 4 R on row-record models: decode_records_persistent (24
@@ -678,7 +678,7 @@ bool rowsUnordered(const memb_hip_ctx* ctx, bool callerSaysRandom)
 // kind, both orders; eight against four): key-order dumps 4-bit -2.4 %, 2-bit -5.0 %, 6-bit -1.0 %, 9-bit-code 4-bit
 // -1.1 %, Student-t -2.5 %; the same batches SHUFFLED +3.4 %, -1.3 %, +3.6 %, +3.5 %, +2.9 %; 1 M random rows +2.0 %, -1.5 %,
 // +2.5 %, +2.7 %, +2.1 %: the rule takes the dump's side for every key format and says what it costs the other order
-// (DESIGN.md section 5.0 has the table). The 8-bit model runs blocks of eight at every size: chooseGeometry.
+// (HISTORY.md, "(r5) 5.0", has the table; DESIGN.md section 5.0 the rule as it stands). The 8-bit model runs blocks of eight at every size: chooseGeometry.
 // force: -1 = by the rule, 0 = one tile per wavefront, 1 = decode_records_persistent where the layout allows
 int planTrained(
     const memb_hip_ctx* ctx, size_t n, size_t ld, size_t colOff, const float* out, bool keysOut, TrainedPlan* plan, int force = -1,
@@ -691,7 +691,7 @@ int planTrained(
     // and registers; x CUs). Two edges of the rule are rounds:
     //   * the FINER INDEX while the batch's fine tiles all fit one round (28 600 words on 256 CUs): every wavefront has one
     //     tile, the batch is one chain of dependent steps per wavefront, and the finer index shortens its longest link, the
-    //     decode. Round 5 (tools/perf/r5/batch3.sh, fine_rule.sh, fine_rule_hbm.sh; the usual index = 100 %), 1 000 /
+    //     decode. Round 5 (batches 3, 17 and 26, profiles/r05_experiments.txt; the usual index = 100 %), 1 000 /
     //     10 000 / 20 000 / 28 000 rows: 4-bit -12 / -13 / -8 / -4 % with the same batch repeated, -15 / -8 / -5 / -5 % with
     //     nothing cached between launches; 6-bit -15 / -17 / -9 / -8 % and -21 / -13 / -9 / -8 %. One row more than a round
     //     and its second round costs what the index saved (30 000 rows +9 / +5 %; nothing cached: +16 / +12 %, 50 000 rows +33 %).

@@ -476,7 +476,7 @@ def test_several_batches_in_one_launch(native, make_model, storage, bits):
 def test_device_lookups_capture_into_a_hip_graph(native, make_model):
     """The device APIs only enqueue kernels on the caller's stream once a context has been used (first use stages the model
     and raises the kernels' LDS limit): a lookup, and several lookups in one launch, can be captured into a HIP graph and
-    replayed -- with new row ids in the same buffers -- bit for bit like eager launches (tools/perf/r5/graphs.py times it:
+    replayed -- with new row ids in the same buffers -- bit for bit like eager launches (round 5, batch 20, profiles/r05_experiments.txt, timed it:
     a replay saves nothing over an eager launch, the one launch for K lookups does)."""
     import torch
     path, words = make_model(6000, 300, 'trained', 4)

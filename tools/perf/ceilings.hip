@@ -161,7 +161,7 @@ __global__ void tiles_persistent(Params p)
     }
 }
 
-// Uniform-storage shapes (tools/perf/r4/store_patterns.py): a row's record is 20 pieces (320 B: {min, max} + 300 weights).
+// Uniform-storage shapes (round 4; patterns 8 and 9): a row's record is 20 pieces (320 B: {min, max} + 300 weights).
 //   ROWS = 1: one row per wavefront -- 20 lanes load the record, the row leaves as TWO stores (1 KiB + 176 B), exit
 //   ROWS = 8: eight rows per wavefront -- 160 pieces in three rounds, 9600 B as ten stores, exit
 template <int ROWS>
